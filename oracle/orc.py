@@ -1,0 +1,133 @@
+"""ctypes loader for oracle/liboracle.so (plain-C restatement, oracle/sjpeg_oracle.c).
+
+TEST INFRASTRUCTURE ONLY (tests/, __graft_entry__.smoke(), bench.py cpu_baseline).
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ORC_SO = os.path.join(_HERE, "liboracle.so")
+YUV_420, YUV_444, YUV_400 = 1, 3, 4
+_u8p = C.POINTER(C.c_uint8)
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE, "all"])
+
+
+class Oracle:
+    def __init__(self):
+        if not os.path.exists(ORC_SO):
+            build()
+        self.lib = lib = C.CDLL(ORC_SO, mode=os.RTLD_LOCAL | os.RTLD_NOW)
+        lib.orc_encode.restype = C.c_size_t
+        lib.orc_encode.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int,
+                                   C.POINTER(_u8p)]
+        lib.orc_encode_matrices.restype = C.c_size_t
+        lib.orc_encode_matrices.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                            C.c_void_p, C.c_int, C.c_int, C.POINTER(_u8p)]
+        lib.orc_scan_bits.restype = C.c_size_t
+        lib.orc_scan_bits.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                      C.c_int, C.POINTER(_u8p)]
+        lib.orc_scan_coeffs.restype = C.c_size_t
+        lib.orc_scan_coeffs.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                        C.c_void_p, C.c_int, C.c_void_p]
+        lib.orc_headers.restype = C.c_size_t
+        lib.orc_headers.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        lib.orc_free.argtypes = [C.c_void_p]
+        lib.orc_fdct.argtypes = [C.c_void_p, C.c_int]
+        lib.orc_get_samples.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                        C.c_int, C.c_void_p]
+        lib.orc_quality_matrices.argtypes = [C.c_float, C.c_void_p]
+        lib.orc_default_codes.argtypes = [C.c_void_p, C.c_void_p]
+
+    def _take(self, n, out):
+        if n == 0:
+            return None
+        data = C.string_at(out, n)
+        self.lib.orc_free(out)
+        return data
+
+    @staticmethod
+    def _img(rgb, stride):
+        rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+        return rgb, rgb.shape[1], rgb.shape[0], (stride if stride is not None else rgb.strides[0])
+
+    def quality_matrices(self, quality):
+        m = np.zeros((2, 64), np.uint8)
+        self.lib.orc_quality_matrices(quality, m.ctypes.data)
+        return m
+
+    def default_codes(self):
+        dc = np.zeros((2, 12), np.uint32)
+        ac = np.zeros((2, 256), np.uint32)
+        self.lib.orc_default_codes(dc.ctypes.data, ac.ctypes.data)
+        return dc, ac
+
+    def encode(self, rgb, quality=75.0, yuv_mode=YUV_420, stride=None):
+        rgb, w, h, stride = self._img(rgb, stride)
+        out = _u8p()
+        n = self.lib.orc_encode(rgb.ctypes.data, w, h, stride, quality, yuv_mode, C.byref(out))
+        return self._take(n, out)
+
+    def encode_matrices(self, rgb, quant, min_quant=None, q_bias=0x78, yuv_mode=YUV_420,
+                        stride=None):
+        rgb, w, h, stride = self._img(rgb, stride)
+        q = np.ascontiguousarray(quant, np.uint8).reshape(2, 64)
+        mq = None if min_quant is None else np.ascontiguousarray(min_quant, np.uint8).reshape(2, 64)
+        out = _u8p()
+        n = self.lib.orc_encode_matrices(rgb.ctypes.data, w, h, stride, q.ctypes.data,
+                                         mq.ctypes.data if mq is not None else None, q_bias,
+                                         yuv_mode, C.byref(out))
+        return self._take(n, out)
+
+    def scan_bits(self, rgb, quant, q_bias=0x78, yuv_mode=YUV_420, stride=None):
+        rgb, w, h, stride = self._img(rgb, stride)
+        q = np.ascontiguousarray(quant, np.uint8).reshape(2, 64)
+        out = _u8p()
+        n = self.lib.orc_scan_bits(rgb.ctypes.data, w, h, stride, yuv_mode, q.ctypes.data, q_bias,
+                                   C.byref(out))
+        return self._take(n, out)
+
+    def scan_coeffs(self, rgb, quant, q_bias=0x78, yuv_mode=YUV_420, stride=None):
+        rgb, w, h, stride = self._img(rgb, stride)
+        q = np.ascontiguousarray(quant, np.uint8).reshape(2, 64)
+        bw = 16 if yuv_mode == YUV_420 else 8
+        per = {YUV_420: 6, YUV_444: 3, YUV_400: 1}[yuv_mode]
+        nb = ((w + bw - 1) // bw) * ((h + bw - 1) // bw) * per
+        zz = np.zeros((nb, 64), np.int16)
+        n = self.lib.orc_scan_coeffs(rgb.ctypes.data, w, h, stride, yuv_mode, q.ctypes.data,
+                                     q_bias, zz.ctypes.data)
+        assert n == nb
+        return zz
+
+    def headers(self, w, h, yuv_mode, quant):
+        q = np.ascontiguousarray(quant, np.uint8).reshape(2, 64)
+        buf = np.zeros(1024, np.uint8)
+        n = self.lib.orc_headers(w, h, yuv_mode, q.ctypes.data, buf.ctypes.data)
+        return buf[:n].tobytes()
+
+    def fdct(self, blocks):
+        c = np.ascontiguousarray(blocks, np.int16).copy()
+        self.lib.orc_fdct(c.ctypes.data, c.size // 64)
+        return c
+
+    def get_samples(self, yuv_mode, rgb, mb_x, mb_y, stride=None):
+        rgb, w, h, stride = self._img(rgb, stride)
+        per = {YUV_420: 6, YUV_444: 3, YUV_400: 1}[yuv_mode]
+        out = np.zeros(per * 64, np.int16)
+        self.lib.orc_get_samples(yuv_mode, rgb.ctypes.data, w, h, stride, mb_x, mb_y,
+                                 out.ctypes.data)
+        return out
+
+
+_o = None
+
+
+def oracle() -> Oracle:
+    global _o
+    if _o is None:
+        _o = Oracle()
+    return _o

@@ -1,0 +1,88 @@
+// TEST INFRASTRUCTURE ONLY -- never linked into the product library.
+//
+// Thin extern "C" shim over the *real* reference encoder (webmproject/sjpeg),
+// compiled together with the reference's own sources where they lie under
+// /root/reference (see oracle/Makefile).  The resulting oracle/_ref/libsjpeg_ref.so
+// is (a) what pins oracle/sjpeg_oracle.c, (b) what generates tests/golden/, and
+// (c) the "reference" cpu_baseline leg of bench.py.  Nothing here restates
+// reference code: it only calls the reference's public API (src/sjpeg.h) and
+// the two linkable internal seams SURVEY.md §8c names (sjpegi.h:80-81,105-108).
+#include <stdint.h>
+#include <string.h>
+#include <string>
+
+#include "sjpeg.h"
+#include "sjpegi.h"
+
+namespace sjpeg {
+extern bool ForceSlowCImplementation;   // src/enc.cc:157-158
+}
+
+extern "C" {
+
+// sjpeg::Encode() with an EncoderParam assembled from plain scalars.
+// quant == NULL -> SetQuality(quality); else SetQuantization(quant, reduction).
+// Returns size (0 on failure); *out must be released with ref_free().
+size_t ref_encode_param(const uint8_t* rgb, int w, int h, int stride,
+                        float quality, int yuv_mode, int huffman, int adaptive,
+                        int trellis, const uint8_t* quant, float reduction,
+                        int limit_quant, int quant_bias, uint8_t** out) {
+  sjpeg::EncoderParam param(quality);
+  if (quant != nullptr) {
+    uint8_t m[2][64];
+    memcpy(m, quant, sizeof(m));
+    param.SetQuantization(m, reduction);
+  }
+  if (limit_quant) param.SetLimitQuantization(true);
+  param.yuv_mode = static_cast<SjpegYUVMode>(yuv_mode);
+  param.Huffman_compress = (huffman != 0);
+  param.adaptive_quantization = (adaptive != 0);
+  param.use_trellis = (trellis != 0);
+  if (quant_bias >= 0) param.quantization_bias = quant_bias;
+  return sjpeg::Encode(rgb, w, h, stride, param, out);
+}
+
+size_t ref_encode(const uint8_t* rgb, int w, int h, int stride, float quality,
+                  int method, int yuv_mode, uint8_t** out) {
+  return SjpegEncode(rgb, w, h, stride, out, quality, method,
+                     static_cast<SjpegYUVMode>(yuv_mode));
+}
+
+size_t ref_compress(const uint8_t* rgb, int w, int h, float quality,
+                    uint8_t** out) {
+  return SjpegCompress(rgb, w, h, quality, out);
+}
+
+void ref_free(uint8_t* p) { SjpegFreeBuffer(p); }
+
+// Stage seams (SURVEY.md §8c "Stage-level access").
+void ref_get_block(int yuv_mode, const uint8_t* rgb, int step, int16_t* out) {
+  sjpeg::GetBlockFunc(static_cast<SjpegYUVMode>(yuv_mode))(rgb, step, out);
+}
+void ref_fdct(int16_t* coeffs, int num_blocks) {
+  sjpeg::GetFdct()(coeffs, num_blocks);
+}
+void ref_force_slow_c(int on) { sjpeg::ForceSlowCImplementation = (on != 0); }
+
+void ref_quant_matrix(float quality, int for_chroma, uint8_t* m) {
+  SjpegQuantMatrix(quality, for_chroma != 0, m);
+}
+int ref_find_quantizer(const uint8_t* data, size_t size, uint8_t* quant) {
+  uint8_t q[2][64];
+  memset(q, 0, sizeof(q));
+  const int n = SjpegFindQuantizer(data, size, q);
+  memcpy(quant, q, sizeof(q));
+  return n;
+}
+int ref_dimensions(const uint8_t* data, size_t size, int* w, int* h, int* is420) {
+  return SjpegDimensions(data, size, w, h, is420) ? 1 : 0;
+}
+float ref_estimate_quality(const uint8_t* m, int for_chroma) {
+  return SjpegEstimateQuality(m, for_chroma != 0);
+}
+int ref_riskiness(const uint8_t* rgb, int w, int h, int stride, float* risk) {
+  return static_cast<int>(SjpegRiskiness(rgb, w, h, stride, risk));
+}
+uint32_t ref_version() { return SjpegVersion(); }
+
+}  // extern "C"

@@ -1,0 +1,118 @@
+"""ctypes loader for oracle/_ref/libsjpeg_ref.so (the REAL reference, see oracle/Makefile).
+
+TEST INFRASTRUCTURE ONLY: used by tests/, tests/golden/make_golden.py and bench.py's
+cpu_baseline leg.  Loaded RTLD_LOCAL so its SjpegEncode & co. never collide with the
+product library's same-named exports.
+"""
+import ctypes as C
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+REF_SO = os.path.join(_HERE, "_ref", "libsjpeg_ref.so")
+
+YUV_AUTO, YUV_420, YUV_SHARP, YUV_444, YUV_400 = range(5)
+_u8p = C.POINTER(C.c_uint8)
+
+
+def available() -> bool:
+    return os.path.exists(REF_SO)
+
+
+class Ref:
+    def __init__(self, path: str = REF_SO):
+        self.lib = lib = C.CDLL(path, mode=os.RTLD_LOCAL | os.RTLD_NOW)
+        lib.ref_encode.restype = C.c_size_t
+        lib.ref_encode.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float,
+                                   C.c_int, C.c_int, C.POINTER(_u8p)]
+        lib.ref_encode_param.restype = C.c_size_t
+        lib.ref_encode_param.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float,
+                                         C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                         C.c_float, C.c_int, C.c_int, C.POINTER(_u8p)]
+        lib.ref_compress.restype = C.c_size_t
+        lib.ref_compress.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.POINTER(_u8p)]
+        lib.ref_free.argtypes = [_u8p]
+        lib.ref_get_block.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        lib.ref_fdct.argtypes = [C.c_void_p, C.c_int]
+        lib.ref_force_slow_c.argtypes = [C.c_int]
+        lib.ref_quant_matrix.argtypes = [C.c_float, C.c_int, C.c_void_p]
+        lib.ref_find_quantizer.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+        lib.ref_find_quantizer.restype = C.c_int
+        lib.ref_dimensions.argtypes = [C.c_void_p, C.c_size_t] + [C.POINTER(C.c_int)] * 3
+        lib.ref_dimensions.restype = C.c_int
+        lib.ref_estimate_quality.argtypes = [C.c_void_p, C.c_int]
+        lib.ref_estimate_quality.restype = C.c_float
+        lib.ref_riskiness.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]
+        lib.ref_riskiness.restype = C.c_int
+
+    def _take(self, n, out):
+        if n == 0:
+            return None
+        data = C.string_at(out, n)
+        self.lib.ref_free(out)
+        return data
+
+    @staticmethod
+    def _img(rgb, stride):
+        rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+        h, w = rgb.shape[0], rgb.shape[1]
+        return rgb, w, h, (stride if stride is not None else rgb.strides[0])
+
+    def encode(self, rgb, quality=75.0, method=0, yuv_mode=YUV_420, stride=None):
+        """SjpegEncode() of the reference (src/api.cc:32-49)."""
+        rgb, w, h, stride = self._img(rgb, stride)
+        out = _u8p()
+        n = self.lib.ref_encode(rgb.ctypes.data, w, h, stride, quality, method, yuv_mode,
+                                C.byref(out))
+        return self._take(n, out)
+
+    def encode_param(self, rgb, quality=75.0, yuv_mode=YUV_420, huffman=False, adaptive=False,
+                     trellis=False, quant=None, reduction=100.0, limit_quant=False,
+                     quant_bias=-1, stride=None):
+        """sjpeg::Encode() with an EncoderParam (src/api.cc:183-191)."""
+        rgb, w, h, stride = self._img(rgb, stride)
+        q = None
+        if quant is not None:
+            q = np.ascontiguousarray(quant, dtype=np.uint8).reshape(2, 64)
+        out = _u8p()
+        n = self.lib.ref_encode_param(rgb.ctypes.data, w, h, stride, quality, yuv_mode,
+                                      int(huffman), int(adaptive), int(trellis),
+                                      q.ctypes.data if q is not None else None, reduction,
+                                      int(limit_quant), quant_bias, C.byref(out))
+        return self._take(n, out)
+
+    def compress(self, rgb, quality=75.0):
+        rgb, w, h, _ = self._img(rgb, None)
+        out = _u8p()
+        n = self.lib.ref_compress(rgb.ctypes.data, w, h, quality, C.byref(out))
+        return self._take(n, out)
+
+    def get_block(self, yuv_mode, rgb_ptr_arr, offset, step, nblocks):
+        out = np.zeros(nblocks * 64, np.int16)
+        self.lib.ref_get_block(yuv_mode, rgb_ptr_arr.ctypes.data + offset, step, out.ctypes.data)
+        return out
+
+    def fdct(self, coeffs):
+        c = np.ascontiguousarray(coeffs, dtype=np.int16).copy()
+        self.lib.ref_fdct(c.ctypes.data, c.size // 64)
+        return c
+
+    def quant_matrix(self, quality, for_chroma):
+        m = np.zeros(64, np.uint8)
+        self.lib.ref_quant_matrix(quality, int(for_chroma), m.ctypes.data)
+        return m
+
+    def find_quantizer(self, jpeg: bytes):
+        q = np.zeros((2, 64), np.uint8)
+        n = self.lib.ref_find_quantizer(jpeg, len(jpeg), q.ctypes.data)
+        return n, q
+
+
+_ref = None
+
+
+def ref() -> Ref:
+    global _ref
+    if _ref is None:
+        _ref = Ref()
+    return _ref

@@ -1,0 +1,613 @@
+/* TEST INFRASTRUCTURE ONLY -- see sjpeg_oracle.h.  Plain C99, scalar, single-threaded.
+ * A restatement of the reference's *plain-C* functions (the normative spec, SURVEY.md
+ * §0 fact 5), written from their described behaviour; each function cites file:line
+ * under /root/reference.  Never linked into, loaded by, or shipped with the product. */
+#include "sjpeg_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ---------------------------------------------------------------- constant tables */
+
+/* zig-zag scan position -> natural index (JPEG Figure A.6; src/quantize.cc:32-41) */
+const uint8_t orc_zigzag[64] = {
+  0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,
+  12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6,  7,  14, 21, 28,
+  35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51,
+  58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+
+/* JPEG Annex K.1 luminance / chrominance matrices (src/quantize.cc:57-75) */
+static const uint8_t kAnnexK1[2][64] = {
+  {16, 11, 10, 16, 24,  40,  51,  61,  12, 12, 14, 19, 26,  58,  60,  55,
+   14, 13, 16, 24, 40,  57,  69,  56,  14, 17, 22, 29, 51,  87,  80,  62,
+   18, 22, 37, 56, 68,  109, 103, 77,  24, 35, 55, 64, 81,  104, 113, 92,
+   49, 64, 78, 87, 103, 121, 120, 101, 72, 92, 95, 98, 112, 100, 103, 99},
+  {17, 18, 24, 47, 99, 99, 99, 99, 18, 21, 26, 66, 99, 99, 99, 99,
+   24, 26, 56, 99, 99, 99, 99, 99, 47, 66, 99, 99, 99, 99, 99, 99,
+   99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99,
+   99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99}};
+
+/* JPEG Annex K.3 Huffman specifications (src/entropy.cc:31-82): BITS then HUFFVAL */
+static const uint8_t kDcBits[2][16] = {
+  {0, 1, 5, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0},
+  {0, 3, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0}};
+static const uint8_t kDcVals[12] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11};
+static const uint8_t kAcBits[2][16] = {
+  {0, 2, 1, 3, 3, 2, 4, 3, 5, 5, 4, 4, 0, 0, 1, 125},
+  {0, 2, 1, 2, 4, 4, 3, 4, 7, 5, 4, 4, 0, 1, 2, 119}};
+static const uint8_t kAcVals[2][162] = {
+  {0x01, 0x02, 0x03, 0x00, 0x04, 0x11, 0x05, 0x12, 0x21, 0x31, 0x41, 0x06, 0x13, 0x51,
+   0x61, 0x07, 0x22, 0x71, 0x14, 0x32, 0x81, 0x91, 0xa1, 0x08, 0x23, 0x42, 0xb1, 0xc1,
+   0x15, 0x52, 0xd1, 0xf0, 0x24, 0x33, 0x62, 0x72, 0x82, 0x09, 0x0a, 0x16, 0x17, 0x18,
+   0x19, 0x1a, 0x25, 0x26, 0x27, 0x28, 0x29, 0x2a, 0x34, 0x35, 0x36, 0x37, 0x38, 0x39,
+   0x3a, 0x43, 0x44, 0x45, 0x46, 0x47, 0x48, 0x49, 0x4a, 0x53, 0x54, 0x55, 0x56, 0x57,
+   0x58, 0x59, 0x5a, 0x63, 0x64, 0x65, 0x66, 0x67, 0x68, 0x69, 0x6a, 0x73, 0x74, 0x75,
+   0x76, 0x77, 0x78, 0x79, 0x7a, 0x83, 0x84, 0x85, 0x86, 0x87, 0x88, 0x89, 0x8a, 0x92,
+   0x93, 0x94, 0x95, 0x96, 0x97, 0x98, 0x99, 0x9a, 0xa2, 0xa3, 0xa4, 0xa5, 0xa6, 0xa7,
+   0xa8, 0xa9, 0xaa, 0xb2, 0xb3, 0xb4, 0xb5, 0xb6, 0xb7, 0xb8, 0xb9, 0xba, 0xc2, 0xc3,
+   0xc4, 0xc5, 0xc6, 0xc7, 0xc8, 0xc9, 0xca, 0xd2, 0xd3, 0xd4, 0xd5, 0xd6, 0xd7, 0xd8,
+   0xd9, 0xda, 0xe1, 0xe2, 0xe3, 0xe4, 0xe5, 0xe6, 0xe7, 0xe8, 0xe9, 0xea, 0xf1, 0xf2,
+   0xf3, 0xf4, 0xf5, 0xf6, 0xf7, 0xf8, 0xf9, 0xfa},
+  {0x00, 0x01, 0x02, 0x03, 0x11, 0x04, 0x05, 0x21, 0x31, 0x06, 0x12, 0x41, 0x51, 0x07,
+   0x61, 0x71, 0x13, 0x22, 0x32, 0x81, 0x08, 0x14, 0x42, 0x91, 0xa1, 0xb1, 0xc1, 0x09,
+   0x23, 0x33, 0x52, 0xf0, 0x15, 0x62, 0x72, 0xd1, 0x0a, 0x16, 0x24, 0x34, 0xe1, 0x25,
+   0xf1, 0x17, 0x18, 0x19, 0x1a, 0x26, 0x27, 0x28, 0x29, 0x2a, 0x35, 0x36, 0x37, 0x38,
+   0x39, 0x3a, 0x43, 0x44, 0x45, 0x46, 0x47, 0x48, 0x49, 0x4a, 0x53, 0x54, 0x55, 0x56,
+   0x57, 0x58, 0x59, 0x5a, 0x63, 0x64, 0x65, 0x66, 0x67, 0x68, 0x69, 0x6a, 0x73, 0x74,
+   0x75, 0x76, 0x77, 0x78, 0x79, 0x7a, 0x82, 0x83, 0x84, 0x85, 0x86, 0x87, 0x88, 0x89,
+   0x8a, 0x92, 0x93, 0x94, 0x95, 0x96, 0x97, 0x98, 0x99, 0x9a, 0xa2, 0xa3, 0xa4, 0xa5,
+   0xa6, 0xa7, 0xa8, 0xa9, 0xaa, 0xb2, 0xb3, 0xb4, 0xb5, 0xb6, 0xb7, 0xb8, 0xb9, 0xba,
+   0xc2, 0xc3, 0xc4, 0xc5, 0xc6, 0xc7, 0xc8, 0xc9, 0xca, 0xd2, 0xd3, 0xd4, 0xd5, 0xd6,
+   0xd7, 0xd8, 0xd9, 0xda, 0xe2, 0xe3, 0xe4, 0xe5, 0xe6, 0xe7, 0xe8, 0xe9, 0xea, 0xf2,
+   0xf3, 0xf4, 0xf5, 0xf6, 0xf7, 0xf8, 0xf9, 0xfa}};
+
+/* ---------------------------------------------------------------- geometry */
+
+typedef struct {
+  int nb_comps, mcu_blocks, block_w, block_h;
+  int nb_blocks[3], quant_idx[3], sampling[3];
+} orc_layout;
+
+/* src/encoders.cc:32-88 */
+static int layout_for(int yuv_mode, orc_layout* L) {
+  memset(L, 0, sizeof(*L));
+  if (yuv_mode == ORC_YUV_420) {
+    L->nb_comps = 3; L->mcu_blocks = 6; L->block_w = L->block_h = 16;
+    L->nb_blocks[0] = 4; L->nb_blocks[1] = L->nb_blocks[2] = 1;
+    L->sampling[0] = 0x22; L->sampling[1] = L->sampling[2] = 0x11;
+    L->quant_idx[1] = L->quant_idx[2] = 1;
+  } else if (yuv_mode == ORC_YUV_444) {
+    L->nb_comps = 3; L->mcu_blocks = 3; L->block_w = L->block_h = 8;
+    L->nb_blocks[0] = L->nb_blocks[1] = L->nb_blocks[2] = 1;
+    L->sampling[0] = L->sampling[1] = L->sampling[2] = 0x11;
+    L->quant_idx[1] = L->quant_idx[2] = 1;
+  } else if (yuv_mode == ORC_YUV_400) {
+    L->nb_comps = 1; L->mcu_blocks = 1; L->block_w = L->block_h = 8;
+    L->nb_blocks[0] = 1; L->sampling[0] = 0x11;
+  } else {
+    return 0;
+  }
+  return 1;
+}
+
+/* ---------------------------------------------------------------- quantizer set-up */
+
+/* src/quantize.cc:77-82 -- libjpeg-6b quality mapping, float, floorf */
+float orc_qfactor(float q) {
+  float s;
+  if (q <= 0) s = 5000;
+  else if (q < 50) s = 5000 / q;
+  else if (q < 100) s = 2 * (100 - q);
+  else s = 0;
+  return floorf(s);
+}
+
+/* src/quantize.cc:88-96 -- float scale, +.5f, truncate, clamp to [1,255] */
+void orc_set_quant_matrix(const uint8_t in[64], float q_factor, uint8_t out[64]) {
+  const float scale = q_factor / 100.f;
+  for (int i = 0; i < 64; ++i) {
+    const int v = (int)(in[i] * scale + .5f);
+    out[i] = (uint8_t)(v < 1 ? 1 : v > 255 ? 255 : v);
+  }
+}
+
+/* src/enc.cc:100-104 */
+void orc_quality_matrices(float quality, uint8_t out[2][64]) {
+  const float qf = orc_qfactor(quality);
+  orc_set_quant_matrix(kAnnexK1[0], qf, out[0]);
+  orc_set_quant_matrix(kAnnexK1[1], qf, out[1]);
+}
+
+/* src/quantize.cc:115-148 -- reciprocal, bias and dead-zone threshold per coefficient.
+ * FP_BITS = 16, AC_BITS = 4 (src/sjpegi.h:165). */
+void orc_finalize_quant(orc_quantizer* q, int q_bias) {
+  for (int i = 0; i < 64; ++i) {
+    if (q->quant[i] < q->min_quant[i]) q->quant[i] = q->min_quant[i];
+  }
+  for (int i = 0; i < 64; ++i) {
+    const uint32_t v = q->quant[i];
+    uint32_t iq, b8;
+    if (v == 1) { iq = 0xffffu; b8 = 0x80; }       /* 1/1 does not fit 16 bits */
+    else { iq = ((1u << 16) + v / 2) / v; b8 = (i == 0) ? 0x80u : (uint32_t)q_bias; }
+    const uint16_t ibias = (uint16_t)((((b8 * v) << 4) + 128) >> 8);
+    const uint16_t iquant = (uint16_t)iq;
+    const uint16_t thresh = (uint16_t)(((1u << 20) + iquant - 1) / iquant - ibias);
+    q->iquant[i] = iquant;
+    q->bias[i] = ibias;
+    q->qthresh[i] = thresh;
+  }
+}
+
+/* ---------------------------------------------------------------- Huffman tables */
+
+/* src/entropy.cc:98-112 -- canonical code assignment, packed (code << 16) | length */
+int orc_build_huffman(const uint8_t bits[16], const uint8_t* syms, uint32_t* tab) {
+  uint32_t code = 0;
+  int total = 0;
+  for (int len = 1; len <= 16; ++len) {
+    for (int k = 0; k < bits[len - 1]; ++k) {
+      tab[*syms++] = (code << 16) | (uint32_t)len;
+      ++code;
+      ++total;
+    }
+    code <<= 1;
+  }
+  return total;
+}
+
+void orc_default_codes(uint32_t dc[2][12], uint32_t ac[2][256]) {
+  memset(dc, 0, 2 * 12 * sizeof(uint32_t));
+  memset(ac, 0, 2 * 256 * sizeof(uint32_t));
+  for (int c = 0; c < 2; ++c) {
+    orc_build_huffman(kDcBits[c], kDcVals, dc[c]);
+    orc_build_huffman(kAcBits[c], kAcVals[c], ac[c]);
+  }
+}
+
+/* ---------------------------------------------------------------- colour conversion */
+
+/* 16.16 fixed-point BT.601 full range; src/colors_rgb.cc:17-19,31-32,785-828.
+ * Y is level-shifted by -128 inside the rounding constant. */
+#define ORC_HALF (1 << 15)
+static int16_t luma_of(int r, int g, int b) {
+  return (int16_t)((19595 * r + 38469 * g + 7471 * b + ORC_HALF - (128 << 16)) >> 16);
+}
+static int16_t cb_of(int r, int g, int b, int shift, int rnd) {
+  return (int16_t)((-11059 * r - 21709 * g + 32768 * b + rnd) >> shift);
+}
+static int16_t cr_of(int r, int g, int b, int shift, int rnd) {
+  return (int16_t)((32768 * r - 27439 * g - 5329 * b + rnd) >> shift);
+}
+
+/* 8x8 pixels -> Y,U,V blocks (src/colors_rgb.cc:830-838) or Y only (:840-848) */
+static void block8_from_rgb(const uint8_t* p, int step, int16_t* out, int with_chroma) {
+  for (int y = 0; y < 8; ++y, p += step) {
+    for (int x = 0; x < 8; ++x) {
+      const int r = p[3 * x], g = p[3 * x + 1], b = p[3 * x + 2];
+      out[y * 8 + x] = luma_of(r, g, b);
+      if (with_chroma) {
+        out[64 + y * 8 + x] = cb_of(r, g, b, 16, ORC_HALF);
+        out[128 + y * 8 + x] = cr_of(r, g, b, 16, ORC_HALF);
+      }
+    }
+  }
+}
+
+/* 16x16 pixels -> Y0 Y1 Y2 Y3 U V (src/colors_rgb.cc:850-879): chroma is ONE transform
+ * of the 2x2 r/g/b sums with rounding HALF<<2 and shift 18. */
+static void mcu420_from_rgb(const uint8_t* p, int step, int16_t* out) {
+  for (int y = 0; y < 16; ++y) {
+    for (int x = 0; x < 16; ++x) {
+      const uint8_t* px = p + y * step + 3 * x;
+      const int blk = (y >> 3) * 2 + (x >> 3);
+      out[blk * 64 + (y & 7) * 8 + (x & 7)] = luma_of(px[0], px[1], px[2]);
+    }
+  }
+  for (int cy = 0; cy < 8; ++cy) {
+    for (int cx = 0; cx < 8; ++cx) {
+      const uint8_t* a = p + (2 * cy) * step + 6 * cx;
+      const uint8_t* b = a + step;
+      const int R = a[0] + a[3] + b[0] + b[3];
+      const int G = a[1] + a[4] + b[1] + b[4];
+      const int B = a[2] + a[5] + b[2] + b[5];
+      out[4 * 64 + cy * 8 + cx] = cb_of(R, G, B, 18, ORC_HALF << 2);
+      out[5 * 64 + cy * 8 + cx] = cr_of(R, G, B, 18, ORC_HALF << 2);
+    }
+  }
+}
+
+static int block_avg(const int16_t* b) {      /* src/encoders.cc:95-99 */
+  int s = 0;
+  for (int i = 0; i < 64; ++i) s += b[i];
+  return (s + 32) >> 6;
+}
+static void block_fill(int16_t* b, int v) {
+  for (int i = 0; i < 64; ++i) b[i] = (int16_t)v;
+}
+
+void orc_get_samples(int yuv_mode, const uint8_t* rgb, int W, int H, int stride,
+                     int mb_x, int mb_y, int16_t* out) {
+  orc_layout L;
+  if (!layout_for(yuv_mode, &L)) return;
+  const int bw = L.block_w, bh = L.block_h;
+  /* src/enc.cc:280-281,292: an MCU is "clipped" iff it is the partial last column/row */
+  const int clipped = (mb_y == H / bh) || (mb_x == W / bw);
+  const uint8_t* src = rgb + (ptrdiff_t)(3 * mb_x) * bw + (ptrdiff_t)mb_y * stride * bh;
+  int step = stride;
+  uint8_t tmp[16 * 16 * 3];
+  const int sub_w = W - mb_x * bw, sub_h = H - mb_y * bh;
+  if (clipped) {
+    /* src/colors_rgb.cc:1212-1232: copy the valid sub_w x sub_h corner, repeat the last
+     * valid column to the right, then the last (already widened) row downwards. */
+    const int vw = sub_w > bw ? bw : sub_w, vh = sub_h > bh ? bh : sub_h;
+    for (int y = 0; y < bh; ++y) {
+      const int sy = y < vh ? y : vh - 1;
+      for (int x = 0; x < bw; ++x) {
+        const int sx = x < vw ? x : vw - 1;
+        memcpy(tmp + (y * bw + x) * 3, src + (ptrdiff_t)sy * stride + 3 * sx, 3);
+      }
+    }
+    src = tmp;
+    step = 3 * bw;
+  }
+  if (yuv_mode == ORC_YUV_420) {
+    mcu420_from_rgb(src, step, out);
+    if (clipped) {
+      /* src/encoders.cc:107-125: luma blocks lying wholly outside the picture become
+       * flat at the average of a neighbouring real block. */
+      int dc = block_avg(out);
+      if (sub_w <= 8) block_fill(out + 64, dc);
+      if (sub_h <= 8) {
+        if (sub_w > 8) dc = block_avg(out + 64);
+        block_fill(out + 128, dc);
+        block_fill(out + 192, dc);
+      } else if (sub_w <= 8) {
+        block_fill(out + 192, block_avg(out + 128));
+      }
+    }
+  } else {
+    block8_from_rgb(src, step, out, yuv_mode == ORC_YUV_444);
+  }
+}
+
+/* ---------------------------------------------------------------- forward DCT */
+
+/* 16-bit fixed-point multiply used by the column pass: (a*b) >> 16 (src/fdct.cc:150) */
+static int32_t mulhi(int32_t a, int32_t b) { return (a * b) >> 16; }
+
+/* Column pass on one column (stride 8); src/fdct.cc:67-144 read with the plain-C
+ * macro set of :148-157.  int32 temporaries, int16 stores, exact operation order. */
+static void fdct_column(int16_t* c) {
+  const int32_t x0 = c[0], x1 = c[8], x2 = c[16], x3 = c[24];
+  const int32_t x4 = c[32], x5 = c[40], x6 = c[48], x7 = c[56];
+  /* first butterflies: differences d, sums s */
+  int32_t d07 = x0 - x7, s07 = x0 + x7;
+  int32_t d25 = x2 - x5, s25 = x2 + x5;
+  int32_t d34 = x3 - x4, s34 = x3 + x4;
+  int32_t d16 = x1 - x6, s16 = x1 + x6;
+  /* even part */
+  int32_t e_d = s07 - s34, e_s = s07 + s34;     /* (m7, m4) */
+  int32_t f_d = s16 - s25, f_s = s16 + s25;     /* (m6, m5) */
+  int32_t a = e_s * 8, b = f_s * 8;
+  c[0] = (int16_t)(a + b);
+  c[32] = (int16_t)(a - b);
+  e_d *= 8; f_d *= 8; d34 *= 8; d07 *= 8;
+  c[16] = (int16_t)(mulhi(27146, f_d) + e_d);   /* kTan2 */
+  c[48] = (int16_t)(mulhi(27146, e_d) - f_d);
+  /* odd part */
+  d25 *= 16; d16 *= 16;                          /* <<(3+1): k2Sqrt2 carries the extra 1/2 */
+  int32_t od = mulhi(d16 - d25, 23170);          /* m1 */
+  int32_t os = mulhi(d16 + d25, 23170);          /* m2 */
+  int32_t p3 = d34 - od, p1 = d34 + od;          /* butterfly(m3, m1) */
+  int32_t p0 = d07 - os, p2 = d07 + os;          /* butterfly(m0, m2) */
+  int32_t t3 = mulhi(p3, -21746) + p3 + 1;       /* kTan3m1, CORRECT_LSB */
+  int32_t t1 = mulhi(p1, 13036) + p2 + 1;        /* kTan1,   CORRECT_LSB */
+  int32_t t4 = mulhi(-21746, p0) + p0;
+  int32_t t5 = mulhi(13036, p2);
+  c[8] = (int16_t)t1;
+  c[24] = (int16_t)(p0 - t3);
+  c[40] = (int16_t)(p3 + t4);
+  c[56] = (int16_t)(t5 - p1);
+}
+
+/* Row pass; src/fdct.cc:174-209.  Products accumulate in 32 bits with wrap-around
+ * (computed unsigned here to keep the C well defined), arithmetic >>16, no rounding. */
+static int16_t descale(uint32_t v) { return (int16_t)((int32_t)v >> 16); }
+static void fdct_row(int16_t* r, const int16_t* t) {
+  const int32_t a0 = r[0] + r[7], b0 = r[0] - r[7];
+  const int32_t a1 = r[1] + r[6], b1 = r[1] - r[6];
+  const int32_t a2 = r[2] + r[5], b2 = r[2] - r[5];
+  const int32_t a3 = r[3] + r[4], b3 = r[3] - r[4];
+  const uint32_t C1 = t[0], C2 = t[1], C3 = t[2], C4 = t[3], C5 = t[4], C6 = t[5], C7 = t[6];
+  const uint32_t c0 = a0 + a3, c1 = a0 - a3, c2 = a1 + a2, c3 = a1 - a2;
+  const uint32_t B0 = b0, B1 = b1, B2 = b2, B3 = b3;
+  r[0] = descale(C4 * (c0 + c2));
+  r[4] = descale(C4 * (c0 - c2));
+  r[2] = descale(C2 * c1 + C6 * c3);
+  r[6] = descale(C6 * c1 - C2 * c3);
+  r[1] = descale(C1 * B0 + C3 * B1 + C5 * B2 + C7 * B3);
+  r[3] = descale(C3 * B0 - C7 * B1 - C1 * B2 - C5 * B3);
+  r[5] = descale(C5 * B0 - C1 * B1 + C7 * B2 + C3 * B3);
+  r[7] = descale(C7 * B0 - C5 * B1 + C3 * B2 - C1 * B3);
+}
+
+/* src/fdct.cc:28-35: cos(k*pi/16)/sqrt(2) in 15 bits, rows 1/7, 2/6, 3/5 pre-scaled */
+static const int16_t kRowTab[4][7] = {
+  {22725, 21407, 19266, 16384, 12873, 8867, 4520},
+  {31521, 29692, 26722, 22725, 17855, 12299, 6270},
+  {29692, 27969, 25172, 21407, 16819, 11585, 5906},
+  {26722, 25172, 22654, 19266, 15137, 10426, 5315}};
+static const uint8_t kRowSel[8] = {0, 1, 2, 3, 0, 3, 2, 1};     /* src/fdct.cc:599-606 */
+
+void orc_fdct(int16_t* coeffs, int num_blocks) {
+  for (int n = 0; n < num_blocks; ++n, coeffs += 64) {
+    for (int x = 0; x < 8; ++x) fdct_column(coeffs + x);
+    for (int y = 0; y < 8; ++y) fdct_row(coeffs + 8 * y, kRowTab[kRowSel[y]]);
+  }
+}
+
+/* ---------------------------------------------------------------- quantization */
+
+static int bit_length(uint32_t v) {   /* CalcLog2, src/sjpegi.h:186-197 */
+  int n = 0;
+  while (v) { ++n; v >>= 1; }
+  return n;
+}
+
+/* ((a + bias) * iquant >> 16) >> 4, src/quantize.cc:119-121 */
+static int quantize_abs(uint32_t a, uint32_t iq, uint32_t bias) {
+  return (int)((((a + bias) * iq) >> 16) >> 4);
+}
+
+int orc_quantize_block(const int16_t in[64], const orc_quantizer* q, int16_t zz[64]) {
+  for (int i = 1; i < 64; ++i) {
+    const int j = orc_zigzag[i];
+    const int v = in[j];
+    const uint32_t a = (uint32_t)(v < 0 ? -v : v);
+    int lvl = 0;
+    if (a >= q->qthresh[j]) lvl = quantize_abs(a, q->iquant[j], q->bias[j]);
+    zz[i] = (int16_t)(v < 0 ? -lvl : lvl);
+  }
+  const int d = in[0];
+  const int dc = d < 0 ? -quantize_abs((uint32_t)-d, q->iquant[0], q->bias[0])
+                       : quantize_abs((uint32_t)d, q->iquant[0], q->bias[0]);
+  zz[0] = (int16_t)dc;
+  return dc;
+}
+
+/* ---------------------------------------------------------------- bit writer */
+
+typedef struct {
+  uint8_t* buf;
+  size_t size, cap;
+  uint32_t acc;      /* pending bits, right-aligned */
+  int nbits;
+} orc_bw;
+
+static void bw_byte(orc_bw* w, uint8_t b) {
+  if (w->size == w->cap) {
+    w->cap = w->cap ? 2 * w->cap : 4096;
+    w->buf = (uint8_t*)realloc(w->buf, w->cap);
+  }
+  w->buf[w->size++] = b;
+}
+/* MSB-first; every completed 0xFF byte of entropy data is followed by 0x00
+ * (src/bit_writer.h:172-209). */
+static void bw_put(orc_bw* w, uint32_t bits, int n) {
+  while (n > 0) {
+    const int take = n > 8 ? 8 : n;      /* feed at most a byte at a time */
+    const uint32_t chunk = (bits >> (n - take)) & ((1u << take) - 1);
+    w->acc = (w->acc << take) | chunk;
+    w->nbits += take;
+    n -= take;
+    while (w->nbits >= 8) {
+      const uint8_t b = (uint8_t)(w->acc >> (w->nbits - 8));
+      bw_byte(w, b);
+      if (b == 0xff) bw_byte(w, 0x00);
+      w->nbits -= 8;
+    }
+    w->acc &= (1u << w->nbits) - 1;
+  }
+}
+static void bw_code(orc_bw* w, uint32_t packed) { bw_put(w, packed >> 16, (int)(packed & 0xff)); }
+/* src/bit_writer.cc:107-116: pad with 1-bits to a byte boundary */
+static void bw_pad(orc_bw* w) {
+  const int pad = (8 - w->nbits) & 7;
+  if (pad) bw_put(w, (1u << pad) - 1, pad);
+}
+static void bw_raw(orc_bw* w, const uint8_t* p, size_t n) {
+  for (size_t i = 0; i < n; ++i) bw_byte(w, p[i]);
+}
+
+/* ---------------------------------------------------------------- entropy coding */
+
+/* Emit one block given its quantized coefficients zz[] (zig-zag, zz[0] = DC value).
+ * DC: src/entropy.cc:133-150 (difference category + suffix); AC: src/entropy.cc:161-198
+ * with the run/level pairs src/quantize.cc:288-320 would have produced. */
+static void code_block(orc_bw* w, const int16_t zz[64], int* dc_pred,
+                       const uint32_t* dc_codes, const uint32_t* ac_codes) {
+  const int diff = zz[0] - *dc_pred;
+  *dc_pred = zz[0];
+  if (diff == 0) {
+    bw_code(w, dc_codes[0]);
+  } else {
+    const int n = bit_length((uint32_t)(diff < 0 ? -diff : diff));
+    const uint32_t suffix = (uint32_t)(diff < 0 ? diff - 1 : diff) & ((1u << n) - 1);
+    bw_code(w, dc_codes[n]);
+    bw_put(w, suffix, n);
+  }
+  int run = 0;
+  for (int i = 1; i < 64; ++i) {
+    const int v = zz[i];
+    if (v == 0) { ++run; continue; }
+    while (run >= 16) { bw_code(w, ac_codes[0xf0]); run -= 16; }
+    const uint32_t a = (uint32_t)(v < 0 ? -v : v);
+    const int n = bit_length(a);
+    const uint32_t suffix = (v < 0 ? ~a : a) & ((1u << n) - 1);
+    bw_code(w, ac_codes[(run << 4) | n]);
+    bw_put(w, suffix, n);
+    run = 0;
+  }
+  if (run > 0) bw_code(w, ac_codes[0x00]);      /* EOB iff last nonzero index < 63 */
+}
+
+/* ---------------------------------------------------------------- scan drivers */
+
+typedef struct {
+  orc_layout L;
+  orc_quantizer q[2];
+  int W, H, mb_w, mb_h;
+} orc_scan;
+
+static int scan_init(orc_scan* s, int W, int H, int yuv_mode, const uint8_t quant[2][64],
+                     const uint8_t* min_quant, int q_bias) {
+  if (!layout_for(yuv_mode, &s->L)) return 0;
+  if (W <= 0 || H <= 0 || W > 65535 || H > 65535) return 0;    /* src/enc.cc:406 */
+  for (int c = 0; c < 2; ++c) {
+    /* Encoder::SetQuantMatrices re-applies SetQuantMatrix(m, 100) (src/enc.cc:106-109):
+     * identity except that 0 becomes 1. */
+    orc_set_quant_matrix(quant[c], 100.f, s->q[c].quant);
+    if (min_quant) memcpy(s->q[c].min_quant, min_quant + 64 * c, 64);
+    else memset(s->q[c].min_quant, 1, 64);
+    orc_finalize_quant(&s->q[c], q_bias);
+  }
+  s->W = W; s->H = H;
+  s->mb_w = (W + s->L.block_w - 1) / s->L.block_w;     /* src/enc.cc:410-411 */
+  s->mb_h = (H + s->L.block_h - 1) / s->L.block_h;
+  return 1;
+}
+
+size_t orc_scan_coeffs(const uint8_t* rgb, int W, int H, int stride, int yuv_mode,
+                       const uint8_t quant[2][64], int q_bias, int16_t* zz) {
+  orc_scan s;
+  if (!scan_init(&s, W, H, yuv_mode, quant, NULL, q_bias)) return 0;
+  size_t nb = 0;
+  int16_t in[6 * 64];
+  for (int my = 0; my < s.mb_h; ++my) {
+    for (int mx = 0; mx < s.mb_w; ++mx) {
+      orc_get_samples(yuv_mode, rgb, W, H, stride, mx, my, in);
+      orc_fdct(in, s.L.mcu_blocks);
+      const int16_t* blk = in;
+      for (int c = 0; c < s.L.nb_comps; ++c) {
+        for (int i = 0; i < s.L.nb_blocks[c]; ++i, blk += 64, ++nb) {
+          orc_quantize_block(blk, &s.q[s.L.quant_idx[c]], zz + 64 * nb);
+        }
+      }
+    }
+  }
+  return nb;
+}
+
+/* The hot loop: src/enc.cc:276-307 */
+static void scan_emit(orc_scan* s, const uint8_t* rgb, int stride, int yuv_mode, orc_bw* w,
+                      uint32_t dc_codes[2][12], uint32_t ac_codes[2][256]) {
+  int pred[3] = {0, 0, 0};                       /* ResetDCs, src/entropy.cc:155-159 */
+  int16_t in[6 * 64], zz[64];
+  for (int my = 0; my < s->mb_h; ++my) {
+    for (int mx = 0; mx < s->mb_w; ++mx) {
+      orc_get_samples(yuv_mode, rgb, s->W, s->H, stride, mx, my, in);
+      orc_fdct(in, s->L.mcu_blocks);
+      const int16_t* blk = in;
+      for (int c = 0; c < s->L.nb_comps; ++c) {
+        const int t = s->L.quant_idx[c];
+        for (int i = 0; i < s->L.nb_blocks[c]; ++i, blk += 64) {
+          orc_quantize_block(blk, &s->q[t], zz);
+          code_block(w, zz, &pred[c], dc_codes[t], ac_codes[t]);
+        }
+      }
+    }
+  }
+  bw_pad(w);
+}
+
+size_t orc_scan_bits(const uint8_t* rgb, int W, int H, int stride, int yuv_mode,
+                     const uint8_t quant[2][64], int q_bias, uint8_t** out) {
+  orc_scan s;
+  *out = NULL;
+  if (!scan_init(&s, W, H, yuv_mode, quant, NULL, q_bias)) return 0;
+  uint32_t dc[2][12], ac[2][256];
+  orc_default_codes(dc, ac);
+  orc_bw w;
+  memset(&w, 0, sizeof(w));
+  scan_emit(&s, rgb, stride, yuv_mode, &w, dc, ac);
+  *out = w.buf;
+  return w.size;
+}
+
+/* ---------------------------------------------------------------- headers */
+
+static void put16(orc_bw* w, int v) { bw_byte(w, (uint8_t)(v >> 8)); bw_byte(w, (uint8_t)v); }
+
+static void write_headers(orc_bw* w, const orc_scan* s, int yuv_mode) {
+  /* SOI + JFIF APP0, v1.01, 1:1 aspect, no thumbnail (src/headers.cc:48-55) */
+  static const uint8_t app0[20] = {0xff, 0xd8, 0xff, 0xe0, 0, 16, 'J', 'F', 'I', 'F', 0,
+                                   1, 1, 0, 0, 1, 0, 1, 0, 0};
+  bw_raw(w, app0, sizeof(app0));
+  /* DQT: 8-bit tables in zig-zag order, ids 0 (and 1) (src/headers.cc:182-196) */
+  const int nq = (yuv_mode == ORC_YUV_400) ? 1 : 2;
+  put16(w, 0xffdb); put16(w, nq * 65 + 2);
+  for (int n = 0; n < nq; ++n) {
+    bw_byte(w, (uint8_t)n);
+    for (int i = 0; i < 64; ++i) bw_byte(w, s->q[n].quant[orc_zigzag[i]]);
+  }
+  /* SOF0 (src/headers.cc:202-219) */
+  put16(w, 0xffc0); put16(w, 3 * s->L.nb_comps + 8);
+  bw_byte(w, 8); put16(w, s->H); put16(w, s->W); bw_byte(w, (uint8_t)s->L.nb_comps);
+  for (int c = 0; c < s->L.nb_comps; ++c) {
+    bw_byte(w, (uint8_t)(c + 1)); bw_byte(w, (uint8_t)s->L.sampling[c]);
+    bw_byte(w, (uint8_t)s->L.quant_idx[c]);
+  }
+  /* DHT: one segment per table: DC-luma, AC-luma, DC-chroma, AC-chroma (src/headers.cc:221-238) */
+  const int nt = (s->L.nb_comps == 1) ? 1 : 2;
+  for (int c = 0; c < nt; ++c) {
+    put16(w, 0xffc4); put16(w, 3 + 16 + 12); bw_byte(w, (uint8_t)c);
+    bw_raw(w, kDcBits[c], 16); bw_raw(w, kDcVals, 12);
+    put16(w, 0xffc4); put16(w, 3 + 16 + 162); bw_byte(w, (uint8_t)(0x10 | c));
+    bw_raw(w, kAcBits[c], 16); bw_raw(w, kAcVals[c], 162);
+  }
+  /* SOS (src/headers.cc:242-258) */
+  put16(w, 0xffda); put16(w, 6 + 2 * s->L.nb_comps); bw_byte(w, (uint8_t)s->L.nb_comps);
+  for (int c = 0; c < s->L.nb_comps; ++c) {
+    bw_byte(w, (uint8_t)(c + 1)); bw_byte(w, (uint8_t)(s->L.quant_idx[c] * 0x11));
+  }
+  bw_byte(w, 0); bw_byte(w, 63); bw_byte(w, 0);
+}
+
+size_t orc_headers(int W, int H, int yuv_mode, const uint8_t quant[2][64], uint8_t* buf) {
+  orc_scan s;
+  if (!scan_init(&s, W, H, yuv_mode, quant, NULL, 0x78)) return 0;
+  orc_bw w;
+  memset(&w, 0, sizeof(w));
+  write_headers(&w, &s, yuv_mode);
+  memcpy(buf, w.buf, w.size);
+  free(w.buf);
+  return w.size;
+}
+
+size_t orc_encode_matrices(const uint8_t* rgb, int W, int H, int stride,
+                           const uint8_t quant[2][64], const uint8_t* min_quant,
+                           int q_bias, int yuv_mode, uint8_t** out) {
+  orc_scan s;
+  *out = NULL;
+  if (rgb == NULL || abs(stride) < 3 * W) return 0;          /* src/api.cc:35-36 */
+  if (!scan_init(&s, W, H, yuv_mode, quant, min_quant, q_bias)) return 0;
+  uint32_t dc[2][12], ac[2][256];
+  orc_default_codes(dc, ac);
+  orc_bw w;
+  memset(&w, 0, sizeof(w));
+  write_headers(&w, &s, yuv_mode);                          /* src/enc.cc:415-443 order */
+  scan_emit(&s, rgb, stride, yuv_mode, &w, dc, ac);
+  put16(&w, 0xffd9);                                        /* src/headers.cc:262-268 */
+  *out = w.buf;
+  return w.size;
+}
+
+size_t orc_encode(const uint8_t* rgb, int W, int H, int stride, float quality,
+                  int yuv_mode, uint8_t** out) {
+  uint8_t m[2][64];
+  orc_quality_matrices(quality, m);
+  return orc_encode_matrices(rgb, W, H, stride, m, NULL, 0x78, yuv_mode, out);
+}
+
+void orc_free(void* p) { free(p); }
