@@ -1,0 +1,151 @@
+/* sjpeg_hip.h -- C-ABI of the MI355X (gfx950) scan engine.
+ *
+ * This is the one device boundary of the library: the host encoder (include/sjpeg.h,
+ * sjpeg_amd/csrc/host_*.cc) prepares quantizers, Huffman codes and JFIF headers exactly
+ * as the reference does, then hands whole frames (or a batch of frames) to
+ * sjpeg_hip_encode_scan(), which replaces the reference's per-MCU hot loop
+ *
+ *     Encoder::SinglePassScan()            /root/reference/src/enc.cc:276-307
+ *       -> GetSamples()                    src/encoders.cc:170-182,206-215,239-248
+ *       -> fDCT_()                         src/fdct.cc:596-609
+ *       -> quantize_block_()               src/quantize.cc:288-320
+ *       -> GenerateDCDiffCode()/CodeBlock  src/entropy.cc:133-198
+ *       -> BitWriter::PutBits/FlushBits    src/bit_writer.h:172-209, bit_writer.cc:107-116
+ *
+ * with hand-written HIP kernels.  Plain pointers and sizes only: no C++ types, no torch
+ * types.  A binding for any host language (cgo, JNI, ctypes, N-API) binds exactly these
+ * symbols; see INTEGRATION.md.
+ *
+ * All functions return 0 on success or a negative SJPEG_HIP_E* code; the message of the
+ * last failure on the calling thread is available from sjpeg_hip_last_error().
+ * Nothing here ever falls back to a CPU implementation: without a usable gfx950 device
+ * the calls fail.
+ */
+#ifndef SJPEG_HIP_H_
+#define SJPEG_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SJPEG_HIP_ABI_VERSION 1
+
+enum {
+  SJPEG_HIP_OK = 0,
+  SJPEG_HIP_EINVAL = -1,      /* bad argument (null pointer, size, mode, ...)        */
+  SJPEG_HIP_ENODEV = -2,      /* no usable HIP device / runtime                      */
+  SJPEG_HIP_ENOMEM = -3,      /* device or host allocation failed                    */
+  SJPEG_HIP_ERUNTIME = -4,    /* a HIP call or kernel failed                         */
+  SJPEG_HIP_ECAPACITY = -5    /* caller's output slots are smaller than required     */
+};
+
+/* Values of SjpegYUVMode (include/sjpeg.h) that the scan engine codes directly. */
+enum { SJPEG_HIP_YUV420 = 1, SJPEG_HIP_YUV444 = 3, SJPEG_HIP_YUV400 = 4 };
+
+/* Everything the scan needs besides pixels, in the reference's own units.
+ * Index 0 = luma tables, 1 = chroma tables (reference quant_idx_, src/encoders.cc:37-39).
+ * iquant/bias are the reference Quantizer fields (src/sjpegi.h:228-235) in NATURAL order
+ * as produced by Encoder::FinalizeQuantMatrix (src/quantize.cc:123-148); qthresh is not
+ * needed: by construction (src/quantize.cc:144-145) a >= qthresh <=> QUANTIZE(a) > 0.
+ * dc_codes/ac_codes are the packed (code << 16) | length words of
+ * BuildHuffmanTable (src/entropy.cc:98-112). */
+typedef struct sjpeg_hip_scan_tables {
+  uint16_t iquant[2][64];
+  uint16_t bias[2][64];
+  uint32_t dc_codes[2][12];
+  uint32_t ac_codes[2][256];
+} sjpeg_hip_scan_tables;
+
+/* Opaque engine: one HIP device, cached device scratch.  Not thread-safe; use one engine
+ * per host thread (they may share a device). */
+typedef struct sjpeg_hip_engine sjpeg_hip_engine;
+
+int sjpeg_hip_abi_version(void);
+int sjpeg_hip_device_count(void);                 /* 0 when no device/runtime */
+const char* sjpeg_hip_last_error(void);
+
+int sjpeg_hip_engine_create(int device, sjpeg_hip_engine** engine);
+void sjpeg_hip_engine_destroy(sjpeg_hip_engine* engine);
+
+/* Worst-case size in bytes of ONE coded frame (header + stuffed entropy data + EOI):
+ * the minimum legal out_stride for sjpeg_hip_encode_scan().  Follows the reference's
+ * own bound of 2560 bytes per MCU (src/enc.cc:206-209).  0 on invalid arguments. */
+size_t sjpeg_hip_frame_bound(int width, int height, int yuv_mode, size_t header_size);
+
+/* Codes `nframes` frames that are RESIDENT IN DEVICE MEMORY, all with the same geometry
+ * and tables, each into its own complete JPEG byte stream:
+ *
+ *   d_out + f*out_stride : [ header bytes | entropy-coded segment | FF D9 ]
+ *   d_sizes[f]           : number of bytes written for frame f
+ *
+ *   d_rgb         packed 8-bit R,G,B; pixel (x,y) of frame f at
+ *                 d_rgb + f*frame_stride + y*row_stride + 3*x.  row_stride may be negative
+ *                 (bottom-up images, as the reference allows: src/api.cc:35-36).
+ *   header        HOST pointer to the bytes that precede the entropy segment (SOI..SOS,
+ *                 written by the host exactly like src/headers.cc); may be NULL/0, in which
+ *                 case each stream starts directly with entropy data.
+ *   append_eoi    non-zero: terminate each stream with FF D9 (src/headers.cc:262-268).
+ *   d_out         device buffer, nframes*out_stride bytes, out_stride >= frame_bound.
+ *   d_sizes       device array of nframes uint64.
+ *   stream        hipStream_t (as void*) on which everything is enqueued; NULL = default
+ *                 stream.  The call is asynchronous: results are valid once the stream
+ *                 has drained.
+ *
+ * The output is bit-identical to what the reference writes between (and including) the
+ * same header and EOI for the same pixels and tables. */
+int sjpeg_hip_encode_scan(sjpeg_hip_engine* engine,
+                          const void* d_rgb, int64_t row_stride, int64_t frame_stride,
+                          int width, int height, int yuv_mode, int nframes,
+                          const sjpeg_hip_scan_tables* tables,
+                          const void* header, size_t header_size, int append_eoi,
+                          void* d_out, size_t out_stride, uint64_t* d_sizes,
+                          void* stream);
+
+/* Stage taps for tests and profiling (same arguments as above where named alike).
+ * d_coeffs receives the quantized coefficients of every block in stream order,
+ * 64 int16 per block in zig-zag order, element 0 = quantized DC *value*
+ * (blocks per frame = mcu count * {6,3,1}).  Pure function of pixels + tables. */
+int sjpeg_hip_scan_coeffs(sjpeg_hip_engine* engine,
+                          const void* d_rgb, int64_t row_stride, int64_t frame_stride,
+                          int width, int height, int yuv_mode, int nframes,
+                          const sjpeg_hip_scan_tables* tables,
+                          int16_t* d_coeffs, void* stream);
+
+/* ---- host-side helpers (tiny CPU work, no device needed) -----------------------------
+ * They produce exactly what the reference's host code would hand to its hot loop, so that
+ * a non-C++ binding can drive sjpeg_hip_encode_scan() without re-implementing them. */
+
+/* quality -> the two 8-bit matrices (natural order) of Encoder::SetQuality
+ * (src/enc.cc:100-104, src/quantize.cc:77-96). */
+void sjpeg_hip_quality_matrices(float quality, uint8_t quant[2][64]);
+
+/* Encoder::FinalizeQuantMatrix for both tables (src/quantize.cc:123-148): clamps quant to
+ * min_quant (NULL = all ones) IN PLACE and fills tables->iquant / tables->bias.
+ * q_bias is the reference's quantization_bias (default 0x78). */
+void sjpeg_hip_finalize_quant(uint8_t quant[2][64], const uint8_t* min_quant /*[2][64]*/,
+                              int q_bias, sjpeg_hip_scan_tables* tables);
+
+/* Installs the default (JPEG Annex K.3) Huffman codes, as WriteDHT/InitCodes does for
+ * method 0 (src/headers.cc:221-222, src/entropy.cc:84-128). */
+void sjpeg_hip_default_huffman(sjpeg_hip_scan_tables* tables);
+
+/* Writes SOI+APP0, DQT, SOF0, DHT (default tables), SOS for a frame without metadata into
+ * buf (capacity cap), bytes identical to src/headers.cc.  Returns the size, 0 on error. */
+size_t sjpeg_hip_make_header(int width, int height, int yuv_mode, const uint8_t quant[2][64],
+                             uint8_t* buf, size_t cap);
+
+/* Duration in milliseconds of the dominant kernel (the fused colour+fDCT+quant+entropy
+ * kernel) in the most recent sjpeg_hip_encode_scan() call on this engine, measured with
+ * HIP events on the caller's stream.  Timing is recorded only after
+ * sjpeg_hip_engine_set_timing(engine, 1).  Negative if unavailable.  Synchronises. */
+int sjpeg_hip_engine_set_timing(sjpeg_hip_engine* engine, int enable);
+float sjpeg_hip_engine_last_scan_ms(sjpeg_hip_engine* engine);
+float sjpeg_hip_engine_last_total_ms(sjpeg_hip_engine* engine);
+
+#ifdef __cplusplus
+}
+#endif
+#endif  /* SJPEG_HIP_H_ */

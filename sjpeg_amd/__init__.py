@@ -1,0 +1,255 @@
+"""sjpeg_amd -- Python binding (ctypes) of the MI355X-native sjpeg-compatible JPEG encoder.
+
+The product is the C/C++ library ``sjpeg_amd/csrc/libsjpeg_amd.so`` (public API
+``include/sjpeg.h``, device C-ABI ``include/sjpeg_hip.h``).  This module only binds those
+symbols -- it contains no encoder logic and no CPU fallback: if the shared library is not
+built, importing the binding raises; if no gfx950 device is present, every encode call fails.
+
+torch is used (optionally) for device memory and streams only.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libsjpeg_amd.so")
+
+YUV_AUTO, YUV_420, YUV_SHARP, YUV_444, YUV_400 = range(5)
+
+_u8p = C.POINTER(C.c_uint8)
+
+
+class ScanTables(C.Structure):
+    """struct sjpeg_hip_scan_tables (include/sjpeg_hip.h)."""
+    _fields_ = [("iquant", (C.c_uint16 * 64) * 2),
+                ("bias", (C.c_uint16 * 64) * 2),
+                ("dc_codes", (C.c_uint32 * 12) * 2),
+                ("ac_codes", (C.c_uint32 * 256) * 2)]
+
+
+class SjpegError(RuntimeError):
+    pass
+
+
+def build(verbose: bool = False) -> str:
+    """Compile the HIP/C++ library in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    subprocess.check_call(["make", "-C", CSRC] + ([] if verbose else ["-s"]))
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: run `make -C sjpeg_amd/csrc` "
+                          "(or __graft_entry__.build()); there is no pure-Python fallback")
+    L = C.CDLL(LIB_PATH, mode=os.RTLD_LOCAL | os.RTLD_NOW)
+    L.SjpegVersion.restype = C.c_uint32
+    L.SjpegHipLastError.restype = C.c_char_p
+    L.SjpegEncode.restype = C.c_size_t
+    L.SjpegEncode.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(_u8p), C.c_float,
+                              C.c_int, C.c_int]
+    L.SjpegCompress.restype = C.c_size_t
+    L.SjpegCompress.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.POINTER(_u8p)]
+    L.SjpegFreeBuffer.argtypes = [_u8p]
+    L.SjpegDimensions.restype = C.c_bool
+    L.SjpegDimensions.argtypes = [C.c_void_p, C.c_size_t] + [C.POINTER(C.c_int)] * 3
+    L.SjpegFindQuantizer.restype = C.c_int
+    L.SjpegFindQuantizer.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+    L.SjpegEstimateQuality.restype = C.c_float
+    L.SjpegEstimateQuality.argtypes = [C.c_void_p, C.c_bool]
+    L.SjpegQuantMatrix.argtypes = [C.c_float, C.c_bool, C.c_void_p]
+    L.sjpeg_hip_abi_version.restype = C.c_int
+    L.sjpeg_hip_device_count.restype = C.c_int
+    L.sjpeg_hip_last_error.restype = C.c_char_p
+    L.sjpeg_hip_engine_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+    L.sjpeg_hip_engine_destroy.argtypes = [C.c_void_p]
+    L.sjpeg_hip_frame_bound.restype = C.c_size_t
+    L.sjpeg_hip_frame_bound.argtypes = [C.c_int, C.c_int, C.c_int, C.c_size_t]
+    L.sjpeg_hip_encode_scan.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int,
+                                        C.c_int, C.c_int, C.c_int, C.POINTER(ScanTables),
+                                        C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t,
+                                        C.c_void_p, C.c_void_p]
+    L.sjpeg_hip_scan_coeffs.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int,
+                                        C.c_int, C.c_int, C.c_int, C.POINTER(ScanTables),
+                                        C.c_void_p, C.c_void_p]
+    L.sjpeg_hip_quality_matrices.argtypes = [C.c_float, C.c_void_p]
+    L.sjpeg_hip_finalize_quant.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(ScanTables)]
+    L.sjpeg_hip_default_huffman.argtypes = [C.POINTER(ScanTables)]
+    L.sjpeg_hip_make_header.restype = C.c_size_t
+    L.sjpeg_hip_make_header.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]
+    L.sjpeg_hip_engine_set_timing.argtypes = [C.c_void_p, C.c_int]
+    L.sjpeg_hip_engine_last_scan_ms.restype = C.c_float
+    L.sjpeg_hip_engine_last_scan_ms.argtypes = [C.c_void_p]
+    L.sjpeg_hip_engine_last_total_ms.restype = C.c_float
+    L.sjpeg_hip_engine_last_total_ms.argtypes = [C.c_void_p]
+    _lib = L
+    return L
+
+
+EXPORTED_C_SYMBOLS = [
+    # include/sjpeg.h (extern "C" part)
+    "SjpegVersion", "SjpegCompress", "SjpegEncode", "SjpegFreeBuffer", "SjpegDimensions",
+    "SjpegFindQuantizer", "SjpegEstimateQuality", "SjpegQuantMatrix", "SjpegHipLastError",
+    # include/sjpeg_hip.h
+    "sjpeg_hip_abi_version", "sjpeg_hip_device_count", "sjpeg_hip_last_error",
+    "sjpeg_hip_engine_create", "sjpeg_hip_engine_destroy", "sjpeg_hip_frame_bound",
+    "sjpeg_hip_encode_scan", "sjpeg_hip_scan_coeffs", "sjpeg_hip_quality_matrices",
+    "sjpeg_hip_finalize_quant", "sjpeg_hip_default_huffman", "sjpeg_hip_make_header",
+    "sjpeg_hip_engine_set_timing", "sjpeg_hip_engine_last_scan_ms",
+    "sjpeg_hip_engine_last_total_ms",
+]
+
+
+# ---------------------------------------------------------------- host API (sjpeg.h)
+
+def last_error() -> str:
+    return (lib().SjpegHipLastError() or b"").decode()
+
+
+def SjpegEncode(rgb: np.ndarray, quality: float = 75.0, method: int = 0,
+                yuv_mode: int = YUV_420, stride=None):
+    """SjpegEncode() of include/sjpeg.h on a host image (H, W, 3) uint8.  Returns bytes or None."""
+    rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+    h, w = rgb.shape[0], rgb.shape[1]
+    out = _u8p()
+    base = rgb.ctypes.data
+    if stride is None:
+        stride = rgb.strides[0]
+    elif stride < 0:
+        base = rgb.ctypes.data + (h - 1) * (-stride)     # first row = last in memory
+    n = lib().SjpegEncode(base, w, h, stride, C.byref(out), quality, method, yuv_mode)
+    if n == 0:
+        return None
+    data = C.string_at(out, n)
+    lib().SjpegFreeBuffer(out)
+    return data
+
+
+# ---------------------------------------------------------------- device C-ABI (sjpeg_hip.h)
+
+def device_count() -> int:
+    return lib().sjpeg_hip_device_count()
+
+
+def make_tables(quality=None, quant=None, min_quant=None, q_bias=0x78):
+    """(ScanTables, final quant[2][64]) exactly as the reference's host code prepares them."""
+    L = lib()
+    q = np.zeros((2, 64), np.uint8)
+    if quant is None:
+        L.sjpeg_hip_quality_matrices(float(quality), q.ctypes.data)
+    else:
+        q[:] = np.asarray(quant, np.uint8).reshape(2, 64)
+    t = ScanTables()
+    mq = None
+    if min_quant is not None:
+        mq = np.ascontiguousarray(min_quant, np.uint8).reshape(2, 64)
+    L.sjpeg_hip_finalize_quant(q.ctypes.data, mq.ctypes.data if mq is not None else None, q_bias,
+                               C.byref(t))
+    L.sjpeg_hip_default_huffman(C.byref(t))
+    return t, q
+
+
+def make_header(w, h, yuv_mode, quant) -> bytes:
+    buf = np.zeros(2048, np.uint8)
+    q = np.ascontiguousarray(quant, np.uint8).reshape(2, 64)
+    n = lib().sjpeg_hip_make_header(w, h, yuv_mode, q.ctypes.data, buf.ctypes.data, buf.size)
+    if n == 0:
+        raise SjpegError("sjpeg_hip_make_header failed")
+    return buf[:n].tobytes()
+
+
+def frame_bound(w, h, yuv_mode, header_size) -> int:
+    return lib().sjpeg_hip_frame_bound(w, h, yuv_mode, header_size)
+
+
+class Engine:
+    """sjpeg_hip_engine bound to one device; drives device-resident (torch) frames."""
+
+    def __init__(self, device: int = 0):
+        self._h = C.c_void_p()
+        rc = lib().sjpeg_hip_engine_create(device, C.byref(self._h))
+        if rc != 0:
+            raise SjpegError(f"sjpeg_hip_engine_create: {lib().sjpeg_hip_last_error().decode()}")
+        self.device = device
+
+    def close(self):
+        if self._h:
+            lib().sjpeg_hip_engine_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_timing(self, on: bool):
+        lib().sjpeg_hip_engine_set_timing(self._h, int(on))
+
+    def last_scan_ms(self) -> float:
+        return lib().sjpeg_hip_engine_last_scan_ms(self._h)
+
+    def last_total_ms(self) -> float:
+        return lib().sjpeg_hip_engine_last_total_ms(self._h)
+
+    @staticmethod
+    def _stream():
+        import torch
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def encode_frames(self, frames, tables: ScanTables, header: bytes, yuv_mode: int,
+                      out=None, sizes=None, out_stride=None, append_eoi=True):
+        """frames: torch.uint8 CUDA tensor [F, H, W, 3] (contiguous rows).  Returns
+        (out [F, out_stride] uint8 CUDA tensor, sizes [F] int64 CUDA tensor).  Asynchronous
+        on the current torch stream."""
+        import torch
+        assert frames.is_cuda and frames.dtype == torch.uint8 and frames.dim() == 4
+        f, h, w, _ = frames.shape
+        if out_stride is None:
+            out_stride = frame_bound(w, h, yuv_mode, len(header))
+        if out is None:
+            out = torch.empty((f, out_stride), dtype=torch.uint8, device=frames.device)
+        if sizes is None:
+            sizes = torch.zeros(f, dtype=torch.int64, device=frames.device)
+        rc = lib().sjpeg_hip_encode_scan(self._h, frames.data_ptr(), frames.stride(1),
+                                         frames.stride(0), w, h, yuv_mode, f, C.byref(tables),
+                                         header, len(header), int(append_eoi), out.data_ptr(),
+                                         out_stride, sizes.data_ptr(), self._stream())
+        if rc != 0:
+            raise SjpegError(f"sjpeg_hip_encode_scan: {lib().sjpeg_hip_last_error().decode()}")
+        return out, sizes
+
+    def scan_coeffs(self, frames, tables: ScanTables, yuv_mode: int):
+        import torch
+        f, h, w, _ = frames.shape
+        px = 16 if yuv_mode == YUV_420 else 8
+        per = {YUV_420: 6, YUV_444: 3, YUV_400: 1}[yuv_mode]
+        nb = ((w + px - 1) // px) * ((h + px - 1) // px) * per
+        coeffs = torch.zeros((f, nb, 64), dtype=torch.int16, device=frames.device)
+        rc = lib().sjpeg_hip_scan_coeffs(self._h, frames.data_ptr(), frames.stride(1),
+                                         frames.stride(0), w, h, yuv_mode, f, C.byref(tables),
+                                         coeffs.data_ptr(), self._stream())
+        if rc != 0:
+            raise SjpegError(f"sjpeg_hip_scan_coeffs: {lib().sjpeg_hip_last_error().decode()}")
+        return coeffs
+
+
+def encode_device(frames, quality=75.0, yuv_mode=YUV_420, engine=None, quant=None):
+    """Convenience: list of JPEG byte strings for device-resident frames [F, H, W, 3]."""
+    import torch
+    eng = engine or Engine(frames.device.index or 0)
+    tables, q = make_tables(quality=quality, quant=quant)
+    f, h, w, _ = frames.shape
+    header = make_header(w, h, yuv_mode, q)
+    out, sizes = eng.encode_frames(frames, tables, header, yuv_mode)
+    torch.cuda.synchronize()
+    sz = sizes.cpu().numpy()
+    return [bytes(out[i, :int(sz[i])].cpu().numpy()) for i in range(f)]

@@ -1,0 +1,484 @@
+// host_api.cc -- the sjpeg-compatible public API (include/sjpeg.h) on top of the HIP scan
+// engine (include/sjpeg_hip.h).
+//
+// Mirrors the reference's host-side sequencing (/root/reference/src/api.cc:32-304,
+// src/enc.cc:391-448, src/encoders.cc:145-152,546-568): argument checks, parameter ->
+// method mapping, quantizer finalisation, header emission, then ONE call into the device
+// for everything the reference does per MCU.  There is no CPU implementation of the hot
+// path in this library: without a gfx950 device every encode fails.
+#include <stdlib.h>
+#include <string.h>
+
+#include <cmath>
+#include <new>
+#include <string>
+#include <vector>
+
+#include <hip/hip_runtime_api.h>
+
+#include "jpeg_host.h"
+#include "sjpeg.h"
+#include "sjpeg_hip.h"
+
+using sjpeg_host::HuffSpec;
+
+namespace {
+
+thread_local std::string g_api_error;
+
+bool Fail(const std::string& msg) {
+  g_api_error = msg;
+  return false;
+}
+bool FailHip(const char* what) {
+  g_api_error = std::string(what) + ": " + sjpeg_hip_last_error();
+  return false;
+}
+
+// reference defaults, src/enc.cc:42-49
+const float kDefaultQuality = 75.f;
+const int kDefaultBias = 0x78;
+const int kDefaultDeltaMaxLuma = 12;
+const int kDefaultDeltaMaxChroma = 1;
+
+struct DefaultMemory : public sjpeg::MemoryManager {
+  void* Alloc(size_t size) override { return malloc(size); }
+  void Free(void* const ptr) override { free(ptr); }
+} g_default_memory;
+
+// ---- sinks (reference: src/bit_writer.h:51-93, src/bit_writer.cc:30-87) ----------------
+
+// new[]-backed sink for the uint8_t** flavours: ownership passes to the caller, who
+// releases with delete[] / SjpegFreeBuffer (src/sjpeg.h:39-41).
+class NewArraySink : public sjpeg::ByteSink {
+ public:
+  NewArraySink() : buf_(nullptr), pos_(0), cap_(0) {}
+  ~NewArraySink() override { Reset(); }
+  bool Commit(size_t used, size_t extra, uint8_t** data) override {
+    pos_ += used;
+    if (pos_ + extra > cap_) {
+      size_t ncap = pos_ + extra + 256;
+      if (ncap < 2 * cap_) ncap = 2 * cap_;
+      uint8_t* nbuf = new (std::nothrow) uint8_t[ncap];
+      if (nbuf == nullptr) return false;
+      if (pos_ > 0) memcpy(nbuf, buf_, pos_);
+      delete[] buf_;
+      buf_ = nbuf;
+      cap_ = ncap;
+    }
+    *data = buf_ + pos_;
+    return true;
+  }
+  bool Finalize() override { return true; }
+  void Reset() override { delete[] buf_; buf_ = nullptr; pos_ = cap_ = 0; }
+  size_t Release(uint8_t** out) {
+    *out = buf_;
+    const size_t n = pos_;
+    buf_ = nullptr; pos_ = cap_ = 0;
+    return n;
+  }
+ private:
+  uint8_t* buf_;
+  size_t pos_, cap_;
+};
+
+template <class T> class ContainerSink : public sjpeg::ByteSink {
+ public:
+  explicit ContainerSink(T* c) : c_(c), pos_(0) {}
+  bool Commit(size_t used, size_t extra, uint8_t** data) override {
+    pos_ += used;
+    c_->resize(pos_ + extra);
+    if (c_->size() != pos_ + extra) return false;
+    *data = extra ? reinterpret_cast<uint8_t*>(&(*c_)[pos_]) : nullptr;
+    return true;
+  }
+  bool Finalize() override { c_->resize(pos_); return true; }
+  void Reset() override { c_->clear(); pos_ = 0; }
+ private:
+  T* const c_;
+  size_t pos_;
+};
+
+// ---- per-thread device context ------------------------------------------------------------
+
+struct DeviceContext {
+  sjpeg_hip_engine* engine = nullptr;
+  int device = 0;
+  void* d_in = nullptr;  size_t in_cap = 0;
+  void* d_out = nullptr; size_t out_cap = 0;
+  uint64_t* d_size = nullptr;
+  ~DeviceContext() {
+    if (engine == nullptr) return;
+    (void)hipSetDevice(device);
+    if (d_in) (void)hipFree(d_in);
+    if (d_out) (void)hipFree(d_out);
+    if (d_size) (void)hipFree(d_size);
+    sjpeg_hip_engine_destroy(engine);
+  }
+  bool Init() {
+    if (engine != nullptr) return true;
+    const char* env = getenv("SJPEG_HIP_DEVICE");
+    device = env ? atoi(env) : 0;
+    if (sjpeg_hip_engine_create(device, &engine) != 0) return FailHip("sjpeg_hip_engine_create");
+    if (hipMalloc(reinterpret_cast<void**>(&d_size), sizeof(uint64_t)) != hipSuccess) {
+      return Fail("hipMalloc(size word) failed");
+    }
+    return true;
+  }
+  bool Ensure(void** p, size_t* cap, size_t need) {
+    if (need <= *cap) return true;
+    if (*p) (void)hipFree(*p);
+    *p = nullptr; *cap = 0;
+    if (hipMalloc(p, need) != hipSuccess) return Fail("hipMalloc(" + std::to_string(need) + ") failed");
+    *cap = need;
+    return true;
+  }
+};
+thread_local DeviceContext g_ctx;
+
+}  // namespace
+
+namespace sjpeg {
+
+// The name and the friendship with EncoderParam come from the reference header; here it is
+// a one-shot plan: resolved parameters -> tables + header -> device call -> sink.
+struct Encoder {
+  Encoder(const uint8_t* rgb, int W, int H, int stride, ByteSink* sink, MemoryManager* mem)
+      : rgb_(rgb), W_(W), H_(H), stride_(stride), sink_(sink),
+        mem_(mem ? mem : &g_default_memory), q_bias_(kDefaultBias), method_(4),
+        yuv_mode_(SJPEG_YUV_420), passes_(1) {
+    memset(min_quant_, 1, sizeof(min_quant_));
+    SetQuality(kDefaultQuality);
+  }
+
+  void SetQuality(float q) {                       // reference: src/enc.cc:100-104
+    const float s = sjpeg_host::QualityToScale(q);
+    sjpeg_host::ScaleMatrix(sjpeg_host::kAnnexK1[0], s, quant_[0]);
+    sjpeg_host::ScaleMatrix(sjpeg_host::kAnnexK1[1], s, quant_[1]);
+  }
+  void SetMethod(int m) { method_ = m < 0 ? 0 : m > 8 ? 8 : m; }   // src/enc.cc:121-122
+  void SetYuvMode(SjpegYUVMode m) { yuv_mode_ = m; }
+
+  // reference: Encoder::InitFromParam, src/api.cc:145-181
+  void InitFromParam(const EncoderParam& p) {
+    sjpeg_host::ScaleMatrix(p.quant_[0], 100.f, quant_[0]);        // src/enc.cc:106-109
+    sjpeg_host::ScaleMatrix(p.quant_[1], 100.f, quant_[1]);
+    if (p.use_min_quant_) {
+      sjpeg_host::MinMatrix(p.min_quant_[0], p.min_quant_tolerance_, min_quant_[0]);
+      sjpeg_host::MinMatrix(p.min_quant_[1], p.min_quant_tolerance_, min_quant_[1]);
+    } else {
+      memset(min_quant_, 1, sizeof(min_quant_));
+    }
+    int method = p.Huffman_compress ? 1 : 0;
+    if (p.adaptive_quantization) method += 3;
+    if (p.use_trellis) method = (method == 4) ? 7 : (method == 6) ? 8 : method;
+    SetMethod(method);
+    q_bias_ = p.quantization_bias;
+    meta_.iccp = p.iccp; meta_.exif = p.exif; meta_.app_markers = p.app_markers;
+    meta_.xmp = p.xmp; meta_.xmp_split = p.xmp_split_point;
+    passes_ = p.passes < 1 ? 1 : p.passes > 20 ? 20 : p.passes;
+    yuv_mode_ = p.yuv_mode;
+  }
+
+  bool Run();
+
+ private:
+  const uint8_t* rgb_;
+  int W_, H_, stride_;
+  ByteSink* sink_;
+  MemoryManager* mem_;
+  uint8_t quant_[2][64], min_quant_[2][64];
+  int q_bias_, method_;
+  SjpegYUVMode yuv_mode_;
+  int passes_;
+  sjpeg_host::Metadata meta_;
+};
+
+bool Encoder::Run() {
+  sink_->Reset();                                                   // src/enc.cc:90
+  if (W_ > 65535 || H_ > 65535) return Fail("dimension > 65535");   // src/enc.cc:406
+  int mode;
+  switch (yuv_mode_) {
+    case SJPEG_YUV_420: mode = SJPEG_HIP_YUV420; break;
+    case SJPEG_YUV_444: mode = SJPEG_HIP_YUV444; break;
+    case SJPEG_YUV_400: mode = SJPEG_HIP_YUV400; break;
+    case SJPEG_YUV_AUTO:
+    case SJPEG_YUV_SHARP:
+      return Fail("SJPEG_YUV_AUTO / SJPEG_YUV_SHARP are not available in this build "
+                  "(riskiness analysis and sharp-YUV conversion are host features outside "
+                  "the GPU hot path); pick 420, 444 or 400");
+    default: return Fail("unknown yuv_mode");                        // src/encoders.cc:553-567
+  }
+  if (method_ != 0) {
+    return Fail("compression method " + std::to_string(method_) + " is not available in this "
+                "build: only method 0 (Huffman_compress = false, adaptive_quantization = false) "
+                "runs on the GPU; no CPU fallback exists");
+  }
+  if (passes_ > 1) return Fail("multi-pass size/PSNR search is not available in this build");
+
+  // quantizers (src/enc.cc:394-397), standard Huffman tables (src/enc.cc:399)
+  sjpeg_hip_scan_tables tables;
+  memset(&tables, 0, sizeof(tables));
+  sjpeg_host::FinalizeQuantizer(quant_[0], min_quant_[0], q_bias_, 0, &tables);
+  sjpeg_host::FinalizeQuantizer(quant_[1], min_quant_[1], q_bias_, 1, &tables);
+  const HuffSpec* dc[2] = {&sjpeg_host::DefaultHuff(0, 0), &sjpeg_host::DefaultHuff(0, 1)};
+  const HuffSpec* ac[2] = {&sjpeg_host::DefaultHuff(1, 0), &sjpeg_host::DefaultHuff(1, 1)};
+  sjpeg_host::InstallCodes(dc, ac, mode == SJPEG_HIP_YUV400 ? 1 : 2, &tables);
+
+  // headers: SOI/APP0, metadata, DQT, SOF, DHT, SOS (src/enc.cc:415-443)
+  std::vector<uint8_t> header;
+  if (!sjpeg_host::AppendHeaders(W_, H_, mode, quant_, dc, ac, &meta_, &header)) {
+    return Fail("invalid metadata (EXIF > 64 KiB, ICC >= 256 chunks or XMP too large)");
+  }
+  // one host allocation goes through the caller's MemoryManager, and its failure is
+  // fatal, as in the reference (tests/unit_test.cc:373-454 rely on both).
+  uint8_t* const staged_header = static_cast<uint8_t*>(mem_->Alloc(header.size()));
+  if (staged_header == nullptr) return Fail("MemoryManager refused an allocation");
+  memcpy(staged_header, header.data(), header.size());
+  struct Guard {
+    MemoryManager* m; void* p;
+    ~Guard() { m->Free(p); }
+  } guard = {mem_, staged_header};
+
+  DeviceContext& ctx = g_ctx;
+  if (!ctx.Init()) return false;
+  if (hipSetDevice(ctx.device) != hipSuccess) return Fail("hipSetDevice failed");
+
+  // pixels -> device.  Rows keep their pitch; a bottom-up picture (negative stride) is
+  // copied as the memory block it is and addressed with a negative device stride.
+  const size_t pitch = static_cast<size_t>(stride_ < 0 ? -static_cast<long long>(stride_) : stride_);
+  const size_t row_bytes = 3 * static_cast<size_t>(W_);
+  const size_t dev_pitch = (row_bytes + 15) & ~static_cast<size_t>(15);
+  if (!ctx.Ensure(&ctx.d_in, &ctx.in_cap, dev_pitch * H_ + 64)) return false;
+  const uint8_t* lowest = stride_ < 0 ? rgb_ + static_cast<long long>(H_ - 1) * stride_ : rgb_;
+  if (hipMemcpy2D(ctx.d_in, dev_pitch, lowest, pitch, row_bytes, H_, hipMemcpyHostToDevice) != hipSuccess) {
+    return Fail("hipMemcpy2D(host -> device) failed");
+  }
+  const uint8_t* d_first = static_cast<const uint8_t*>(ctx.d_in);
+  long long d_stride = static_cast<long long>(dev_pitch);
+  if (stride_ < 0) { d_first += dev_pitch * (H_ - 1); d_stride = -d_stride; }
+
+  const size_t bound = sjpeg_hip_frame_bound(W_, H_, mode, header.size());
+  if (bound == 0 || !ctx.Ensure(&ctx.d_out, &ctx.out_cap, bound)) return false;
+  if (sjpeg_hip_encode_scan(ctx.engine, d_first, d_stride, 0, W_, H_, mode, 1, &tables,
+                            staged_header, header.size(), /*append_eoi=*/1, ctx.d_out, bound,
+                            ctx.d_size, nullptr) != 0) {
+    return FailHip("sjpeg_hip_encode_scan");
+  }
+  uint64_t size = 0;
+  if (hipMemcpy(&size, ctx.d_size, sizeof(size), hipMemcpyDeviceToHost) != hipSuccess) {
+    return Fail(std::string("device execution failed: ") + hipGetErrorString(hipGetLastError()));
+  }
+  if (size == 0) return Fail("internal: coded frame exceeded its bound");
+
+  // device -> sink, straight into the sink's own storage
+  uint8_t* dst = nullptr;
+  if (!sink_->Commit(0, size, &dst) || dst == nullptr) { sink_->Reset(); return Fail("sink refused the output"); }
+  if (hipMemcpy(dst, ctx.d_out, size, hipMemcpyDeviceToHost) != hipSuccess) {
+    sink_->Reset();
+    return Fail("hipMemcpy(device -> host) failed");
+  }
+  if (!sink_->Commit(size, 0, &dst) || !sink_->Finalize()) { sink_->Reset(); return Fail("sink failed"); }
+  return true;
+}
+
+// ---- EncoderParam (reference: src/api.cc:74-143) ---------------------------------------------
+
+EncoderParam::EncoderParam() : search_hook(nullptr), memory(nullptr) { Init(kDefaultQuality); }
+EncoderParam::EncoderParam(float quality_factor) : search_hook(nullptr), memory(nullptr) {
+  Init(quality_factor);
+}
+
+void EncoderParam::Init(float quality_factor) {
+  yuv_mode = SJPEG_YUV_AUTO;
+  Huffman_compress = true;
+  adaptive_quantization = true;
+  adaptive_bias = false;
+  use_trellis = false;
+  target_mode = TARGET_NONE;
+  target_value = 0;
+  passes = 1;
+  tolerance = 1.;
+  qmin = 0.;
+  qmax = 100.;
+  quantization_bias = kDefaultBias;
+  qdelta_max_luma = kDefaultDeltaMaxLuma;
+  qdelta_max_chroma = kDefaultDeltaMaxChroma;
+  use_min_quant_ = false;
+  min_quant_tolerance_ = 0;
+  memset(min_quant_, 0, sizeof(min_quant_));
+  SetQuality(quality_factor);
+}
+
+void EncoderParam::SetQuality(float quality_factor) {
+  const float s = sjpeg_host::QualityToScale(quality_factor);
+  sjpeg_host::ScaleMatrix(sjpeg_host::kAnnexK1[0], s, quant_[0]);
+  sjpeg_host::ScaleMatrix(sjpeg_host::kAnnexK1[1], s, quant_[1]);
+}
+
+void EncoderParam::SetQuantization(const uint8_t m[2][64], float reduction) {
+  if (reduction <= 1.f) reduction = 1.f;
+  if (m == nullptr) return;
+  for (int c = 0; c < 2; ++c) {
+    for (int i = 0; i < 64; ++i) {
+      // double arithmetic, as src/api.cc:115
+      const int v = static_cast<int>(m[c][i] * 100. / reduction + .5);
+      quant_[c][i] = static_cast<uint8_t>(v > 255 ? 255 : v < 1 ? 1 : v);
+    }
+  }
+}
+
+void EncoderParam::SetLimitQuantization(bool limit_quantization, int tolerance) {
+  use_min_quant_ = limit_quantization;
+  if (limit_quantization) SetMinQuantization(quant_, tolerance);
+}
+
+void EncoderParam::SetMinQuantization(const uint8_t m[2][64], int tolerance) {
+  use_min_quant_ = true;
+  memcpy(min_quant_[0], m[0], 64);
+  memcpy(min_quant_[1], m[1], 64);
+  min_quant_tolerance_ = tolerance < 0 ? 0 : tolerance > 100 ? 100 : tolerance;
+}
+
+void EncoderParam::ResetMetadata() {
+  iccp.clear(); exif.clear(); app_markers.clear(); xmp.clear();
+  xmp_split_point = 0u;
+}
+
+// ---- SearchHook defaults (reference: src/dichotomy.cc:41-75) ------------------------------
+
+bool SearchHook::Setup(const EncoderParam& param) {
+  for_size = (param.target_mode == EncoderParam::TARGET_SIZE);
+  target = param.target_value;
+  tolerance = param.tolerance / 100.;
+  qmin = (param.qmin < 0) ? 0 : param.qmin;
+  qmax = (param.qmax > 100) ? 100 : (param.qmax < param.qmin) ? param.qmin : param.qmax;
+  const float q0 = SjpegEstimateQuality(param.GetQuantMatrix(0), false);
+  q = q0 < qmin ? qmin : q0 > qmax ? qmax : q0;
+  value = 0;
+  pass = 0;
+  return true;
+}
+
+bool SearchHook::Update(float result) {
+  value = result;
+  if (std::fabs(value - target) < tolerance * target) return true;
+  if (value > target) qmax = q; else qmin = q;
+  const float last_q = q;
+  q = (qmin + qmax) / 2.;
+  return std::fabs(q - last_q) < 0.15;
+}
+
+void SearchHook::NextMatrix(int idx, uint8_t dst[64]) {
+  sjpeg_host::ScaleMatrix(sjpeg_host::kAnnexK1[idx], sjpeg_host::QualityToScale(q), dst);
+}
+
+// ---- entry points (reference: src/api.cc:183-304) ---------------------------------------------
+
+bool Encode(const uint8_t* rgb, int width, int height, int stride,
+            const EncoderParam& param, ByteSink* sink) {
+  if (rgb == nullptr || sink == nullptr) return Fail("null argument");
+  if (width <= 0 || height <= 0 || std::abs(stride) < 3 * width) return Fail("bad dimensions or stride");
+  Encoder enc(rgb, width, height, stride, sink, param.memory);
+  enc.InitFromParam(param);
+  return enc.Run();
+}
+
+size_t Encode(const uint8_t* rgb, int width, int height, int stride,
+              const EncoderParam& param, uint8_t** out_data) {
+  if (out_data == nullptr) return 0;
+  NewArraySink sink;
+  if (!Encode(rgb, width, height, stride, param, &sink)) return 0;
+  return sink.Release(out_data);
+}
+
+bool Encode(const uint8_t* rgb, int width, int height, int stride,
+            const EncoderParam& param, std::string* output) {
+  if (output == nullptr) return false;
+  output->clear();
+  ContainerSink<std::string> sink(output);
+  return Encode(rgb, width, height, stride, param, &sink);
+}
+
+std::shared_ptr<ByteSink> MakeByteSink(std::string* output) {
+  return std::shared_ptr<ByteSink>(new (std::nothrow) ContainerSink<std::string>(output));
+}
+template<> std::shared_ptr<ByteSink> MakeByteSink(std::vector<uint8_t>* output) {
+  return std::shared_ptr<ByteSink>(new (std::nothrow) ContainerSink<std::vector<uint8_t> >(output));
+}
+
+}  // namespace sjpeg
+
+// ---- plain-C entry points (reference: src/api.cc:32-67) ---------------------------------------
+
+extern "C" {
+
+uint32_t SjpegVersion() { return SJPEG_VERSION; }
+
+const char* SjpegHipLastError() { return g_api_error.c_str(); }
+
+size_t SjpegEncode(const uint8_t* rgb, int width, int height, int stride, uint8_t** out_data,
+                   float quality, int method, SjpegYUVMode yuv_mode) {
+  if (rgb == nullptr || out_data == nullptr) return 0;
+  if (width <= 0 || height <= 0 || std::abs(stride) < 3 * width) return 0;
+  *out_data = nullptr;
+  NewArraySink sink;
+  sjpeg::Encoder enc(rgb, width, height, stride, &sink, nullptr);
+  enc.SetYuvMode(yuv_mode);
+  enc.SetQuality(quality);
+  enc.SetMethod(method);
+  if (!enc.Run()) return 0;
+  return sink.Release(out_data);
+}
+
+size_t SjpegCompress(const uint8_t* rgb, int width, int height, float quality, uint8_t** out_data) {
+  return SjpegEncode(rgb, width, height, 3 * width, out_data, quality, 4, SJPEG_YUV_AUTO);
+}
+
+void SjpegFreeBuffer(const uint8_t* buffer) { delete[] buffer; }
+
+// ---- C-ABI host helpers declared in sjpeg_hip.h --------------------------------------------
+
+void sjpeg_hip_quality_matrices(float quality, uint8_t quant[2][64]) {
+  const float s = sjpeg_host::QualityToScale(quality);
+  sjpeg_host::ScaleMatrix(sjpeg_host::kAnnexK1[0], s, quant[0]);
+  sjpeg_host::ScaleMatrix(sjpeg_host::kAnnexK1[1], s, quant[1]);
+}
+
+void sjpeg_hip_finalize_quant(uint8_t quant[2][64], const uint8_t* min_quant, int q_bias,
+                              sjpeg_hip_scan_tables* tables) {
+  uint8_t ones[64];
+  memset(ones, 1, sizeof(ones));
+  for (int c = 0; c < 2; ++c) {
+    uint8_t m[64];
+    sjpeg_host::ScaleMatrix(quant[c], 100.f, m);          // 0 -> 1, as src/enc.cc:106-109
+    memcpy(quant[c], m, 64);
+    sjpeg_host::FinalizeQuantizer(quant[c], min_quant ? min_quant + 64 * c : ones, q_bias, c, tables);
+  }
+}
+
+void sjpeg_hip_default_huffman(sjpeg_hip_scan_tables* tables) {
+  const HuffSpec* dc[2] = {&sjpeg_host::DefaultHuff(0, 0), &sjpeg_host::DefaultHuff(0, 1)};
+  const HuffSpec* ac[2] = {&sjpeg_host::DefaultHuff(1, 0), &sjpeg_host::DefaultHuff(1, 1)};
+  sjpeg_host::InstallCodes(dc, ac, 2, tables);
+}
+
+size_t sjpeg_hip_make_header(int width, int height, int yuv_mode, const uint8_t quant[2][64],
+                             uint8_t* buf, size_t cap) {
+  if (buf == nullptr || width <= 0 || height <= 0 || width > 65535 || height > 65535) return 0;
+  const HuffSpec* dc[2] = {&sjpeg_host::DefaultHuff(0, 0), &sjpeg_host::DefaultHuff(0, 1)};
+  const HuffSpec* ac[2] = {&sjpeg_host::DefaultHuff(1, 0), &sjpeg_host::DefaultHuff(1, 1)};
+  std::vector<uint8_t> h;
+  if (!sjpeg_host::AppendHeaders(width, height, yuv_mode, quant, dc, ac, nullptr, &h)) return 0;
+  if (h.size() > cap) return 0;
+  memcpy(buf, h.data(), h.size());
+  return h.size();
+}
+
+}  // extern "C"
+
+bool SjpegCompress(const uint8_t* rgb, int width, int height, float quality, std::string* output) {
+  sjpeg::EncoderParam param;
+  param.SetQuality(quality);
+  return sjpeg::Encode(rgb, width, height, 3 * width, param, output);
+}
