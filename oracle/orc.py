@@ -17,6 +17,13 @@ def build():
     subprocess.check_call(["make", "-s", "-C", _HERE, "all"])
 
 
+class Quantizer(C.Structure):
+    """orc_quantizer (oracle/sjpeg_oracle.h) == reference struct Quantizer minus codes_."""
+    _fields_ = [("quant", C.c_uint8 * 64), ("min_quant", C.c_uint8 * 64),
+                ("iquant", C.c_uint16 * 64), ("qthresh", C.c_uint16 * 64),
+                ("bias", C.c_uint16 * 64)]
+
+
 class Oracle:
     def __init__(self):
         if not os.path.exists(ORC_SO):
@@ -42,6 +49,15 @@ class Oracle:
                                         C.c_int, C.c_void_p]
         lib.orc_quality_matrices.argtypes = [C.c_float, C.c_void_p]
         lib.orc_default_codes.argtypes = [C.c_void_p, C.c_void_p]
+        lib.orc_finalize_quant.argtypes = [C.POINTER(Quantizer), C.c_int]
+
+    def finalize_quant(self, quant64, min_quant64=None, q_bias=0x78) -> Quantizer:
+        q = Quantizer()
+        q.quant[:] = list(np.asarray(quant64, np.uint8).reshape(64))
+        mq = np.ones(64, np.uint8) if min_quant64 is None else np.asarray(min_quant64, np.uint8)
+        q.min_quant[:] = list(mq.reshape(64))
+        self.lib.orc_finalize_quant(C.byref(q), q_bias)
+        return q
 
     def _take(self, n, out):
         if n == 0:

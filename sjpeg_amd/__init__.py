@@ -47,6 +47,12 @@ def lib() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    try:
+        # When torch is around it must come first: it ships its own HIP runtime, and one
+        # process must hold exactly one (device pointers and streams are shared with torch).
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} is missing: run `make -C sjpeg_amd/csrc` "
                           "(or __graft_entry__.build()); there is no pure-Python fallback")

@@ -1,0 +1,170 @@
+"""CPU-side tests of the product library: it loads, exports every symbol the headers declare,
+its host-side preparation (quantizers, codes, headers, JPEG tools) equals the oracle's /
+golden vectors, and without a GPU the encode path FAILS (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import sjpeg_amd as sj
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_loads_and_exports_declared_symbols():
+    lib = sj.lib()
+    assert lib.SjpegVersion() == 0x000101
+    assert lib.sjpeg_hip_abi_version() == 1
+    declared = set()
+    for hdr in ("include/sjpeg_hip.h", "include/sjpeg.h"):
+        text = open(os.path.join(ROOT, hdr)).read()
+        text = text.split("namespace sjpeg")[0]                   # C part only
+        declared |= set(re.findall(r"\b(sjpeg_hip_[a-z_0-9]+|Sjpeg[A-Za-z]+)\s*\(", text))
+    declared -= {"SjpegYUVMode"}
+    assert declared, "header parse failed"
+    assert declared == set(sj.EXPORTED_C_SYMBOLS), declared ^ set(sj.EXPORTED_C_SYMBOLS)
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
+def test_cxx_api_symbols_present():
+    import subprocess
+    out = subprocess.check_output(["nm", "-D", "--defined-only", "-C", sj.LIB_PATH]).decode()
+    for sym in ("sjpeg::Encode(unsigned char const*, int, int, int, sjpeg::EncoderParam const&, sjpeg::ByteSink*)",
+                "sjpeg::Encode(unsigned char const*, int, int, int, sjpeg::EncoderParam const&, unsigned char**)",
+                "sjpeg::EncoderParam::EncoderParam(float)", "sjpeg::EncoderParam::SetQuantization",
+                "sjpeg::EncoderParam::SetLimitQuantization", "sjpeg::MakeByteSink",
+                "sjpeg::SearchHook::Update(float)"):
+        assert sym in out, sym
+
+
+@pytest.mark.parametrize("q", [0, 1, 10, 49.5, 50, 75, 90, 93, 99, 100])
+def test_quantizer_tables_match_oracle(oracle, q):
+    t, quant = sj.make_tables(quality=q)
+    want = oracle.quality_matrices(q)
+    assert (quant == want).all()
+    for c in range(2):
+        fq = oracle.finalize_quant(want[c])
+        assert list(t.iquant[c]) == list(fq.iquant)
+        assert list(t.bias[c]) == list(fq.bias)
+
+
+def test_min_quant_and_bias(oracle):
+    rng = np.random.RandomState(3)
+    m = rng.randint(1, 256, (2, 64)).astype(np.uint8)
+    mq = rng.randint(1, 64, (2, 64)).astype(np.uint8)
+    t, quant = sj.make_tables(quant=m, min_quant=mq, q_bias=0x33)
+    for c in range(2):
+        fq = oracle.finalize_quant(m[c], mq[c], 0x33)
+        assert list(quant[c]) == list(fq.quant)
+        assert list(t.iquant[c]) == list(fq.iquant) and list(t.bias[c]) == list(fq.bias)
+
+
+def test_default_huffman_codes_match_oracle(oracle):
+    t, _ = sj.make_tables(quality=75)
+    dc, ac = oracle.default_codes()
+    assert (np.array(t.dc_codes) == dc).all()
+    assert (np.array(t.ac_codes) == ac).all()
+
+
+@pytest.mark.parametrize("mode", [1, 3, 4])
+@pytest.mark.parametrize("dims", [(1, 1), (3840, 2160), (65535, 65535), (17, 13)])
+def test_header_bytes_match_oracle(oracle, mode, dims):
+    _, quant = sj.make_tables(quality=83)
+    assert sj.make_header(dims[0], dims[1], mode, quant) == oracle.headers(dims[0], dims[1], mode, quant)
+
+
+def test_header_is_prefix_of_golden(golden_small):
+    key = "test128|128x128|420|q75|m0"
+    _, quant = sj.make_tables(quality=75)
+    h = sj.make_header(128, 128, 1, quant)
+    assert golden_small[key][:len(h)] == h
+
+
+def test_frame_bound():
+    assert sj.frame_bound(0, 10, 1, 0) == 0
+    assert sj.frame_bound(10, 10, 2, 0) == 0          # SHARP is not a scan mode
+    b = sj.frame_bound(3840, 2160, 1, 619)
+    assert b >= 32400 * 2560                          # reference bound per MCU (enc.cc:206-209)
+
+
+def test_jpeg_tools_on_golden(golden_small):
+    lib = sj.lib()
+    for key in ("test128|128x128|420|q75|m0", "struct|17x13|444|q95|m0", "noise|140x99|400|q10|m0"):
+        data = golden_small[key]
+        _, dims, mname, q, _ = key.split("|")
+        w0, h0 = (int(v) for v in dims.split("x"))
+        w, h, is420 = C.c_int(), C.c_int(), C.c_int()
+        assert lib.SjpegDimensions(data, len(data), C.byref(w), C.byref(h), C.byref(is420))
+        assert (w.value, h.value, is420.value) == (w0, h0, int(mname == "420"))
+        quant = np.zeros((2, 64), np.uint8)
+        n = lib.SjpegFindQuantizer(data, len(data), quant.ctypes.data)
+        assert n == (1 if mname == "400" else 2)
+        _, want = sj.make_tables(quality=float(q[1:]))
+        assert (quant[0] == want[0]).all()
+        if n == 2:
+            assert (quant[1] == want[1]).all()
+        # every truncation is safe and never reports success on nonsense (unit_test.cc:456-484)
+        for cut in range(0, min(len(data), 700), 7):
+            lib.SjpegDimensions(data[:cut], cut, C.byref(w), C.byref(h), None)
+            lib.SjpegFindQuantizer(data[:cut], cut, quant.ctypes.data)
+
+
+def test_quant_matrix_and_quality_estimate(oracle):
+    lib = sj.lib()
+    for q in (1, 25, 50, 75, 90, 100):
+        for chroma in (False, True):
+            m = np.zeros(64, np.uint8)
+            lib.SjpegQuantMatrix(float(q), chroma, m.ctypes.data)
+            assert (m == oracle.quality_matrices(q)[int(chroma)]).all()
+            est = lib.SjpegEstimateQuality(m.ctypes.data, chroma)
+            assert abs(est - q) <= 1 or q in (1, 100)     # unit_test.cc:625-646
+
+
+def test_live_jpeg_tools_vs_reference(reference, golden_small):
+    lib = sj.lib()
+    rng = np.random.RandomState(5)
+    for _ in range(30):
+        m = rng.randint(1, 256, 64).astype(np.uint8)
+        for chroma in (False, True):
+            a = lib.SjpegEstimateQuality(m.ctypes.data, chroma)
+            b = reference.lib.ref_estimate_quality(m.ctypes.data, int(chroma))
+            assert a == b
+
+
+def test_invalid_arguments_fail_cleanly():
+    # reference: unit_test.cc:165-193 -- all of these return 0 without touching the GPU
+    img = np.zeros((8, 8, 3), np.uint8)
+    lib = sj.lib()
+    out = C.POINTER(C.c_uint8)()
+    assert lib.SjpegEncode(None, 8, 8, 24, C.byref(out), 75.0, 0, 1) == 0
+    assert lib.SjpegEncode(img.ctypes.data, 0, 8, 24, C.byref(out), 75.0, 0, 1) == 0
+    assert lib.SjpegEncode(img.ctypes.data, 8, -1, 24, C.byref(out), 75.0, 0, 1) == 0
+    assert lib.SjpegEncode(img.ctypes.data, 8, 8, 23, C.byref(out), 75.0, 0, 1) == 0
+    assert lib.SjpegEncode(img.ctypes.data, 8, 8, -23, C.byref(out), 75.0, 0, 1) == 0
+    assert lib.SjpegEncode(img.ctypes.data, 8, 8, 24, None, 75.0, 0, 1) == 0
+
+
+def test_no_gpu_means_failure_not_fallback():
+    if sj.device_count() > 0:
+        pytest.skip("a GPU is present")
+    img = np.zeros((16, 16, 3), np.uint8)
+    assert sj.SjpegEncode(img, 75, 0, sj.YUV_420) is None
+    assert "no HIP device" in sj.last_error()
+    with pytest.raises(sj.SjpegError):
+        sj.Engine(0)
+
+
+def test_product_never_references_oracle():
+    # the shipped library and binding must not import, link or load anything under oracle/
+    for rel in ("sjpeg_amd/__init__.py", "sjpeg_amd/dist.py"):
+        assert "oracle" not in open(os.path.join(ROOT, rel)).read().replace("no pure-Python", "")
+    for f in os.listdir(os.path.join(ROOT, "sjpeg_amd", "csrc")):
+        if f.endswith((".cc", ".hip", ".h", "Makefile")):
+            text = open(os.path.join(ROOT, "sjpeg_amd", "csrc", f)).read()
+            assert "oracle/" not in text and "sjpeg_oracle" not in text, f
+    import subprocess
+    needed = subprocess.check_output(["readelf", "-d", sj.LIB_PATH]).decode()
+    assert "oracle" not in needed and "sjpeg_ref" not in needed
