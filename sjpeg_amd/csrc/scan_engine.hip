@@ -33,6 +33,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <new>
@@ -79,6 +80,7 @@ struct ScanArgs {
   uint32_t slot_words;
   uint32_t* seg_nbits;     // [nframes*nseg]
   int16_t* coeffs;         // optional tap (TAP instantiation only)
+  int ablate;              // profiling knob (env SJPEG_HIP_ABLATE): stop after phase 1/2/3; 0 = full
 };
 
 // LDS carve (bytes), all offsets multiples of 16
@@ -350,6 +352,7 @@ __global__ __launch_bounds__(kThreads) void scan_segments(const ScanArgs a) {
     }
   }
   __syncthreads();
+  if (a.ablate == 1) return;
 
   // ---- P2: one thread per block: fix-up, fDCT, quantize ---------------------------------
   const int ml = tid / BPM;                    // local MCU (0 = halo)
@@ -446,6 +449,8 @@ __global__ __launch_bounds__(kThreads) void scan_segments(const ScanArgs a) {
     }
   }
 
+  if (a.ablate == 2) { if (nz_lo + nz_hi + dc_val == 0x7fffffff) a.seg_nbits[0] = 1; return; }
+
   // ---- P3: entropy coding ----------------------------------------------------------------
   dcs[tid] = dc_val;
   __syncthreads();
@@ -493,6 +498,7 @@ __global__ __launch_bounds__(kThreads) void scan_segments(const ScanArgs a) {
   uint32_t total;
   const uint32_t start = wg_exclusive_scan(len, misc, &total);
   const uint32_t end = start + len;
+  if (a.ablate == 3) { if (tid == 0) a.seg_nbits[static_cast<size_t>(frame) * a.nseg + seg] = total; return; }
 
   // pass 2: emit into the LDS window, round by round (one round unless the segment
   // overflows the window); words are MSB-first, flushed coalesced to the segment's slot.
@@ -817,6 +823,7 @@ struct sjpeg_hip_engine {
   DevBuf<uint32_t> seg_words, seg_nbits, ubuf, chunk_ff;
   DevBuf<unsigned long long> seg_off, chunk_off;
   bool timing = false;
+  int ablate = 0;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   bool ev_valid = false;
 };
@@ -880,6 +887,7 @@ int prepare_scan(sjpeg_hip_engine* e, const void* d_rgb, int64_t row_stride, int
   a->slot_words = g->slot_words;
   a->seg_nbits = e->seg_nbits.p;
   a->coeffs = nullptr;
+  a->ablate = e->ablate;
   return 0;
 }
 
@@ -915,6 +923,7 @@ int sjpeg_hip_engine_create(int device, sjpeg_hip_engine** engine) {
   sjpeg_hip_engine* e = new (std::nothrow) sjpeg_hip_engine;
   if (e == nullptr) return fail(SJPEG_HIP_ENOMEM, "host allocation failed");
   e->device = device;
+  if (const char* ab = getenv("SJPEG_HIP_ABLATE")) e->ablate = atoi(ab);   // profiling only
   *engine = e;
   return 0;
 }
