@@ -150,6 +150,20 @@ def main():
     scan_avg = float(np.mean(scan_ms)) * 1e-3
     algo_bytes = 3.0 * W * H * F
     achieved = algo_bytes / scan_avg
+    # HBM bytes per launch from the committed PMC pass of this same command (profiles/):
+    # 2 x FETCH_SIZE KiB (gfx950 wide-read correction, MI355X_MICROARCH.md) + WRITE_SIZE KiB.
+    traffic = None
+    try:
+        import re
+        txt = open(os.path.join(ROOT, "profiles", "r01", "v2_pmc_summary.txt")).read()
+        blk = txt[txt.index("scan_segments<1"):]
+        blk = blk[:blk.index("==", 5)] if "==" in blk[5:] else blk
+        fetch = float(re.search(r"FETCH_SIZE\s+total=\S+\s+per_dispatch=(\S+)", blk).group(1))
+        write = float(re.search(r"WRITE_SIZE\s+total=\S+\s+per_dispatch=(\S+)", blk).group(1))
+        if F == 16 and args.input == "struct":
+            traffic = int((2.0 * fetch + write) * 1024)
+    except Exception:
+        traffic = None
 
     # ---- parity: every coded frame must equal the reference bit for bit -------------------
     torch.cuda.synchronize()
@@ -194,7 +208,7 @@ def main():
             "bit_exact": bool(parity),
             "bytes_per_frame": int(sz[0]),
             "roofline": {"bound": "hbm", "achieved": round(achieved / 1e9, 1), "peak": HBM_PEAK / 1e9,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK, 4), "traffic": None,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK, 4), "traffic": traffic,
                          "kernel": "scan_segments<420>", "kernel_ms": round(scan_avg * 1e3, 4),
                          "all_kernels_ms": round(float(np.mean(total_ms)), 4),
                          "algorithmic_bytes_per_launch": int(algo_bytes)},

@@ -86,7 +86,7 @@ struct ScanArgs {
 // LDS carve (bytes), all offsets multiples of 16
 constexpr int kSamplesBytes = kThreads * kSlotBytes;            // 36864
 constexpr int kOffWin = kSamplesBytes;
-constexpr int kOffQ = kOffWin + kWinWords * 4;
+constexpr int kOffQ = kOffWin + kWinWords * 4 + 16;               // +1 spare word (16 B keeps alignment)
 constexpr int kOffAc = kOffQ + 2 * 64 * 8;
 constexpr int kOffDc = kOffAc + 2 * 256 * 4;
 constexpr int kOffMisc = kOffDc + 128;                          // scan scratch
@@ -654,24 +654,29 @@ __global__ __launch_bounds__(kThreads) void scan_segments(const ScanArgs a) {
   {
     unsigned long long m = nzm;
     auto next_pos = [&]() -> int { if (!m) return 0; const int i = __builtin_ctzll(m); m &= m - 1; return i; };
-    int i_cur = next_pos();                        // 0 = exhausted (position 0 is the DC)
-    uint32_t e_cur = zz[i_cur];
     int prev = 1;
-    uint32_t pend_code = 0;                        // table word of the previous symbol
-    while (i_cur) {
-      const int i_nxt = next_pos();
-      const uint32_t e_nxt = zz[i_nxt];
-      const uint32_t mag = e_cur & 0x7fffu;
-      const int run = i_cur - prev;
-      prev = i_cur + 1;
+    // one step: consume entry (iC, eC) -> issue its table read into codeOut; fetch the next
+    // entry into (iN, eN); account the table word of the step before (codeIn).  The loop is
+    // unrolled by two with swapped roles, so an in-flight LDS result is never copied (a copy
+    // would force a wait and serialise the round trips again).
+    auto step = [&](int iC, uint32_t eC, int& iN, uint32_t& eN, uint32_t codeIn, uint32_t& codeOut) {
+      iN = next_pos();
+      eN = zz[iN];
+      const uint32_t mag = eC & 0x7fffu;
+      const int run = iC - prev;
+      prev = iC + 1;
       const int n = 32 - __clz(mag);
-      const uint32_t code = ac[((run & 15) << 4) | n];
-      len += (pend_code & 0xffu) + static_cast<uint32_t>(run >> 4) * zl + n;
-      pend_code = code;
-      i_cur = i_nxt;
-      e_cur = e_nxt;
+      codeOut = ac[((run & 15) << 4) | n];
+      len += (codeIn & 0xffu) + static_cast<uint32_t>(run >> 4) * zl + n;
+    };
+    int iA = next_pos(), iB = 0;                   // 0 = exhausted (position 0 is the DC)
+    uint32_t eA = zz[iA], eB = 0, cA = 0, cB = 0;
+    while (iA) {
+      step(iA, eA, iB, eB, cA, cB);
+      if (!iB) { cA = cB; break; }
+      step(iB, eB, iA, eA, cB, cA);
     }
-    len += pend_code & 0xffu;
+    len += cA & 0xffu;
     if (b_emits) {
       len += dc_len;
       if (prev <= 63) len += eob & 0xffu;          // last non-zero index < 63
@@ -695,7 +700,7 @@ __global__ __launch_bounds__(kThreads) void scan_segments(const ScanArgs a) {
   uint32_t carry = 0;
   bool done = !b_emits;
   for (;;) {
-    for (int i = tid; i < kWinWords; i += kThreads) win[i] = 0;
+    for (int i = tid; i < kWinWords + 1; i += kThreads) win[i] = 0;
     if (tid == 0) misc[8] = total;
     __syncthreads();
     if (tid == 0 && carry != 0) atomicOr(&win[0], carry);
@@ -706,52 +711,55 @@ __global__ __launch_bounds__(kThreads) void scan_segments(const ScanArgs a) {
     const uint32_t limit = misc[8];
     if (fits && start < limit) {
       const uint32_t pos = start - base;
-      uint32_t wi = pos >> 5;
-      uint32_t o = pos & 31;                       // bits already used in the current word
-      uint32_t word = 0;                           // this thread's bits of window word wi, MSB first
+      uint32_t bp = pos;                           // running bit position inside the window
+      // branch-free append: OR the (<= 27) bits into the one or two window words they touch
       auto put = [&](uint32_t bits, uint32_t nb) { // 1 <= nb <= 27
         const uint32_t v = bits << (32 - nb);      // left-aligned
-        word |= v >> o;
-        o += nb;
-        if (o >= 32) {                             // word complete: o_before >= 5 here
-          atomicOr(&win[wi], word);
-          ++wi;
-          o -= 32;
-          word = v << (nb - o);
-        }
+        const uint32_t o = bp & 31u;
+        uint32_t* w = win + (bp >> 5);
+        atomicOr(w, v >> o);
+        atomicOr(w + 1, (v << 1) << (31u - o));    // zero when the symbol ends inside the word
+        bp += nb;
       };
       put(dc_bits, dc_len);
       unsigned long long m = nzm;
       auto next_pos = [&]() -> int { if (!m) return 0; const int i = __builtin_ctzll(m); m &= m - 1; return i; };
-      int i_cur = next_pos();
-      uint32_t e_cur = zz[i_cur];
       int prev = 1;
-      // pending symbol (its table word is still in flight)
-      uint32_t p_code = 0, p_suffix = 0, p_n = 0, p_zr = 0;
-      bool p_valid = false;
-      while (i_cur || p_valid) {
-        // stage A of the next symbol: indices, issue the table read
-        const int i_nxt = next_pos();
-        const uint32_t e_nxt = zz[i_nxt];
-        const bool c_valid = i_cur != 0;
-        const uint32_t mag = e_cur & 0x7fffu;
-        const int run = i_cur - prev;
+      // stage A of entry (iC, eC): indices + issue the table read (codeOut); fetch next entry;
+      // stage B of the symbol before it (sIn = n | zr << 8 | suffix << 16, codeIn in flight).
+      auto step = [&](int iC, uint32_t eC, int& iN, uint32_t& eN,
+                      uint32_t codeIn, uint32_t sIn, bool vIn, uint32_t& codeOut, uint32_t& sOut) {
+        iN = next_pos();
+        eN = zz[iN];
+        const uint32_t mag = eC & 0x7fffu;
+        const int run = iC - prev;
+        prev = iC + 1;
         const uint32_t n = 32u - __clz(mag);
         const uint32_t ones = (1u << n) - 1u;
-        const uint32_t suffix = (e_cur & 0x8000u) ? (mag ^ ones) : mag;    // negative: ~mag on n bits
-        const uint32_t code = ac[c_valid ? (((run & 15) << 4) | n) : 0u];
-        if (c_valid) prev = i_cur + 1;
-        // stage B of the pending symbol: ZRL escapes, then code + suffix
-        if (p_valid) {
-          for (uint32_t z = 0; z < p_zr; ++z) put(zrl >> 16, zl);
-          put(((p_code >> 16) << p_n) | p_suffix, (p_code & 0xffu) + p_n);
+        const uint32_t suffix = (eC & 0x8000u) ? (mag ^ ones) : mag;      // negative: ~mag on n bits
+        codeOut = ac[((run & 15) << 4) | n];
+        sOut = n | ((static_cast<uint32_t>(run) >> 4) << 8) | (suffix << 16);
+        if (vIn) {
+          const uint32_t pn = sIn & 0xffu;
+          for (uint32_t z = (sIn >> 8) & 0xffu; z > 0; --z) put(zrl >> 16, zl);
+          put(((codeIn >> 16) << pn) | (sIn >> 16), (codeIn & 0xffu) + pn);
         }
-        p_valid = c_valid; p_code = code; p_suffix = suffix; p_n = n; p_zr = static_cast<uint32_t>(run) >> 4;
-        i_cur = i_nxt;
-        e_cur = e_nxt;
+      };
+      int iA = next_pos(), iB = 0;
+      uint32_t eA = zz[iA], eB = 0, cA = 0, cB = 0, sA = 0, sB = 0;
+      bool pend = false;                           // a symbol waits for stage B (in cA/sA)
+      while (iA) {
+        step(iA, eA, iB, eB, cA, sA, pend, cB, sB);
+        if (!iB) { cA = cB; sA = sB; pend = true; break; }
+        step(iB, eB, iA, eA, cB, sB, true, cA, sA);
+        pend = true;
+      }
+      if (pend) {
+        const uint32_t pn = sA & 0xffu;
+        for (uint32_t z = (sA >> 8) & 0xffu; z > 0; --z) put(zrl >> 16, zl);
+        put(((cA >> 16) << pn) | (sA >> 16), (cA & 0xffu) + pn);
       }
       if (prev <= 63) put(eob >> 16, eob & 0xffu);
-      if (o > 0) atomicOr(&win[wi], word);
       done = true;
     }
     __syncthreads();
@@ -1046,6 +1054,8 @@ void digest_tables(const sjpeg_hip_scan_tables* t, DevTables* d) {
 
 template <bool TAP>
 int launch_scan(int mode, dim3 grid, hipStream_t st, const ScanArgs& a) {
+  static const int kLdsPad = getenv("SJPEG_HIP_LDS_PAD") ? atoi(getenv("SJPEG_HIP_LDS_PAD")) : 0;  // occupancy experiments
+  const int kLdsBytes = ::kLdsBytes + kLdsPad;
   switch (mode) {
     case SJPEG_HIP_YUV420:
       hipLaunchKernelGGL((scan_segments<SJPEG_HIP_YUV420, TAP>), grid, dim3(kThreads), kLdsBytes, st, a);
