@@ -59,6 +59,14 @@ typedef struct sjpeg_hip_scan_tables {
   uint32_t ac_codes[2][256];
 } sjpeg_hip_scan_tables;
 
+/* A Huffman table in DHT form: BITS (number of codes of each length 1..16) and HUFFVAL
+ * (symbols by increasing code length), reference struct HuffmanTable (src/sjpegi.h:221-225). */
+typedef struct sjpeg_hip_huffman_spec {
+  uint8_t bits[16];
+  uint8_t syms[256];
+  int32_t nsyms;
+} sjpeg_hip_huffman_spec;
+
 /* Opaque engine: one HIP device, cached device scratch.  Not thread-safe; use one engine
  * per host thread (they may share a device). */
 typedef struct sjpeg_hip_engine sjpeg_hip_engine;
@@ -114,6 +122,27 @@ int sjpeg_hip_scan_coeffs(sjpeg_hip_engine* engine,
                           const sjpeg_hip_scan_tables* tables,
                           int16_t* d_coeffs, void* stream);
 
+/* Statistics passes for the reference's methods 1..6 (same pixel arguments as above).
+ *
+ * sjpeg_hip_scan_histogram: replaces Encoder::CollectHistograms (src/histogram.cc:317-339 with
+ * StoreHisto :56-108).  d_hist receives, per frame, uint32 [2][64][128]: for quantizer table
+ * t (0 luma, 1 chroma) and NATURAL coefficient position p, the number of blocks whose
+ * un-quantized coefficient c has |c| >> 2 == bin (bin < 128).
+ *
+ * sjpeg_hip_scan_symbol_stats: replaces the statistics half of SinglePassScanOptimized
+ * (src/enc.cc:323-372, AddEntropyStats src/entropy.cc:208-227).  Needs tables->iquant/bias.
+ * d_freq receives, per frame, uint32 [2][272]: [t][0..255] AC symbol counts (run << 4 | size,
+ * 0xF0 = ZRL, 0x00 = EOB), [t][256 + n] DC size-category counts. */
+int sjpeg_hip_scan_histogram(sjpeg_hip_engine* engine,
+                             const void* d_rgb, int64_t row_stride, int64_t frame_stride,
+                             int width, int height, int yuv_mode, int nframes,
+                             uint32_t* d_hist, void* stream);
+int sjpeg_hip_scan_symbol_stats(sjpeg_hip_engine* engine,
+                                const void* d_rgb, int64_t row_stride, int64_t frame_stride,
+                                int width, int height, int yuv_mode, int nframes,
+                                const sjpeg_hip_scan_tables* tables,
+                                uint32_t* d_freq, void* stream);
+
 /* ---- host-side helpers (tiny CPU work, no device needed) -----------------------------
  * They produce exactly what the reference's host code would hand to its hot loop, so that
  * a non-C++ binding can drive sjpeg_hip_encode_scan() without re-implementing them. */
@@ -136,6 +165,25 @@ void sjpeg_hip_default_huffman(sjpeg_hip_scan_tables* tables);
  * buf (capacity cap), bytes identical to src/headers.cc.  Returns the size, 0 on error. */
 size_t sjpeg_hip_make_header(int width, int height, int yuv_mode, const uint8_t quant[2][64],
                              uint8_t* buf, size_t cap);
+
+/* Encoder::AnalyseHisto (src/histogram.cc:126-315) on ONE frame's histogram (host memory,
+ * uint32 [2][64][128]): adapts quant IN PLACE, then re-finalises both tables into `tables`
+ * exactly like the reference (quantization clamped to min_quant, NULL = all ones).
+ * qdelta_max_* are EncoderParam::qdelta_max_luma / _chroma (defaults 12 / 1). */
+void sjpeg_hip_adapt_quant(const uint32_t* hist, int yuv_mode, uint8_t quant[2][64],
+                           const uint8_t* min_quant /*[2][64]*/, int q_bias,
+                           int qdelta_max_luma, int qdelta_max_chroma,
+                           sjpeg_hip_scan_tables* tables);
+
+/* CompileEntropyStats / BuildOptimalTable (src/entropy.cc:254-444) on ONE frame's symbol
+ * statistics (host memory, uint32 [2][272]): fills specs[4] = {DC luma, DC chroma, AC luma,
+ * AC chroma} (chroma untouched for 4:0:0) and installs their codes into `tables`. */
+void sjpeg_hip_optimize_huffman(const uint32_t* freq, int yuv_mode,
+                                sjpeg_hip_huffman_spec specs[4], sjpeg_hip_scan_tables* tables);
+
+/* sjpeg_hip_make_header with explicit Huffman tables (specs as above; NULL = Annex K defaults). */
+size_t sjpeg_hip_make_header_ex(int width, int height, int yuv_mode, const uint8_t quant[2][64],
+                                const sjpeg_hip_huffman_spec* specs, uint8_t* buf, size_t cap);
 
 /* Duration in milliseconds of the dominant kernel (the fused colour+fDCT+quant+entropy
  * kernel) in the most recent sjpeg_hip_encode_scan() call on this engine, measured with

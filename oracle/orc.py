@@ -50,6 +50,19 @@ class Oracle:
         lib.orc_quality_matrices.argtypes = [C.c_float, C.c_void_p]
         lib.orc_default_codes.argtypes = [C.c_void_p, C.c_void_p]
         lib.orc_finalize_quant.argtypes = [C.POINTER(Quantizer), C.c_int]
+        lib.orc_encode_method.restype = C.c_size_t
+        lib.orc_encode_method.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int,
+                                          C.c_int, C.POINTER(_u8p)]
+        lib.orc_encode_full.restype = C.c_size_t
+        lib.orc_encode_full.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                        C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_u8p)]
+        lib.orc_histogram.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        lib.orc_symbol_stats.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                         C.c_int, C.c_void_p]
+        lib.orc_build_optimal.restype = C.c_int
+        lib.orc_build_optimal.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        lib.orc_adapt_quant.argtypes = [C.c_void_p, C.c_int, C.POINTER(Quantizer), C.c_int, C.c_int,
+                                        C.c_int]
 
     def finalize_quant(self, quant64, min_quant64=None, q_bias=0x78) -> Quantizer:
         q = Quantizer()
@@ -87,6 +100,55 @@ class Oracle:
         out = _u8p()
         n = self.lib.orc_encode(rgb.ctypes.data, w, h, stride, quality, yuv_mode, C.byref(out))
         return self._take(n, out)
+
+    def encode_method(self, rgb, quality=75.0, yuv_mode=YUV_420, method=0, stride=None):
+        rgb, w, h, stride = self._img(rgb, stride)
+        out = _u8p()
+        n = self.lib.orc_encode_method(rgb.ctypes.data, w, h, stride, quality, yuv_mode, method,
+                                       C.byref(out))
+        return self._take(n, out)
+
+    def encode_full(self, rgb, quant, min_quant=None, q_bias=0x78, dmax_luma=12, dmax_chroma=1,
+                    yuv_mode=YUV_420, method=0, stride=None):
+        rgb, w, h, stride = self._img(rgb, stride)
+        q = np.ascontiguousarray(quant, np.uint8).reshape(2, 64)
+        mq = None if min_quant is None else np.ascontiguousarray(min_quant, np.uint8).reshape(2, 64)
+        out = _u8p()
+        n = self.lib.orc_encode_full(rgb.ctypes.data, w, h, stride, q.ctypes.data,
+                                     mq.ctypes.data if mq is not None else None, q_bias, dmax_luma,
+                                     dmax_chroma, yuv_mode, method, C.byref(out))
+        return self._take(n, out)
+
+    def histogram(self, rgb, yuv_mode=YUV_420, stride=None):
+        rgb, w, h, stride = self._img(rgb, stride)
+        hist = np.zeros((2, 64, 128), np.uint32)
+        self.lib.orc_histogram(rgb.ctypes.data, w, h, stride, yuv_mode, hist.ctypes.data)
+        return hist
+
+    def symbol_stats(self, rgb, quant, q_bias=0x78, yuv_mode=YUV_420, stride=None):
+        rgb, w, h, stride = self._img(rgb, stride)
+        q = np.ascontiguousarray(quant, np.uint8).reshape(2, 64)
+        freq = np.zeros((2, 272), np.uint32)
+        self.lib.orc_symbol_stats(rgb.ctypes.data, w, h, stride, yuv_mode, q.ctypes.data, q_bias,
+                                  freq.ctypes.data)
+        return freq
+
+    def build_optimal(self, freq, size):
+        f = np.ascontiguousarray(freq, np.uint32)
+        bits = np.zeros(16, np.uint8)
+        syms = np.zeros(256, np.uint8)
+        n = self.lib.orc_build_optimal(f.ctypes.data, size, bits.ctypes.data, syms.ctypes.data)
+        return bits, syms[:n].copy(), n
+
+    def adapt_quant(self, hist, nb_comps, quant, min_quant=None, q_bias=0x78, dmax_luma=12,
+                    dmax_chroma=1):
+        qs = (Quantizer * 2)()
+        for c in range(2):
+            qs[c] = self.finalize_quant(np.asarray(quant)[c], None if min_quant is None
+                                        else np.asarray(min_quant)[c], q_bias)
+        h = np.ascontiguousarray(hist, np.uint32)
+        self.lib.orc_adapt_quant(h.ctypes.data, nb_comps, qs, q_bias, dmax_luma, dmax_chroma)
+        return np.array([list(qs[0].quant), list(qs[1].quant)], np.uint8), qs
 
     def encode_matrices(self, rgb, quant, min_quant=None, q_bias=0x78, yuv_mode=YUV_420,
                         stride=None):

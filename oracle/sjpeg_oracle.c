@@ -539,7 +539,24 @@ size_t orc_scan_bits(const uint8_t* rgb, int W, int H, int stride, int yuv_mode,
 
 static void put16(orc_bw* w, int v) { bw_byte(w, (uint8_t)(v >> 8)); bw_byte(w, (uint8_t)v); }
 
+typedef struct { uint8_t bits[16]; uint8_t syms[256]; int nsyms; } orc_huff;
+
+static void default_huff(orc_huff h[4]) {        /* DC luma, DC chroma, AC luma, AC chroma */
+  for (int c = 0; c < 2; ++c) {
+    memset(&h[c], 0, sizeof(h[c])); memset(&h[2 + c], 0, sizeof(h[2 + c]));
+    memcpy(h[c].bits, kDcBits[c], 16); memcpy(h[c].syms, kDcVals, 12); h[c].nsyms = 12;
+    memcpy(h[2 + c].bits, kAcBits[c], 16); memcpy(h[2 + c].syms, kAcVals[c], 162); h[2 + c].nsyms = 162;
+  }
+}
+
+static void write_headers_huff(orc_bw* w, const orc_scan* s, int yuv_mode, const orc_huff h[4]);
 static void write_headers(orc_bw* w, const orc_scan* s, int yuv_mode) {
+  orc_huff h[4];
+  default_huff(h);
+  write_headers_huff(w, s, yuv_mode, h);
+}
+
+static void write_headers_huff(orc_bw* w, const orc_scan* s, int yuv_mode, const orc_huff h[4]) {
   /* SOI + JFIF APP0, v1.01, 1:1 aspect, no thumbnail (src/headers.cc:48-55) */
   static const uint8_t app0[20] = {0xff, 0xd8, 0xff, 0xe0, 0, 16, 'J', 'F', 'I', 'F', 0,
                                    1, 1, 0, 0, 1, 0, 1, 0, 0};
@@ -561,10 +578,10 @@ static void write_headers(orc_bw* w, const orc_scan* s, int yuv_mode) {
   /* DHT: one segment per table: DC-luma, AC-luma, DC-chroma, AC-chroma (src/headers.cc:221-238) */
   const int nt = (s->L.nb_comps == 1) ? 1 : 2;
   for (int c = 0; c < nt; ++c) {
-    put16(w, 0xffc4); put16(w, 3 + 16 + 12); bw_byte(w, (uint8_t)c);
-    bw_raw(w, kDcBits[c], 16); bw_raw(w, kDcVals, 12);
-    put16(w, 0xffc4); put16(w, 3 + 16 + 162); bw_byte(w, (uint8_t)(0x10 | c));
-    bw_raw(w, kAcBits[c], 16); bw_raw(w, kAcVals[c], 162);
+    put16(w, 0xffc4); put16(w, 3 + 16 + h[c].nsyms); bw_byte(w, (uint8_t)c);
+    bw_raw(w, h[c].bits, 16); bw_raw(w, h[c].syms, (size_t)h[c].nsyms);
+    put16(w, 0xffc4); put16(w, 3 + 16 + h[2 + c].nsyms); bw_byte(w, (uint8_t)(0x10 | c));
+    bw_raw(w, h[2 + c].bits, 16); bw_raw(w, h[2 + c].syms, (size_t)h[2 + c].nsyms);
   }
   /* SOS (src/headers.cc:242-258) */
   put16(w, 0xffda); put16(w, 6 + 2 * s->L.nb_comps); bw_byte(w, (uint8_t)s->L.nb_comps);
@@ -608,6 +625,265 @@ size_t orc_encode(const uint8_t* rgb, int W, int H, int stride, float quality,
   uint8_t m[2][64];
   orc_quality_matrices(quality, m);
   return orc_encode_matrices(rgb, W, H, stride, m, NULL, 0x78, yuv_mode, out);
+}
+
+/* ---------------------------------------------------------------- methods 1..6 */
+
+/* src/histogram.cc:98-108 (plain-C variant: bins >= 128 are dropped), :317-339 */
+void orc_histogram(const uint8_t* rgb, int W, int H, int stride, int yuv_mode, uint32_t* hist) {
+  orc_layout L;
+  memset(hist, 0, 2 * 64 * 128 * sizeof(uint32_t));
+  if (!layout_for(yuv_mode, &L)) return;
+  const int mb_w = (W + L.block_w - 1) / L.block_w, mb_h = (H + L.block_h - 1) / L.block_h;
+  int16_t in[6 * 64];
+  for (int my = 0; my < mb_h; ++my) {
+    for (int mx = 0; mx < mb_w; ++mx) {
+      orc_get_samples(yuv_mode, rgb, W, H, stride, mx, my, in);
+      orc_fdct(in, L.mcu_blocks);
+      const int16_t* blk = in;
+      for (int c = 0; c < L.nb_comps; ++c) {
+        uint32_t* h = hist + (size_t)L.quant_idx[c] * 64 * 128;
+        for (int n = 0; n < L.nb_blocks[c]; ++n, blk += 64) {
+          for (int i = 0; i < 64; ++i) {
+            const int k = (blk[i] < 0 ? -blk[i] : blk[i]) >> 2;
+            if (k < 128) ++h[i * 128 + k];
+          }
+        }
+      }
+    }
+  }
+}
+
+/* src/histogram.cc:126-315.  double/float expressions in the reference's order. */
+void orc_adapt_quant(const uint32_t* hist, int nb_comps, orc_quantizer q[2], int q_bias,
+                     int qdelta_max_luma, int qdelta_max_chroma) {
+  enum { DMIN = -12, NQ = 25 };
+  static const float weight[NQ] = {0, 0, 0, 0, 0, 1, 5, 16, 43, 94, 164, 228, 255,
+                                   228, 164, 94, 43, 16, 5, 1, 0, 0, 0, 0, 0};
+  for (int idx = (nb_comps > 1 ? 1 : 0); idx >= 0; --idx) {
+    const int delta_max = (idx == 0 ? qdelta_max_luma : qdelta_max_chroma) - DMIN;
+    float sizes[64][NQ], dist[64][NQ];
+    double num = 0., den = 0.;
+    uint64_t omit = 0x103ull;
+    for (int pos = 0; pos < 64; ++pos) {
+      if (omit & (1ull << pos)) continue;
+      const int dq0 = q[idx].quant[pos], min_dq0 = q[idx].min_quant[pos];
+      const int bias = 1 << 16 >> 1;
+      const uint32_t* h = hist + ((size_t)idx * 64 + pos) * 128;
+      int total = 0, last = 0;
+      for (int i = 0; i < 128; ++i) { total += (int)h[i]; if (h[i]) last = i + 1; }
+      if (total < 0.5 * last) { omit |= 1ull << pos; continue; }
+      double sw = 0., sx = 0., sxx = 0., syy1 = 0., sy1 = 0., sxy1 = 0., sy2 = 0., sxy2 = 0.;
+      for (int d = 0; d < NQ; ++d) {
+        double bsum = 0., dsum = 0.;
+        const int dq = dq0 + (d + DMIN);
+        if (dq >= min_dq0 && dq <= 255) {
+          const int idq = ((1 << 16) + dq - 1) / dq;
+          for (int i = 0; i < last; ++i) {
+            if (h[i]) {
+              const int hi = (int)h[i];
+              const int v = (i << 2) + 2;
+              const int qv = (v * idq + bias) >> 16;
+              if (qv) {
+                const int bits = bit_length((uint32_t)qv);
+                const int dqv = qv * dq;
+                const int error = (v - dqv) * (v - dqv);
+                bsum += hi * bits;
+                dsum += hi * error;
+              } else {
+                dsum += hi * v * v;
+              }
+            }
+          }
+          dist[pos][d] = (float)dsum;
+          sizes[pos][d] = (float)bsum;
+          const double w = weight[d];
+          if (w > 0.) {
+            const double x = (double)(d + DMIN);
+            sw += w; sx += w * x; sxx += w * x * x;
+            sy1 += w * dsum; syy1 += w * dsum * dsum; sy2 += w * bsum;
+            sxy1 += w * dsum * x; sxy2 += w * bsum * x;
+          }
+        } else {
+          dist[pos][d] = 3.402823466e+38F;     /* FLT_MAX */
+          sizes[pos][d] = 0;
+        }
+      }
+      const double cov = sw * sxy1 - sx * sy1;
+      if (cov * cov < 0.5 * (sw * sxx - sx * sx) * (sw * syy1 - sy1 * sy1)) { omit |= 1ull << pos; continue; }
+      num += cov;
+      den += sw * sxy2 - sx * sy2;
+    }
+    double lambda = 0x80;
+    if (num > 1000. && den < -10.) { lambda = -num / den; if (lambda < 1.) lambda = 1.; }
+    for (int pos = 0; pos < 64; ++pos) {
+      if (omit & (1ull << pos)) continue;
+      float best = 3.402823466e+38F;
+      int best_dq = 0;
+      for (int d = 0; d <= delta_max; ++d) {
+        if (dist[pos][d] < 3.402823466e+38F) {
+          const float score = dist[pos][d] + lambda * sizes[pos][d];
+          if (score < best) { best = score; best_dq = d + DMIN; }
+        }
+      }
+      q[idx].quant[pos] = (uint8_t)(q[idx].quant[pos] + best_dq);
+    }
+    orc_finalize_quant(&q[idx], q_bias);
+  }
+}
+
+static void block_stats(const int16_t zz[64], int* dc_pred, uint32_t* f /*[272]*/) {
+  const int diff = zz[0] - *dc_pred;             /* src/entropy.cc:208-227 */
+  *dc_pred = zz[0];
+  ++f[256 + bit_length((uint32_t)(diff < 0 ? -diff : diff))];
+  int run = 0;
+  for (int i = 1; i < 64; ++i) {
+    const int v = zz[i];
+    if (v == 0) { ++run; continue; }
+    if (run >> 4) f[0xf0] += (uint32_t)(run >> 4);
+    ++f[((run & 15) << 4) | bit_length((uint32_t)(v < 0 ? -v : v))];
+    run = 0;
+  }
+  if (run > 0) ++f[0x00];
+}
+
+static void scan_stats(orc_scan* s, const uint8_t* rgb, int stride, int yuv_mode, uint32_t* freq) {
+  int pred[3] = {0, 0, 0};
+  int16_t in[6 * 64], zz[64];
+  memset(freq, 0, 2 * 272 * sizeof(uint32_t));
+  for (int my = 0; my < s->mb_h; ++my) {
+    for (int mx = 0; mx < s->mb_w; ++mx) {
+      orc_get_samples(yuv_mode, rgb, s->W, s->H, stride, mx, my, in);
+      orc_fdct(in, s->L.mcu_blocks);
+      const int16_t* blk = in;
+      for (int c = 0; c < s->L.nb_comps; ++c) {
+        const int t = s->L.quant_idx[c];
+        for (int i = 0; i < s->L.nb_blocks[c]; ++i, blk += 64) {
+          orc_quantize_block(blk, &s->q[t], zz);
+          block_stats(zz, &pred[c], freq + 272 * t);
+        }
+      }
+    }
+  }
+}
+
+void orc_symbol_stats(const uint8_t* rgb, int W, int H, int stride, int yuv_mode,
+                      const uint8_t quant[2][64], int q_bias, uint32_t* freq) {
+  orc_scan s;
+  if (!scan_init(&s, W, H, yuv_mode, quant, NULL, q_bias)) return;
+  scan_stats(&s, rgb, stride, yuv_mode, freq);
+}
+
+/* src/entropy.cc:254-430: Huffman's merging with the all-ones code reserved and lengths
+ * limited to 16 bits. */
+int orc_build_optimal(const uint32_t* freq, int size, uint8_t out_bits[16], uint8_t syms[256]) {
+  int codesizes[257], chain[257], tail[257];
+  uint64_t sorted[257];
+  int nb = 0;
+  for (int i = 0; i < size; ++i) {
+    if (freq[i] > 0) sorted[nb++] = ((uint64_t)freq[i] << 9) | (uint64_t)i;
+    codesizes[i] = 0; chain[i] = -1; tail[i] = i;
+  }
+  const int nsyms = nb;
+  for (int a = 1; a < nb; ++a) {                 /* decreasing order; keys are unique */
+    const uint64_t key = sorted[a];
+    int b = a;
+    while (b > 0 && sorted[b - 1] < key) { sorted[b] = sorted[b - 1]; --b; }
+    sorted[b] = key;
+  }
+  sorted[nb++] = (1ull << 9) | (uint64_t)size;   /* pseudo symbol -> forbidden all-ones code */
+  codesizes[size] = 0; chain[size] = -1; tail[size] = size;
+  for (int n = nb - 1; n >= 1; --n) {
+    const uint64_t s1 = sorted[n - 1], s2 = sorted[n];
+    const int i = (int)(s1 & 0x1ff), j = (int)(s2 & 0x1ff);
+    chain[tail[i]] = j;
+    tail[i] = tail[j];
+    for (int t = i; t >= 0; t = chain[t]) ++codesizes[t];
+    const uint64_t merged = s1 + (s2 & ~0x1ffull);
+    int k = n - 1;
+    while (k > 0 && sorted[k - 1] < merged) { sorted[k] = sorted[k - 1]; --k; }
+    sorted[k] = merged;
+  }
+  uint8_t bits[32];
+  memset(bits, 0, sizeof(bits));
+  int max_bits = 0;
+  for (int i = 0; i <= size; ++i) {
+    int sz = codesizes[i];
+    if (sz > 0) {
+      if (sz > 32) { sz = 32; codesizes[i] = 32; }
+      ++bits[sz - 1];
+      if (sz > max_bits) max_bits = sz;
+    }
+  }
+  int start[32], position = 0;
+  for (int i = 0; i < max_bits; ++i) { start[i] = position; position += bits[i]; }
+  memset(syms, 0, 256);
+  for (int sym = 0; sym < size; ++sym) {
+    if (codesizes[sym] > 0) syms[start[codesizes[sym] - 1]++] = (uint8_t)sym;
+  }
+  for (int l = max_bits - 1; l >= 16; --l) {
+    while (bits[l] > 0) {
+      int k = l - 2;
+      while (bits[k] == 0) --k;
+      bits[l] -= 2; bits[l - 1] += 1; bits[k] -= 1; bits[k + 1] += 2;
+    }
+  }
+  max_bits = 16;
+  while (bits[--max_bits] == 0) {}
+  --bits[max_bits];
+  memcpy(out_bits, bits, 16);
+  return nsyms;
+}
+
+/* src/enc.cc:391-448 with the method flags of :121-129 (no trellis, single pass) */
+size_t orc_encode_full(const uint8_t* rgb, int W, int H, int stride, const uint8_t quant[2][64],
+                       const uint8_t* min_quant, int q_bias, int qdelta_max_luma,
+                       int qdelta_max_chroma, int yuv_mode, int method, uint8_t** out) {
+  orc_scan s;
+  *out = NULL;
+  if (rgb == NULL || abs(stride) < 3 * W) return 0;
+  if (method < 0) method = 0;
+  if (method > 6) return 0;                       /* trellis: outside the oracle's scope */
+  if (!scan_init(&s, W, H, yuv_mode, quant, min_quant, q_bias)) return 0;
+  const int adaptive = method >= 3, optimize = (method != 0 && method != 3);
+  if (adaptive) {
+    uint32_t* hist = (uint32_t*)malloc(2 * 64 * 128 * sizeof(uint32_t));
+    orc_histogram(rgb, W, H, stride, yuv_mode, hist);
+    orc_adapt_quant(hist, s.L.nb_comps, s.q, q_bias, qdelta_max_luma, qdelta_max_chroma);
+    free(hist);
+  }
+  orc_huff h[4];
+  default_huff(h);
+  uint32_t dc[2][12], ac[2][256];
+  if (optimize) {
+    uint32_t freq[2][272];
+    scan_stats(&s, rgb, stride, yuv_mode, &freq[0][0]);
+    const int nt = s.L.nb_comps == 1 ? 1 : 2;
+    for (int t = 0; t < nt; ++t) {
+      memset(&h[t], 0, sizeof(h[t])); memset(&h[2 + t], 0, sizeof(h[2 + t]));
+      h[t].nsyms = orc_build_optimal(freq[t] + 256, 12, h[t].bits, h[t].syms);
+      h[2 + t].nsyms = orc_build_optimal(freq[t], 256, h[2 + t].bits, h[2 + t].syms);
+    }
+  }
+  memset(dc, 0, sizeof(dc)); memset(ac, 0, sizeof(ac));
+  for (int t = 0; t < 2; ++t) {
+    orc_build_huffman(h[t].bits, h[t].syms, dc[t]);
+    orc_build_huffman(h[2 + t].bits, h[2 + t].syms, ac[t]);
+  }
+  orc_bw w;
+  memset(&w, 0, sizeof(w));
+  write_headers_huff(&w, &s, yuv_mode, h);
+  scan_emit(&s, rgb, stride, yuv_mode, &w, dc, ac);
+  put16(&w, 0xffd9);
+  *out = w.buf;
+  return w.size;
+}
+
+size_t orc_encode_method(const uint8_t* rgb, int W, int H, int stride, float quality,
+                         int yuv_mode, int method, uint8_t** out) {
+  uint8_t m[2][64];
+  orc_quality_matrices(quality, m);
+  return orc_encode_full(rgb, W, H, stride, m, NULL, 0x78, 12, 1, yuv_mode, method, out);
 }
 
 void orc_free(void* p) { free(p); }

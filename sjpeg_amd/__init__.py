@@ -30,6 +30,11 @@ class ScanTables(C.Structure):
                 ("ac_codes", (C.c_uint32 * 256) * 2)]
 
 
+class HuffmanSpec(C.Structure):
+    """struct sjpeg_hip_huffman_spec (include/sjpeg_hip.h)."""
+    _fields_ = [("bits", C.c_uint8 * 16), ("syms", C.c_uint8 * 256), ("nsyms", C.c_int32)]
+
+
 class SjpegError(RuntimeError):
     pass
 
@@ -91,6 +96,18 @@ def lib() -> C.CDLL:
     L.sjpeg_hip_default_huffman.argtypes = [C.POINTER(ScanTables)]
     L.sjpeg_hip_make_header.restype = C.c_size_t
     L.sjpeg_hip_make_header.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]
+    L.sjpeg_hip_scan_histogram.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int,
+                                           C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    L.sjpeg_hip_scan_symbol_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int,
+                                              C.c_int, C.c_int, C.c_int, C.POINTER(ScanTables),
+                                              C.c_void_p, C.c_void_p]
+    L.sjpeg_hip_adapt_quant.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                        C.c_int, C.c_int, C.POINTER(ScanTables)]
+    L.sjpeg_hip_optimize_huffman.argtypes = [C.c_void_p, C.c_int, C.POINTER(HuffmanSpec),
+                                             C.POINTER(ScanTables)]
+    L.sjpeg_hip_make_header_ex.restype = C.c_size_t
+    L.sjpeg_hip_make_header_ex.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                           C.POINTER(HuffmanSpec), C.c_void_p, C.c_size_t]
     L.sjpeg_hip_engine_set_timing.argtypes = [C.c_void_p, C.c_int]
     L.sjpeg_hip_engine_last_scan_ms.restype = C.c_float
     L.sjpeg_hip_engine_last_scan_ms.argtypes = [C.c_void_p]
@@ -109,6 +126,8 @@ EXPORTED_C_SYMBOLS = [
     "sjpeg_hip_engine_create", "sjpeg_hip_engine_destroy", "sjpeg_hip_frame_bound",
     "sjpeg_hip_encode_scan", "sjpeg_hip_scan_coeffs", "sjpeg_hip_quality_matrices",
     "sjpeg_hip_finalize_quant", "sjpeg_hip_default_huffman", "sjpeg_hip_make_header",
+    "sjpeg_hip_scan_histogram", "sjpeg_hip_scan_symbol_stats", "sjpeg_hip_adapt_quant",
+    "sjpeg_hip_optimize_huffman", "sjpeg_hip_make_header_ex",
     "sjpeg_hip_engine_set_timing", "sjpeg_hip_engine_last_scan_ms",
     "sjpeg_hip_engine_last_total_ms",
 ]
@@ -169,6 +188,40 @@ def make_header(w, h, yuv_mode, quant) -> bytes:
     n = lib().sjpeg_hip_make_header(w, h, yuv_mode, q.ctypes.data, buf.ctypes.data, buf.size)
     if n == 0:
         raise SjpegError("sjpeg_hip_make_header failed")
+    return buf[:n].tobytes()
+
+
+def adapt_quant(hist: np.ndarray, yuv_mode, quant, min_quant=None, q_bias=0x78, dmax_luma=12,
+                dmax_chroma=1):
+    """Host AnalyseHisto on one frame's histogram [2][64][128]; returns (ScanTables, new quant)."""
+    h = np.ascontiguousarray(hist, np.uint32).reshape(2, 64, 128)
+    q = np.ascontiguousarray(quant, np.uint8).reshape(2, 64).copy()
+    mq = None if min_quant is None else np.ascontiguousarray(min_quant, np.uint8).reshape(2, 64)
+    t = ScanTables()
+    lib().sjpeg_hip_finalize_quant(q.ctypes.data, mq.ctypes.data if mq is not None else None, q_bias,
+                                   C.byref(t))
+    lib().sjpeg_hip_adapt_quant(h.ctypes.data, yuv_mode, q.ctypes.data,
+                                mq.ctypes.data if mq is not None else None, q_bias, dmax_luma,
+                                dmax_chroma, C.byref(t))
+    lib().sjpeg_hip_default_huffman(C.byref(t))
+    return t, q
+
+
+def optimize_huffman(freq: np.ndarray, yuv_mode, tables: ScanTables):
+    """Host BuildOptimalTable on one frame's symbol statistics [2][272]; installs the codes into
+    `tables` and returns the four HuffmanSpec (DC luma, DC chroma, AC luma, AC chroma)."""
+    f = np.ascontiguousarray(freq, np.uint32).reshape(2, 272)
+    specs = (HuffmanSpec * 4)()
+    lib().sjpeg_hip_optimize_huffman(f.ctypes.data, yuv_mode, specs, C.byref(tables))
+    return specs
+
+
+def make_header_ex(w, h, yuv_mode, quant, specs) -> bytes:
+    buf = np.zeros(4096, np.uint8)
+    q = np.ascontiguousarray(quant, np.uint8).reshape(2, 64)
+    n = lib().sjpeg_hip_make_header_ex(w, h, yuv_mode, q.ctypes.data, specs, buf.ctypes.data, buf.size)
+    if n == 0:
+        raise SjpegError("sjpeg_hip_make_header_ex failed")
     return buf[:n].tobytes()
 
 
@@ -233,6 +286,30 @@ class Engine:
             raise SjpegError(f"sjpeg_hip_encode_scan: {lib().sjpeg_hip_last_error().decode()}")
         return out, sizes
 
+    def scan_histogram(self, frames, yuv_mode: int):
+        """[F, 2, 64, 128] uint32 (as int32 tensor) coefficient histograms (adaptive quantization)."""
+        import torch
+        f, h, w, _ = frames.shape
+        out = torch.zeros((f, 2, 64, 128), dtype=torch.int32, device=frames.device)
+        rc = lib().sjpeg_hip_scan_histogram(self._h, frames.data_ptr(), frames.stride(1),
+                                            frames.stride(0), w, h, yuv_mode, f, out.data_ptr(),
+                                            self._stream())
+        if rc != 0:
+            raise SjpegError(f"sjpeg_hip_scan_histogram: {lib().sjpeg_hip_last_error().decode()}")
+        return out
+
+    def scan_symbol_stats(self, frames, tables: ScanTables, yuv_mode: int):
+        """[F, 2, 272] symbol counts (256 AC + 16 DC per table) for Huffman optimisation."""
+        import torch
+        f, h, w, _ = frames.shape
+        out = torch.zeros((f, 2, 272), dtype=torch.int32, device=frames.device)
+        rc = lib().sjpeg_hip_scan_symbol_stats(self._h, frames.data_ptr(), frames.stride(1),
+                                               frames.stride(0), w, h, yuv_mode, f, C.byref(tables),
+                                               out.data_ptr(), self._stream())
+        if rc != 0:
+            raise SjpegError(f"sjpeg_hip_scan_symbol_stats: {lib().sjpeg_hip_last_error().decode()}")
+        return out
+
     def scan_coeffs(self, frames, tables: ScanTables, yuv_mode: int):
         import torch
         f, h, w, _ = frames.shape
@@ -246,6 +323,36 @@ class Engine:
         if rc != 0:
             raise SjpegError(f"sjpeg_hip_scan_coeffs: {lib().sjpeg_hip_last_error().decode()}")
         return coeffs
+
+
+def encode_device_method(frames, quality=75.0, yuv_mode=YUV_420, method=4, engine=None, quant=None,
+                         min_quant=None, q_bias=0x78, dmax_luma=12, dmax_chroma=1):
+    """Per-frame adaptive quantization / optimised Huffman tables (reference methods 0..6) for
+    device-resident frames, driven through the C-ABI exactly like the C++ host API does:
+    GPU statistics passes + host analysis + GPU encode.  Returns a list of JPEG byte strings."""
+    import torch
+    eng = engine or Engine(frames.device.index or 0)
+    method = max(0, min(int(method), 8))
+    if method >= 7:
+        raise SjpegError("trellis methods are not available")
+    adaptive, optimize = method >= 3, method not in (0, 3)
+    f, h, w, _ = frames.shape
+    out_frames = []
+    hists = eng.scan_histogram(frames, yuv_mode).cpu().numpy().view(np.uint32) if adaptive else None
+    for k in range(f):
+        one = frames[k:k + 1]
+        tables, q = make_tables(quality=quality, quant=quant, min_quant=min_quant, q_bias=q_bias)
+        if adaptive:
+            tables, q = adapt_quant(hists[k], yuv_mode, q, min_quant, q_bias, dmax_luma, dmax_chroma)
+        specs = None
+        if optimize:
+            freq = eng.scan_symbol_stats(one, tables, yuv_mode).cpu().numpy().view(np.uint32)[0]
+            specs = optimize_huffman(freq, yuv_mode, tables)
+        header = make_header_ex(w, h, yuv_mode, q, specs)
+        out, sizes = eng.encode_frames(one, tables, header, yuv_mode)
+        torch.cuda.synchronize()
+        out_frames.append(bytes(out[0, :int(sizes[0])].cpu().numpy()))
+    return out_frames
 
 
 def encode_device(frames, quality=75.0, yuv_mode=YUV_420, engine=None, quant=None):

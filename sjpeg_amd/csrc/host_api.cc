@@ -106,12 +106,14 @@ struct DeviceContext {
   int device = 0;
   void* d_in = nullptr;  size_t in_cap = 0;
   void* d_out = nullptr; size_t out_cap = 0;
+  void* d_stats = nullptr; size_t stats_cap = 0;
   uint64_t* d_size = nullptr;
   ~DeviceContext() {
     if (engine == nullptr) return;
     (void)hipSetDevice(device);
     if (d_in) (void)hipFree(d_in);
     if (d_out) (void)hipFree(d_out);
+    if (d_stats) (void)hipFree(d_stats);
     if (d_size) (void)hipFree(d_size);
     sjpeg_hip_engine_destroy(engine);
   }
@@ -146,7 +148,8 @@ struct Encoder {
   Encoder(const uint8_t* rgb, int W, int H, int stride, ByteSink* sink, MemoryManager* mem)
       : rgb_(rgb), W_(W), H_(H), stride_(stride), sink_(sink),
         mem_(mem ? mem : &g_default_memory), q_bias_(kDefaultBias), method_(4),
-        yuv_mode_(SJPEG_YUV_420), passes_(1) {
+        yuv_mode_(SJPEG_YUV_420), passes_(1), qdelta_luma_(kDefaultDeltaMaxLuma),
+        qdelta_chroma_(kDefaultDeltaMaxChroma) {
     memset(min_quant_, 1, sizeof(min_quant_));
     SetQuality(kDefaultQuality);
   }
@@ -174,6 +177,8 @@ struct Encoder {
     if (p.use_trellis) method = (method == 4) ? 7 : (method == 6) ? 8 : method;
     SetMethod(method);
     q_bias_ = p.quantization_bias;
+    qdelta_luma_ = p.qdelta_max_luma;
+    qdelta_chroma_ = p.qdelta_max_chroma;
     meta_.iccp = p.iccp; meta_.exif = p.exif; meta_.app_markers = p.app_markers;
     meta_.xmp = p.xmp; meta_.xmp_split = p.xmp_split_point;
     passes_ = p.passes < 1 ? 1 : p.passes > 20 ? 20 : p.passes;
@@ -191,6 +196,7 @@ struct Encoder {
   int q_bias_, method_;
   SjpegYUVMode yuv_mode_;
   int passes_;
+  int qdelta_luma_, qdelta_chroma_;
   sjpeg_host::Metadata meta_;
 };
 
@@ -209,36 +215,17 @@ bool Encoder::Run() {
                   "the GPU hot path); pick 420, 444 or 400");
     default: return Fail("unknown yuv_mode");                        // src/encoders.cc:553-567
   }
-  if (method_ != 0) {
-    return Fail("compression method " + std::to_string(method_) + " is not available in this "
-                "build: only method 0 (Huffman_compress = false, adaptive_quantization = false) "
-                "runs on the GPU; no CPU fallback exists");
+  // method flags, reference: src/enc.cc:121-129
+  const bool adaptive = method_ >= 3;
+  const bool optimize = (method_ != 0) && (method_ != 3);
+  if (method_ >= 7) {
+    return Fail("trellis quantization (methods 7, 8 / use_trellis) is not available in this build: "
+                "it is a per-block dynamic program outside the GPU hot path; no CPU fallback exists");
   }
   if (passes_ > 1) return Fail("multi-pass size/PSNR search is not available in this build");
-
-  // quantizers (src/enc.cc:394-397), standard Huffman tables (src/enc.cc:399)
-  sjpeg_hip_scan_tables tables;
-  memset(&tables, 0, sizeof(tables));
-  sjpeg_host::FinalizeQuantizer(quant_[0], min_quant_[0], q_bias_, 0, &tables);
-  sjpeg_host::FinalizeQuantizer(quant_[1], min_quant_[1], q_bias_, 1, &tables);
-  const HuffSpec* dc[2] = {&sjpeg_host::DefaultHuff(0, 0), &sjpeg_host::DefaultHuff(0, 1)};
-  const HuffSpec* ac[2] = {&sjpeg_host::DefaultHuff(1, 0), &sjpeg_host::DefaultHuff(1, 1)};
-  sjpeg_host::InstallCodes(dc, ac, mode == SJPEG_HIP_YUV400 ? 1 : 2, &tables);
-
-  // headers: SOI/APP0, metadata, DQT, SOF, DHT, SOS (src/enc.cc:415-443)
-  std::vector<uint8_t> header;
-  if (!sjpeg_host::AppendHeaders(W_, H_, mode, quant_, dc, ac, &meta_, &header)) {
-    return Fail("invalid metadata (EXIF > 64 KiB, ICC >= 256 chunks or XMP too large)");
+  if (qdelta_luma_ < 0 || qdelta_luma_ > 12 || qdelta_chroma_ < 0 || qdelta_chroma_ > 12) {
+    return Fail("qdelta_max_luma / qdelta_max_chroma must be in [0, 12]");
   }
-  // one host allocation goes through the caller's MemoryManager, and its failure is
-  // fatal, as in the reference (tests/unit_test.cc:373-454 rely on both).
-  uint8_t* const staged_header = static_cast<uint8_t*>(mem_->Alloc(header.size()));
-  if (staged_header == nullptr) return Fail("MemoryManager refused an allocation");
-  memcpy(staged_header, header.data(), header.size());
-  struct Guard {
-    MemoryManager* m; void* p;
-    ~Guard() { m->Free(p); }
-  } guard = {mem_, staged_header};
 
   DeviceContext& ctx = g_ctx;
   if (!ctx.Init()) return false;
@@ -257,6 +244,71 @@ bool Encoder::Run() {
   const uint8_t* d_first = static_cast<const uint8_t*>(ctx.d_in);
   long long d_stride = static_cast<long long>(dev_pitch);
   if (stride_ < 0) { d_first += dev_pitch * (H_ - 1); d_stride = -d_stride; }
+  const int nb_comps = (mode == SJPEG_HIP_YUV400) ? 1 : 3;
+
+  // quantizers (src/enc.cc:394-397)
+  sjpeg_hip_scan_tables tables;
+  memset(&tables, 0, sizeof(tables));
+  sjpeg_host::FinalizeQuantizer(quant_[0], min_quant_[0], q_bias_, 0, &tables);
+  sjpeg_host::FinalizeQuantizer(quant_[1], min_quant_[1], q_bias_, 1, &tables);
+  if (!ctx.Ensure(&ctx.d_stats, &ctx.stats_cap, 2 * 64 * 128 * sizeof(uint32_t))) return false;
+
+  if (adaptive) {
+    // CollectHistograms on the GPU, AnalyseHisto on the host (src/enc.cc:425-429)
+    if (sjpeg_hip_scan_histogram(ctx.engine, d_first, d_stride, 0, W_, H_, mode, 1,
+                                 static_cast<uint32_t*>(ctx.d_stats), nullptr) != 0) {
+      return FailHip("sjpeg_hip_scan_histogram");
+    }
+    std::vector<uint32_t> hist(2 * 64 * 128);
+    if (hipMemcpy(hist.data(), ctx.d_stats, hist.size() * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess) {
+      return Fail(std::string("histogram pass failed: ") + hipGetErrorString(hipGetLastError()));
+    }
+    sjpeg_host::AdaptQuantMatrices(reinterpret_cast<const uint32_t(*)[64][128]>(hist.data()), nb_comps,
+                                   quant_, min_quant_, qdelta_luma_, qdelta_chroma_);
+    for (int idx = (nb_comps > 1 ? 1 : 0); idx >= 0; --idx) {
+      sjpeg_host::FinalizeQuantizer(quant_[idx], min_quant_[idx], q_bias_, idx, &tables);
+    }
+  }
+
+  // Huffman tables: Annex K defaults (src/enc.cc:399) or optimised for this picture
+  const HuffSpec* dc[2] = {&sjpeg_host::DefaultHuff(0, 0), &sjpeg_host::DefaultHuff(0, 1)};
+  const HuffSpec* ac[2] = {&sjpeg_host::DefaultHuff(1, 0), &sjpeg_host::DefaultHuff(1, 1)};
+  HuffSpec opt[4];
+  const int ntables = (nb_comps == 1) ? 1 : 2;
+  if (optimize) {
+    // statistics half of SinglePassScanOptimized on the GPU (src/enc.cc:323-372),
+    // CompileEntropyStats on the host (src/entropy.cc:432-444)
+    if (sjpeg_hip_scan_symbol_stats(ctx.engine, d_first, d_stride, 0, W_, H_, mode, 1, &tables,
+                                    static_cast<uint32_t*>(ctx.d_stats), nullptr) != 0) {
+      return FailHip("sjpeg_hip_scan_symbol_stats");
+    }
+    uint32_t freq[2][272];
+    if (hipMemcpy(freq, ctx.d_stats, sizeof(freq), hipMemcpyDeviceToHost) != hipSuccess) {
+      return Fail(std::string("statistics pass failed: ") + hipGetErrorString(hipGetLastError()));
+    }
+    for (int t = 0; t < ntables; ++t) {
+      sjpeg_host::BuildOptimalSpec(freq[t] + 256, 12, &opt[t]);
+      sjpeg_host::BuildOptimalSpec(freq[t], 256, &opt[2 + t]);
+      dc[t] = &opt[t];
+      ac[t] = &opt[2 + t];
+    }
+  }
+  sjpeg_host::InstallCodes(dc, ac, ntables, &tables);
+
+  // headers: SOI/APP0, metadata, DQT, SOF, DHT, SOS (src/enc.cc:415-443)
+  std::vector<uint8_t> header;
+  if (!sjpeg_host::AppendHeaders(W_, H_, mode, quant_, dc, ac, &meta_, &header)) {
+    return Fail("invalid metadata (EXIF > 64 KiB, ICC >= 256 chunks or XMP too large)");
+  }
+  // one host allocation goes through the caller's MemoryManager, and its failure is
+  // fatal, as in the reference (tests/unit_test.cc:373-454 rely on both).
+  uint8_t* const staged_header = static_cast<uint8_t*>(mem_->Alloc(header.size()));
+  if (staged_header == nullptr) return Fail("MemoryManager refused an allocation");
+  memcpy(staged_header, header.data(), header.size());
+  struct Guard {
+    MemoryManager* m; void* p;
+    ~Guard() { m->Free(p); }
+  } guard = {mem_, staged_header};
 
   const size_t bound = sjpeg_hip_frame_bound(W_, H_, mode, header.size());
   if (bound == 0 || !ctx.Ensure(&ctx.d_out, &ctx.out_cap, bound)) return false;
@@ -468,6 +520,49 @@ size_t sjpeg_hip_make_header(int width, int height, int yuv_mode, const uint8_t 
   if (buf == nullptr || width <= 0 || height <= 0 || width > 65535 || height > 65535) return 0;
   const HuffSpec* dc[2] = {&sjpeg_host::DefaultHuff(0, 0), &sjpeg_host::DefaultHuff(0, 1)};
   const HuffSpec* ac[2] = {&sjpeg_host::DefaultHuff(1, 0), &sjpeg_host::DefaultHuff(1, 1)};
+  std::vector<uint8_t> h;
+  if (!sjpeg_host::AppendHeaders(width, height, yuv_mode, quant, dc, ac, nullptr, &h)) return 0;
+  if (h.size() > cap) return 0;
+  memcpy(buf, h.data(), h.size());
+  return h.size();
+}
+
+void sjpeg_hip_adapt_quant(const uint32_t* hist, int yuv_mode, uint8_t quant[2][64],
+                           const uint8_t* min_quant, int q_bias, int qdelta_max_luma,
+                           int qdelta_max_chroma, sjpeg_hip_scan_tables* tables) {
+  uint8_t mq[2][64];
+  if (min_quant != nullptr) memcpy(mq, min_quant, sizeof(mq)); else memset(mq, 1, sizeof(mq));
+  const int nb_comps = (yuv_mode == SJPEG_HIP_YUV400) ? 1 : 3;
+  sjpeg_host::AdaptQuantMatrices(reinterpret_cast<const uint32_t(*)[64][128]>(hist), nb_comps, quant, mq,
+                                 qdelta_max_luma, qdelta_max_chroma);
+  for (int idx = (nb_comps > 1 ? 1 : 0); idx >= 0; --idx) {
+    sjpeg_host::FinalizeQuantizer(quant[idx], mq[idx], q_bias, idx, tables);
+  }
+}
+
+void sjpeg_hip_optimize_huffman(const uint32_t* freq, int yuv_mode, sjpeg_hip_huffman_spec specs[4],
+                                sjpeg_hip_scan_tables* tables) {
+  const int ntables = (yuv_mode == SJPEG_HIP_YUV400) ? 1 : 2;
+  const HuffSpec* dc[2] = {&sjpeg_host::DefaultHuff(0, 0), &sjpeg_host::DefaultHuff(0, 1)};
+  const HuffSpec* ac[2] = {&sjpeg_host::DefaultHuff(1, 0), &sjpeg_host::DefaultHuff(1, 1)};
+  for (int t = 0; t < ntables; ++t) {
+    sjpeg_host::BuildOptimalSpec(freq + t * 272 + 256, 12, &specs[t]);
+    sjpeg_host::BuildOptimalSpec(freq + t * 272, 256, &specs[2 + t]);
+    dc[t] = &specs[t];
+    ac[t] = &specs[2 + t];
+  }
+  sjpeg_host::InstallCodes(dc, ac, ntables, tables);
+}
+
+size_t sjpeg_hip_make_header_ex(int width, int height, int yuv_mode, const uint8_t quant[2][64],
+                                const sjpeg_hip_huffman_spec* specs, uint8_t* buf, size_t cap) {
+  if (buf == nullptr || width <= 0 || height <= 0 || width > 65535 || height > 65535) return 0;
+  const HuffSpec* dc[2] = {&sjpeg_host::DefaultHuff(0, 0), &sjpeg_host::DefaultHuff(0, 1)};
+  const HuffSpec* ac[2] = {&sjpeg_host::DefaultHuff(1, 0), &sjpeg_host::DefaultHuff(1, 1)};
+  if (specs != nullptr) {
+    const int ntables = (yuv_mode == SJPEG_HIP_YUV400) ? 1 : 2;
+    for (int t = 0; t < ntables; ++t) { dc[t] = &specs[t]; ac[t] = &specs[2 + t]; }
+  }
   std::vector<uint8_t> h;
   if (!sjpeg_host::AppendHeaders(width, height, yuv_mode, quant, dc, ac, nullptr, &h)) return 0;
   if (h.size() > cap) return 0;

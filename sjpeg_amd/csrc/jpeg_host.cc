@@ -246,3 +246,177 @@ bool AppendHeaders(int W, int H, int yuv_mode, const uint8_t quant[2][64],
 }
 
 }  // namespace sjpeg_host
+
+// ------------------------------------------------------------------------------------------
+// Adaptive quantization (method >= 3) and optimised Huffman tables (method 1, 4..): host-side
+// analysis of statistics gathered on the GPU.  Floating-point expressions keep the reference's
+// types and evaluation order so that every integer decision comes out identical.
+
+#include <float.h>
+#include <stdlib.h>
+
+namespace sjpeg_host {
+
+namespace {
+enum { kQDeltaMin = -12, kQDeltaMax = 12, kQSize = kQDeltaMax + 1 - kQDeltaMin };   // sjpegi.h:269-273
+// Gaussian weights, sigma ~ 3, centred on delta 0 (histogram.cc:117-124)
+const float kDeltaWeight[kQSize] = {0, 0, 0, 0, 0, 1, 5, 16, 43, 94, 164, 228, 255,
+                                    228, 164, 94, 43, 16, 5, 1, 0, 0, 0, 0, 0};
+int BitLength(int v) { int n = 0; while (v) { ++n; v >>= 1; } return n; }
+}  // namespace
+
+void AdaptQuantMatrices(const uint32_t hist[2][64][128], int nb_comps, uint8_t quant[2][64],
+                        const uint8_t min_quant[2][64], int qdelta_max_luma, int qdelta_max_chroma) {
+  const double r_limit = 0.5;                       // kCorrelationThreshold
+  for (int idx = (nb_comps > 1 ? 1 : 0); idx >= 0; --idx) {
+    const int delta_max = ((idx == 0) ? qdelta_max_luma : qdelta_max_chroma) - kQDeltaMin;
+    static thread_local float sizes[64][kQSize];
+    static thread_local float distortions[64][kQSize];
+    double num = 0., den = 0.;
+    uint64_t omit = 0x103ull;                       // DC and its two neighbours are never touched
+    for (int pos = 0; pos < 64; ++pos) {
+      if (omit & (1ull << pos)) continue;
+      const int dq0 = quant[idx][pos];
+      const int min_dq0 = min_quant[idx][pos];
+      const int bias = 1 << 16 >> 1;
+      const uint32_t* const h = hist[idx][pos];
+      int total = 0, last = 0;
+      for (int i = 0; i < 128; ++i) {
+        total += static_cast<int>(h[i]);
+        if (h[i]) last = i + 1;
+      }
+      if (total < 0.5 * last) {                     // kDensityThreshold
+        omit |= 1ull << pos;
+        continue;
+      }
+      double sw = 0., sx = 0., sxx = 0., syy1 = 0., sy1 = 0., sxy1 = 0., sy2 = 0., sxy2 = 0.;
+      for (int delta = 0; delta < kQSize; ++delta) {
+        double bsum = 0., dsum = 0.;
+        const int dq = dq0 + (delta + kQDeltaMin);
+        if (dq >= min_dq0 && dq <= 255) {
+          const int idq = ((1 << 16) + dq - 1) / dq;
+          for (int i = 0; i < last; ++i) {
+            if (h[i]) {
+              const int hi = static_cast<int>(h[i]);
+              const int v = (i << 2) + 2;           // bin centroid: HSHIFT = 2, HHALF = 2
+              const int qv = (v * idq + bias) >> 16;
+              if (qv) {
+                const int bits = BitLength(qv);
+                const int dqv = qv * dq;
+                const int error = (v - dqv) * (v - dqv);
+                bsum += hi * bits;
+                dsum += hi * error;
+              } else {
+                dsum += hi * v * v;
+              }
+            }
+          }
+          distortions[pos][delta] = static_cast<float>(dsum);
+          sizes[pos][delta] = static_cast<float>(bsum);
+          const double w = kDeltaWeight[delta];
+          if (w > 0.) {
+            const double x = static_cast<double>(delta + kQDeltaMin);
+            sw += w;
+            sx += w * x;
+            sxx += w * x * x;
+            sy1 += w * dsum;
+            syy1 += w * dsum * dsum;
+            sy2 += w * bsum;
+            sxy1 += w * dsum * x;
+            sxy2 += w * bsum * x;
+          }
+        } else {
+          distortions[pos][delta] = FLT_MAX;
+          sizes[pos][delta] = 0;
+        }
+      }
+      const double cov_xy1 = sw * sxy1 - sx * sy1;
+      if (cov_xy1 * cov_xy1 < r_limit * (sw * sxx - sx * sx) * (sw * syy1 - sy1 * sy1)) {
+        omit |= 1ull << pos;
+        continue;
+      }
+      num += cov_xy1;
+      den += sw * sxy2 - sx * sy2;
+    }
+    double lambda = 0x80;                           // HLAMBDA
+    if (num > 1000. && den < -10.) {
+      lambda = -num / den;
+      if (lambda < 1.) lambda = 1.;
+    }
+    for (int pos = 0; pos < 64; ++pos) {
+      if (omit & (1ull << pos)) continue;
+      float best_score = FLT_MAX;
+      int best_dq = 0;
+      for (int delta = 0; delta <= delta_max; ++delta) {
+        if (distortions[pos][delta] < FLT_MAX) {
+          const float score = distortions[pos][delta] + lambda * sizes[pos][delta];
+          if (score < best_score) {
+            best_score = score;
+            best_dq = delta + kQDeltaMin;
+          }
+        }
+      }
+      quant[idx][pos] = static_cast<uint8_t>(quant[idx][pos] + best_dq);
+    }
+  }
+}
+
+void BuildOptimalSpec(const uint32_t* freq, int size, HuffSpec* out) {
+  enum { kMaxBits = 32, kMaxCodeSize = 16 };
+  int codesizes[257], chain[257], chain_end[257];   // chain_end: index of the tail of i's chain
+  uint64_t sorted[257];
+  int nb_syms = 0;
+  for (int i = 0; i < size; ++i) {
+    if (freq[i] > 0) sorted[nb_syms++] = (static_cast<uint64_t>(freq[i]) << 9) | static_cast<uint64_t>(i);
+    codesizes[i] = 0; chain[i] = -1; chain_end[i] = i;
+  }
+  out->nsyms = nb_syms;
+  // decreasing (frequency, symbol): keys are unique, so any correct sort gives the same order
+  std::sort(sorted, sorted + nb_syms, [](uint64_t a, uint64_t b) { return a > b; });
+  // pseudo symbol of lowest frequency: takes the all-ones code, which JPEG forbids
+  sorted[nb_syms++] = (1ull << 9) | static_cast<uint64_t>(size);
+  codesizes[size] = 0; chain[size] = -1; chain_end[size] = size;
+  for (int nb = nb_syms - 1; nb >= 1; --nb) {       // Huffman merging, least frequent pair first
+    const uint64_t s1 = sorted[nb - 1], s2 = sorted[nb];
+    int i = static_cast<int>(s1 & 0x1ff);
+    const int j = static_cast<int>(s2 & 0x1ff);
+    chain[chain_end[i]] = j;
+    chain_end[i] = chain_end[j];
+    for (int t = i; t >= 0; t = chain[t]) ++codesizes[t];
+    const uint64_t merged = s1 + (s2 & ~0x1ffull);
+    int k = nb - 1;
+    while (k > 0 && sorted[k - 1] < merged) { sorted[k] = sorted[k - 1]; --k; }
+    sorted[k] = merged;
+  }
+  uint8_t bits[kMaxBits];
+  memset(bits, 0, sizeof(bits));
+  int max_bits = 0;
+  for (int i = 0; i <= size; ++i) {
+    int s = codesizes[i];
+    if (s > 0) {
+      if (s > kMaxBits) { s = kMaxBits; codesizes[i] = kMaxBits; }
+      ++bits[s - 1];
+      if (s > max_bits) max_bits = s;
+    }
+  }
+  int start[kMaxBits], position = 0;
+  for (int i = 0; i < max_bits; ++i) { start[i] = position; position += bits[i]; }
+  memset(out->syms, 0, sizeof(out->syms));
+  for (int sym = 0; sym < size; ++sym) {            // symbols by increasing code length
+    const int s = codesizes[sym];
+    if (s > 0) out->syms[start[s - 1]++] = static_cast<uint8_t>(sym);
+  }
+  for (int l = max_bits - 1; l >= kMaxCodeSize; --l) {   // limit to 16 bits (Annex K.2 style)
+    while (bits[l] > 0) {
+      int k = l - 2;
+      while (bits[k] == 0) --k;
+      bits[l] -= 2; bits[l - 1] += 1; bits[k] -= 1; bits[k + 1] += 2;
+    }
+  }
+  max_bits = kMaxCodeSize;
+  while (bits[--max_bits] == 0) {}
+  --bits[max_bits];                                 // drop the pseudo symbol
+  for (int i = 0; i < kMaxCodeSize; ++i) out->bits[i] = bits[i];
+}
+
+}  // namespace sjpeg_host

@@ -20,11 +20,7 @@ extern const uint8_t kZigzag[64];           // zig-zag position -> natural index
 extern const uint8_t kAnnexK1[2][64];       // default luma/chroma matrices, natural order
 
 // A Huffman table in DHT form: BITS (codes per length 1..16) + HUFFVAL (symbols).
-struct HuffSpec {
-  uint8_t bits[16];
-  uint8_t syms[256];
-  int nsyms;
-};
+typedef sjpeg_hip_huffman_spec HuffSpec;
 const HuffSpec& DefaultHuff(int type /*0 DC, 1 AC*/, int comp /*0 luma, 1 chroma*/);
 
 // reference: GetQFactor / SetQuantMatrix, src/quantize.cc:77-96
@@ -62,6 +58,22 @@ struct Metadata {
 bool AppendHeaders(int W, int H, int yuv_mode, const uint8_t quant[2][64],
                    const HuffSpec* dc[2], const HuffSpec* ac[2], const Metadata* meta,
                    std::vector<uint8_t>* out);
+
+}  // namespace sjpeg_host
+
+
+// ---- adaptive quantization and optimised Huffman tables (host analysis; the statistics they
+// consume are collected by the GPU: sjpeg_hip_scan_histogram / sjpeg_hip_scan_symbol_stats) ----
+namespace sjpeg_host {
+
+// reference: Encoder::AnalyseHisto, src/histogram.cc:126-315.  hist[idx][pos][bin] counts the
+// coefficients of table idx (0 luma, 1 chroma) at NATURAL position pos with |c| >> 2 == bin
+// (bin < 128).  Rewrites quant[idx][pos] (within min_quant and the delta limits).
+void AdaptQuantMatrices(const uint32_t hist[2][64][128], int nb_comps, uint8_t quant[2][64],
+                        const uint8_t min_quant[2][64], int qdelta_max_luma, int qdelta_max_chroma);
+
+// reference: BuildOptimalTable, src/entropy.cc:254-430.  freq[size] -> DHT spec.
+void BuildOptimalSpec(const uint32_t* freq, int size, HuffSpec* out);
 
 }  // namespace sjpeg_host
 

@@ -79,7 +79,8 @@ struct ScanArgs {
   uint32_t* seg_words;     // [nframes*nseg][slot_words]
   uint32_t slot_words;
   uint32_t* seg_nbits;     // [nframes*nseg]
-  int16_t* coeffs;         // optional tap (TAP instantiation only)
+  int16_t* coeffs;         // kKindTap: quantized coefficients
+  uint32_t* partial;       // kKindHisto / kKindStats: per-workgroup partial statistics
   int ablate;              // profiling knob (env SJPEG_HIP_ABLATE): stop after phase 1/2/3; 0 = full
 };
 
@@ -375,7 +376,11 @@ __device__ __forceinline__ uint32_t wg_exclusive_scan(uint32_t x, uint32_t* scra
 // ------------------------------------------------------------------------------------
 // K1: colour + fDCT + quantize + entropy-code one segment
 
-template <int MODE, bool TAP>
+enum { kKindEncode = 0, kKindTap = 1, kKindHisto = 2, kKindStats = 3 };
+constexpr int kHistoWords = 2 * 64 * 32;          // per-workgroup partial: u8 counters [2][64][128]
+constexpr int kStatsWords = 2 * 272;              // per-workgroup partial: u32 [2][256 AC + 16 DC]
+
+template <int MODE, int KIND>
 __global__ __launch_bounds__(kThreads) void scan_segments(const ScanArgs a) {
   using G = Geo<MODE>;
   constexpr int BPM = G::kBpm;
@@ -538,6 +543,45 @@ __global__ __launch_bounds__(kThreads) void scan_segments(const ScanArgs a) {
   for (int c = 0; c < 4; ++c) {
     fdct_col8_pk(p[0][c], p[1][c], p[2][c], p[3][c], p[4][c], p[5][c], p[6][c], p[7][c]);
   }
+  if (KIND == kKindHisto) {
+    // Adaptive-quantization statistics (reference StoreHisto, src/histogram.cc:56-108): for every
+    // natural position, histogram of |coefficient| >> 2 (bins < 128), one histogram per
+    // quantizer table.  8-bit counters packed four to a word in LDS (a workgroup has at most
+    // 252 blocks), flushed as this workgroup's partial; reduce_partials() sums them.
+    __syncthreads();                            // every thread holds its samples: slots are free
+    uint32_t* const lh = reinterpret_cast<uint32_t*>(smem);
+    for (int i = tid; i < kHistoWords; i += kThreads) lh[i] = 0;
+    __syncthreads();
+    int acc[8];
+    auto bump = [&](int row, const int* ac8) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int c = ac8[i] >> 16;
+        const uint32_t bin = static_cast<uint32_t>(c < 0 ? -c : c) >> 2;
+        const bool ok = emits && bin < 128u;
+        // most coefficients fall in bin 0: count those lanes with one ballot per table
+        const unsigned long long z0 = __ballot(ok && bin == 0 && tbl == 0);
+        const unsigned long long z1 = __ballot(ok && bin == 0 && tbl == 1);
+        if ((tid & 63) == 0) {
+          if (z0) atomicAdd(&lh[(0 * 64 + row * 8 + i) * 32], static_cast<uint32_t>(__popcll(z0)));
+          if (z1) atomicAdd(&lh[(1 * 64 + row * 8 + i) * 32], static_cast<uint32_t>(__popcll(z1)));
+        }
+        if (ok && bin != 0) atomicAdd(&lh[(tbl * 64 + row * 8 + i) * 32 + (bin >> 2)], 1u << (8 * (bin & 3)));
+      }
+    };
+    fdct_row8_pk<22725, 21407, 19266, 16384, 12873, 8867, 4520>(p[0], acc); bump(0, acc);
+    fdct_row8_pk<31521, 29692, 26722, 22725, 17855, 12299, 6270>(p[1], acc); bump(1, acc);
+    fdct_row8_pk<29692, 27969, 25172, 21407, 16819, 11585, 5906>(p[2], acc); bump(2, acc);
+    fdct_row8_pk<26722, 25172, 22654, 19266, 15137, 10426, 5315>(p[3], acc); bump(3, acc);
+    fdct_row8_pk<22725, 21407, 19266, 16384, 12873, 8867, 4520>(p[4], acc); bump(4, acc);
+    fdct_row8_pk<26722, 25172, 22654, 19266, 15137, 10426, 5315>(p[5], acc); bump(5, acc);
+    fdct_row8_pk<29692, 27969, 25172, 21407, 16819, 11585, 5906>(p[6], acc); bump(6, acc);
+    fdct_row8_pk<31521, 29692, 26722, 22725, 17855, 12299, 6270>(p[7], acc); bump(7, acc);
+    __syncthreads();
+    uint32_t* const dst = a.partial + (static_cast<size_t>(frame) * a.nseg + seg) * kHistoWords;
+    for (int i = tid; i < kHistoWords; i += kThreads) dst[i] = lh[i];
+    return;
+  }
   uint32_t nz_lo = 0, nz_hi = 0;
   uint32_t ent[32];                             // natural order, 2 entries per dword
   {
@@ -564,7 +608,7 @@ __global__ __launch_bounds__(kThreads) void scan_segments(const ScanArgs a) {
                                               kPairSel(kZig(i + 2), kZig(i + 3)));
     *reinterpret_cast<uint2*>(slot + 2 * i) = make_uint2(w0, w1);
   }
-  if (TAP) {
+  if (KIND == kKindTap) {
     if (emits) {
       const long long nblk_frame = static_cast<long long>(a.n_mcus) * BPM;
       const long long blk = frame * nblk_frame + static_cast<long long>(m_first - 1 + ml) * BPM + k;
@@ -605,6 +649,40 @@ __global__ __launch_bounds__(kThreads) void scan_segments(const ScanArgs a) {
   }
   __syncthreads();                                 // every pred has been read: tails are free again
   tail[0] = nz_lo; tail[1] = nz_hi; tail[2] = dc_word;
+
+  if (KIND == kKindStats) {
+    // Symbol statistics for optimised Huffman tables (reference AddEntropyStats,
+    // src/entropy.cc:208-227): per table, counts of AC symbols (run << 4 | size, ZRL, EOB) and
+    // of DC size categories.  LDS counters, flushed as this workgroup's partial.
+    uint32_t* const lf = win;                      // [2][272]: 256 AC then 16 DC
+    for (int i = tid; i < kStatsWords; i += kThreads) lf[i] = 0;
+    __syncthreads();
+    if (emits) {
+      uint32_t* const f = lf + tbl * 272;
+      {
+        const int diff = dc_val - pred;
+        const int ad = diff < 0 ? -diff : diff;
+        atomicAdd(&f[256 + (32 - __clz(ad))], 1u);
+      }
+      const uint16_t* const zz = reinterpret_cast<const uint16_t*>(slot);
+      unsigned long long m = (static_cast<unsigned long long>(nz_hi) << 32) | nz_lo;
+      int prev = 1;
+      while (m) {
+        const int i = __builtin_ctzll(m);
+        m &= m - 1;
+        const uint32_t mag = zz[i] & 0x7fffu;
+        const int run = i - prev;
+        prev = i + 1;
+        if (run >> 4) atomicAdd(&f[0xf0], static_cast<uint32_t>(run >> 4));
+        atomicAdd(&f[((run & 15) << 4) | (32 - __clz(mag))], 1u);
+      }
+      if (prev <= 63) atomicAdd(&f[0x00], 1u);
+    }
+    __syncthreads();
+    uint32_t* const dst = a.partial + (static_cast<size_t>(frame) * a.nseg + seg) * kStatsWords;
+    for (int i = tid; i < kStatsWords; i += kThreads) dst[i] = lf[i];
+    return;
+  }
 
   // The run/size coding of a block (src/entropy.cc:161-198) is a serial walk over its non-zero
   // coefficients.  Blocks are handed to threads sorted by their number of non-zeros (counting
@@ -773,6 +851,31 @@ __global__ __launch_bounds__(kThreads) void scan_segments(const ScanArgs a) {
     __syncthreads();
   }
   if (tid == 0) a.seg_nbits[static_cast<size_t>(frame) * a.nseg + seg] = total;
+}
+
+// ------------------------------------------------------------------------------------
+// Sums the per-workgroup partial statistics of one frame: out[frame][i] = sum over segments.
+// BYTES: partial words hold four 8-bit counters (histogram) -> four u32 outputs per word.
+template <bool BYTES>
+__global__ __launch_bounds__(kThreads) void reduce_partials(const uint32_t* part, int nseg, int words,
+                                                           uint32_t* out) {
+  const int frame = blockIdx.y;
+  const int w = blockIdx.x * kThreads + threadIdx.x;
+  if (w >= words) return;
+  const uint32_t* src = part + static_cast<size_t>(frame) * nseg * words + w;
+  if (BYTES) {
+    uint32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    for (int s = 0; s < nseg; ++s) {
+      const uint32_t v = src[static_cast<size_t>(s) * words];
+      s0 += v & 0xffu; s1 += (v >> 8) & 0xffu; s2 += (v >> 16) & 0xffu; s3 += v >> 24;
+    }
+    uint32_t* dst = out + (static_cast<size_t>(frame) * words + w) * 4;
+    dst[0] = s0; dst[1] = s1; dst[2] = s2; dst[3] = s3;
+  } else {
+    uint32_t sum = 0;
+    for (int s = 0; s < nseg; ++s) sum += src[static_cast<size_t>(s) * words];
+    out[static_cast<size_t>(frame) * words + w] = sum;
+  }
 }
 
 // ------------------------------------------------------------------------------------
@@ -1030,7 +1133,7 @@ struct sjpeg_hip_engine {
   int device = 0;
   DevBuf<DevTables> tables;
   DevBuf<uint8_t> header;
-  DevBuf<uint32_t> seg_words, seg_nbits, ubuf, chunk_ff;
+  DevBuf<uint32_t> seg_words, seg_nbits, ubuf, chunk_ff, partial;
   DevBuf<unsigned long long> seg_off, chunk_off;
   bool timing = false;
   int ablate = 0;
@@ -1052,7 +1155,7 @@ void digest_tables(const sjpeg_hip_scan_tables* t, DevTables* d) {
   memcpy(d->ac, t->ac_codes, sizeof(d->ac));
 }
 
-template <bool TAP>
+template <int TAP>
 int launch_scan(int mode, dim3 grid, hipStream_t st, const ScanArgs& a) {
   static const int kLdsPad = getenv("SJPEG_HIP_LDS_PAD") ? atoi(getenv("SJPEG_HIP_LDS_PAD")) : 0;  // occupancy experiments
   const int kLdsBytes = ::kLdsBytes + kLdsPad;
@@ -1100,6 +1203,7 @@ int prepare_scan(sjpeg_hip_engine* e, const void* d_rgb, int64_t row_stride, int
   a->slot_words = g->slot_words;
   a->seg_nbits = e->seg_nbits.p;
   a->coeffs = nullptr;
+  a->partial = nullptr;
   a->ablate = e->ablate;
   return 0;
 }
@@ -1145,7 +1249,7 @@ void sjpeg_hip_engine_destroy(sjpeg_hip_engine* e) {
   if (e == nullptr) return;
   (void)hipSetDevice(e->device);
   e->tables.release(); e->header.release(); e->seg_words.release(); e->seg_nbits.release();
-  e->ubuf.release(); e->chunk_ff.release(); e->seg_off.release(); e->chunk_off.release();
+  e->ubuf.release(); e->chunk_ff.release(); e->partial.release(); e->seg_off.release(); e->chunk_off.release();
   for (auto& ev : e->ev) if (ev) (void)hipEventDestroy(ev);
   delete e;
 }
@@ -1190,7 +1294,55 @@ int sjpeg_hip_scan_coeffs(sjpeg_hip_engine* e, const void* d_rgb, int64_t row_st
                               tables, st, &g, &a);
   if (rc) return rc;
   a.coeffs = d_coeffs;
-  return launch_scan<true>(yuv_mode, dim3(g.nseg, nframes), st, a);
+  return launch_scan<kKindTap>(yuv_mode, dim3(g.nseg, nframes), st, a);
+}
+
+static int scan_statistics(sjpeg_hip_engine* e, const void* d_rgb, int64_t row_stride,
+                           int64_t frame_stride, int width, int height, int yuv_mode, int nframes,
+                           const sjpeg_hip_scan_tables* tables, bool histogram, uint32_t* d_out,
+                           void* stream) {
+  if (d_out == nullptr) return fail(SJPEG_HIP_EINVAL, "output pointer == NULL");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  sjpeg_hip_scan_tables dummy;
+  if (tables == nullptr) {                        // the histogram does not depend on any table
+    memset(&dummy, 0, sizeof(dummy));
+    tables = &dummy;
+  }
+  FrameGeo g;
+  ScanArgs a;
+  int rc = prepare_scan(e, d_rgb, row_stride, frame_stride, width, height, yuv_mode, nframes,
+                        tables, st, &g, &a);
+  if (rc) return rc;
+  const int words = histogram ? kHistoWords : kStatsWords;
+  if ((rc = e->partial.ensure(static_cast<size_t>(nframes) * g.nseg * words))) return rc;
+  a.partial = e->partial.p;
+  if (histogram) rc = launch_scan<kKindHisto>(yuv_mode, dim3(g.nseg, nframes), st, a);
+  else rc = launch_scan<kKindStats>(yuv_mode, dim3(g.nseg, nframes), st, a);
+  if (rc) return rc;
+  const dim3 grid((words + kThreads - 1) / kThreads, nframes);
+  if (histogram) {
+    hipLaunchKernelGGL(reduce_partials<true>, grid, dim3(kThreads), 0, st, e->partial.p, g.nseg, words, d_out);
+  } else {
+    hipLaunchKernelGGL(reduce_partials<false>, grid, dim3(kThreads), 0, st, e->partial.p, g.nseg, words, d_out);
+  }
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int sjpeg_hip_scan_histogram(sjpeg_hip_engine* e, const void* d_rgb, int64_t row_stride,
+                             int64_t frame_stride, int width, int height, int yuv_mode, int nframes,
+                             uint32_t* d_hist, void* stream) {
+  return scan_statistics(e, d_rgb, row_stride, frame_stride, width, height, yuv_mode, nframes,
+                         nullptr, true, d_hist, stream);
+}
+
+int sjpeg_hip_scan_symbol_stats(sjpeg_hip_engine* e, const void* d_rgb, int64_t row_stride,
+                                int64_t frame_stride, int width, int height, int yuv_mode,
+                                int nframes, const sjpeg_hip_scan_tables* tables, uint32_t* d_freq,
+                                void* stream) {
+  if (tables == nullptr) return fail(SJPEG_HIP_EINVAL, "tables == NULL");
+  return scan_statistics(e, d_rgb, row_stride, frame_stride, width, height, yuv_mode, nframes,
+                         tables, false, d_freq, stream);
 }
 
 int sjpeg_hip_encode_scan(sjpeg_hip_engine* e, const void* d_rgb, int64_t row_stride,
@@ -1232,7 +1384,7 @@ int sjpeg_hip_encode_scan(sjpeg_hip_engine* e, const void* d_rgb, int64_t row_st
   s.sizes = reinterpret_cast<unsigned long long*>(d_sizes);
 
   if (e->timing) HIP_TRY(hipEventRecord(e->ev[0], st));
-  if ((rc = launch_scan<false>(yuv_mode, dim3(g.nseg, nframes), st, a))) return rc;
+  if ((rc = launch_scan<kKindEncode>(yuv_mode, dim3(g.nseg, nframes), st, a))) return rc;
   if (e->timing) HIP_TRY(hipEventRecord(e->ev[1], st));
 
   hipLaunchKernelGGL(scan_seg_offsets, dim3(nframes), dim3(kThreads), 0, st, s);

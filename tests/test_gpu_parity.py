@@ -164,6 +164,8 @@ def test_unsupported_requests_fail_loudly():
     img = synth.g_struct(32, 32, 1)
     assert sj.SjpegEncode(img, 75.0, 0, sj.YUV_SHARP) is None
     assert "not available" in sj.last_error()
+    assert sj.SjpegEncode(img, 75.0, 7, sj.YUV_420) is None        # trellis
+    assert "trellis" in sj.last_error()
     lib = sj.lib()
     out = C.POINTER(C.c_uint8)()
     assert lib.SjpegEncode(img.ctypes.data, 32, 32, 96, C.byref(out), 75.0, 0, 7) == 0   # bad mode
@@ -181,6 +183,66 @@ def test_concurrent_host_threads_are_deterministic(oracle):
     [t.start() for t in th]
     [t.join() for t in th]
     assert all(r == want for r in res)
+
+
+# ---- methods 1..6: adaptive quantization + optimised Huffman (default EncoderParam = 4) -------
+
+@pytest.mark.parametrize("mode", [1, 3, 4])
+def test_statistics_kernels_match_oracle(engine, oracle, mode):
+    for (w, h, gen) in ((64, 64, synth.g_struct), (250, 130, synth.g_noise), (1920, 1080, synth.g_struct),
+                        (17, 13, synth.g_noise)):
+        img = gen(w, h, 31)
+        hist = engine.scan_histogram(dev(img), mode)
+        tables, quant = sj.make_tables(quality=80.0)
+        freq = engine.scan_symbol_stats(dev(img), tables, mode)
+        torch.cuda.synchronize()
+        assert (hist[0].cpu().numpy().view(np.uint32) == oracle.histogram(img, mode)).all()
+        want = oracle.symbol_stats(img, quant, 0x78, mode)
+        assert (freq[0].cpu().numpy().view(np.uint32) == want).all()
+
+
+def test_golden_methods_host_api(golden_small):
+    n = 0
+    for key, want in golden_small.items():
+        img, mode, q, method = golden_input(key)
+        if method in (1, 3, 4):
+            got = sj.SjpegEncode(img, q, method, mode)
+            assert got is not None, sj.last_error()
+            assert got == want, key
+            n += 1
+    assert n == 9
+
+
+def test_methods_random_vs_oracle(oracle):
+    rng = np.random.RandomState(77)
+    for _ in range(40):
+        w, h = int(rng.randint(1, 160)), int(rng.randint(1, 160))
+        img = synth.g_struct(w, h, int(rng.randint(1 << 30))) if rng.rand() < 0.6 else \
+            rng.randint(0, 256, (h, w, 3)).astype(np.uint8)
+        mode = int(rng.choice([1, 3, 4]))
+        q = float(rng.choice([5, 40, 75, 92, 99]))
+        m = int(rng.choice([1, 2, 3, 4, 5, 6]))
+        got = sj.SjpegEncode(img, q, m, mode)
+        assert got == oracle.encode_method(img, q, mode, m), (w, h, mode, q, m, sj.last_error())
+
+
+def test_methods_full_size_digests(engine, digests):
+    frames = dev(synth.g_struct(3840, 2160))
+    for m in (1, 3, 4):
+        got = sj.encode_device_method(frames, 75.0, 1, m, engine=engine)[0]
+        d = digests[f"struct4k|420|q75|m{m}"]
+        assert len(got) == d["size"] and hashlib.md5(got).hexdigest() == d["md5"], m
+    host = sj.SjpegEncode(synth.g_struct(3840, 2160), 75.0, 4, 1)
+    assert hashlib.md5(host).hexdigest() == digests["struct4k|420|q75|m4"]["md5"]
+
+
+def test_c5_recompress_default_params(engine, digests):
+    d = digests["recompress|r90|default"]
+    src = np.array(digests["recompress|r90|m0"]["source_quant"], np.uint8).reshape(2, 64)
+    quant = np.clip((src.astype(np.float64) * 100.0 / 90.0 + 0.5).astype(np.int64), 1, 255).astype(np.uint8)
+    got = sj.encode_device_method(dev(synth.g_struct(3840, 2160)), yuv_mode=1, method=4, engine=engine,
+                                  quant=quant, min_quant=quant)[0]
+    assert len(got) == d["size"] and hashlib.md5(got).hexdigest() == d["md5"]
 
 
 # ---- BASELINE.json full-size configurations --------------------------------------------------

@@ -134,6 +134,60 @@ def test_live_jpeg_tools_vs_reference(reference, golden_small):
             assert a == b
 
 
+def test_adapt_quant_matches_oracle(oracle):
+    """Host AnalyseHisto (product) vs the oracle's, on oracle-computed histograms."""
+    from oracle import synth
+    for (w, h, mode, q) in ((128, 96, 1, 75.0), (200, 120, 3, 90.0), (64, 64, 4, 50.0), (333, 211, 1, 30.0)):
+        for gen in (synth.g_struct, synth.g_noise):
+            img = gen(w, h, 5)
+            hist = oracle.histogram(img, mode)
+            _, quant = sj.make_tables(quality=q)
+            want, qs = oracle.adapt_quant(hist, 1 if mode == 4 else 3, quant)
+            t, got = sj.adapt_quant(hist, mode, quant)
+            assert (got == want).all(), (w, h, mode, q)
+            ncheck = 1 if mode == 4 else 2
+            for c in range(ncheck):
+                assert list(t.iquant[c]) == list(qs[c].iquant) and list(t.bias[c]) == list(qs[c].bias)
+
+
+def test_optimal_huffman_matches_oracle(oracle):
+    from oracle import synth
+    rng = np.random.RandomState(4)
+    cases = [oracle.symbol_stats(synth.g_struct(160, 96, 3), sj.make_tables(quality=75)[1], 0x78, 1),
+             oracle.symbol_stats(synth.g_noise(96, 96, 3), sj.make_tables(quality=95)[1], 0x78, 3)]
+    f = np.zeros((2, 272), np.uint32)
+    f[:, :256] = rng.randint(0, 2, (2, 256)) * rng.randint(1, 1 << 20, (2, 256))   # sparse, huge spread
+    f[:, 256:268] = rng.randint(1, 100, (2, 12))
+    cases.append(f)
+    g = np.zeros((2, 272), np.uint32)                   # Fibonacci counts: code lengths up to 27
+    fib = [1, 1]                                        # bits, exercising the 16-bit limiter
+    while len(fib) < 28:
+        fib.append(fib[-1] + fib[-2])
+    g[:, 1:29] = np.array(fib, np.uint32)
+    g[:, 256:268] = np.array(fib[:12], np.uint32)
+    cases.append(g)
+    for freq in cases:
+        t = sj.ScanTables()
+        specs = sj.optimize_huffman(freq, 1, t)
+        for tbl in range(2):
+            for kind, off, size in ((0, 256, 12), (2, 0, 256)):
+                bits, syms, n = oracle.build_optimal(freq[tbl, off:off + size], size)
+                sp = specs[kind + tbl]
+                assert sp.nsyms == n and list(sp.bits) == list(bits) and list(sp.syms[:n]) == list(syms)
+                assert sum(sp.bits) == n and all(b >= 0 for b in sp.bits)
+
+
+def test_header_with_custom_tables_matches_golden(golden_small, oracle, img128):
+    # method-1 golden stream: its header must be reproduced from oracle statistics
+    want = golden_small["test128|128x128|420|q75|m1"]
+    _, quant = sj.make_tables(quality=75)
+    freq = oracle.symbol_stats(img128, quant, 0x78, 1)
+    t, _ = sj.make_tables(quality=75)
+    specs = sj.optimize_huffman(freq, 1, t)
+    h = sj.make_header_ex(128, 128, 1, quant, specs)
+    assert want[:len(h)] == h
+
+
 def test_invalid_arguments_fail_cleanly():
     # reference: unit_test.cc:165-193 -- all of these return 0 without touching the GPU
     img = np.zeros((8, 8, 3), np.uint8)
