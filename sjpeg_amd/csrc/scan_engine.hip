@@ -46,9 +46,10 @@ namespace {
 // ------------------------------------------------------------------------------------
 // geometry
 
-constexpr int kThreads = 256;        // 4 waves
+constexpr int kThreads = 256;        // stitch kernels (K2..K5): 4 waves
+constexpr int kScanThreads = 256;    // K1: 4 waves = 41 coded MCUs + 1 halo MCU in 4:2:0
 constexpr int kSlotBytes = 144;      // 64 int16 + 16 B pad: conflict-free ds_read_b128 per lane
-constexpr int kWinWords = 2048;      // LDS bit window, 32-bit MSB-first words (8 KiB)
+constexpr int kWinWords = 2048;       // LDS bit window, 32-bit MSB-first words (8 KiB)
 constexpr int kMaxBlockBits = 1728;  // 22 (DC) + 63*27 (AC) rounded up; reference bound enc.cc:206-209
 constexpr int kChunkWords = 1024;    // K3/K5 chunk: 4 KiB of un-stuffed stream
 constexpr int kChunkBytes = kChunkWords * 4;
@@ -81,17 +82,24 @@ struct ScanArgs {
   uint32_t* seg_nbits;     // [nframes*nseg]
   int16_t* coeffs;         // kKindTap: quantized coefficients
   uint32_t* partial;       // kKindHisto / kKindStats: per-workgroup partial statistics
+  unsigned long long* stamps;  // profiling (env SJPEG_HIP_STAMPS): 8 cycle stamps per workgroup
   int ablate;              // profiling knob (env SJPEG_HIP_ABLATE): stop after phase 1/2/3; 0 = full
 };
 
 // LDS carve (bytes), all offsets multiples of 16
-constexpr int kSamplesBytes = kThreads * kSlotBytes;            // 36864
+constexpr int kSamplesBytes = kScanThreads * kSlotBytes;        // 36864
 constexpr int kOffWin = kSamplesBytes;
-constexpr int kOffQ = kOffWin + kWinWords * 4 + 16;               // +1 spare word (16 B keeps alignment)
-constexpr int kOffAc = kOffQ + 2 * 64 * 8;
-constexpr int kOffDc = kOffAc + 2 * 256 * 4;
-constexpr int kOffMisc = kOffDc + 128;                          // scan scratch
-constexpr int kLdsBytes = kOffMisc + 64;
+// The quantizer table (1 KiB) and the DC codes are only read before the bit window is first
+// touched (P2 / DC coding), so they live INSIDE the window region.
+constexpr int kOffQ = kOffWin;                                  // uint4[64]
+constexpr int kOffDc = kOffWin + 1024;                          // uint32[24]
+constexpr int kOffAc = kOffWin + kWinWords * 4 + 16;            // +1 spare word (16 B keeps alignment)
+constexpr int kOffMisc = kOffAc + 2 * 256 * 4;                  // scan scratch
+constexpr int kLdsBytes = kOffMisc + 64;                        // 47184: three workgroups per CU
+constexpr int kOffStats = kLdsBytes;                            // kKindStats only: u32[2][272]
+constexpr int kLdsBytesStats = kOffStats + 2 * 272 * 4;
+static_assert(kWinWords * 4 >= 1024 + 96 && kWinWords >= 64 + 64 + kScanThreads, "window region too small");
+static_assert(3 * kLdsBytes <= 160 * 1024, "three workgroups per CU");
 
 // ------------------------------------------------------------------------------------
 // small device helpers
@@ -350,6 +358,7 @@ __device__ __forceinline__ void load_row8(const uint8_t* frame, long long row_st
 }
 
 // workgroup exclusive scan of one uint32 per thread; returns exclusive prefix, *total = sum
+template <int NT>
 __device__ __forceinline__ uint32_t wg_exclusive_scan(uint32_t x, uint32_t* scratch /*>=8 u32*/,
                                                       uint32_t* total) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -363,7 +372,7 @@ __device__ __forceinline__ uint32_t wg_exclusive_scan(uint32_t x, uint32_t* scra
   __syncthreads();
   uint32_t base = 0, sum = 0;
 #pragma unroll
-  for (int w = 0; w < kThreads / 64; ++w) {
+  for (int w = 0; w < NT / 64; ++w) {
     const uint32_t s = scratch[w];
     if (w < wave) base += s;
     sum += s;
@@ -381,7 +390,7 @@ constexpr int kHistoWords = 2 * 64 * 32;          // per-workgroup partial: u8 c
 constexpr int kStatsWords = 2 * 272;              // per-workgroup partial: u32 [2][256 AC + 16 DC]
 
 template <int MODE, int KIND>
-__global__ __launch_bounds__(kThreads) void scan_segments(const ScanArgs a) {
+__global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) {
   using G = Geo<MODE>;
   constexpr int BPM = G::kBpm;
   constexpr int PX = G::kMcuPx;
@@ -394,6 +403,12 @@ __global__ __launch_bounds__(kThreads) void scan_segments(const ScanArgs a) {
 
   const int tid = threadIdx.x;
   const int seg = blockIdx.x, frame = blockIdx.y;
+  auto stamp = [&](int k) {
+    if (a.stamps != nullptr && tid == 0) {
+      a.stamps[(static_cast<size_t>(frame) * a.nseg + seg) * 8 + k] = __builtin_readcyclecounter();
+    }
+  };
+  stamp(0);
   const int m_first = seg * G::kSegMcus;                       // first coded MCU of the segment
   const int n_coded = min(G::kSegMcus, a.n_mcus - m_first);
   const int halo = m_first > 0 ? 1 : 0;                        // previous MCU: DC predictors only
@@ -403,7 +418,7 @@ __global__ __launch_bounds__(kThreads) void scan_segments(const ScanArgs a) {
   {
     const DevTables* t = a.tables;
     if (tid < 64) lq[tid] = (&t->q[0][0])[tid];
-    for (int i = tid; i < 512; i += kThreads) lac[i] = (&t->ac[0][0])[i];
+    for (int i = tid; i < 512; i += kScanThreads) lac[i] = (&t->ac[0][0])[i];
     if (tid < 24) ldc[tid] = (&t->dc[0][0])[tid];
   }
 
@@ -418,7 +433,7 @@ __global__ __launch_bounds__(kThreads) void scan_segments(const ScanArgs a) {
     const int nstrips = 8 * per_row;
     const int rnd_y = 0;
     (void)rnd_y;
-    for (int s = tid; s < nstrips; s += kThreads) {
+    for (int s = tid; s < nstrips; s += kScanThreads) {
       const int yp = s / per_row;
       const int rem = s - yp * per_row;
       const int ml = ml_lo + rem / kStripsX;
@@ -485,6 +500,7 @@ __global__ __launch_bounds__(kThreads) void scan_segments(const ScanArgs a) {
     }
   }
   __syncthreads();
+  stamp(1);
   if (a.ablate == 1) return;
 
   // ---- P2: one thread per block: fix-up, fDCT, quantize ---------------------------------
@@ -550,7 +566,7 @@ __global__ __launch_bounds__(kThreads) void scan_segments(const ScanArgs a) {
     // 252 blocks), flushed as this workgroup's partial; reduce_partials() sums them.
     __syncthreads();                            // every thread holds its samples: slots are free
     uint32_t* const lh = reinterpret_cast<uint32_t*>(smem);
-    for (int i = tid; i < kHistoWords; i += kThreads) lh[i] = 0;
+    for (int i = tid; i < kHistoWords; i += kScanThreads) lh[i] = 0;
     __syncthreads();
     int acc[8];
     auto bump = [&](int row, const int* ac8) {
@@ -579,7 +595,7 @@ __global__ __launch_bounds__(kThreads) void scan_segments(const ScanArgs a) {
     fdct_row8_pk<31521, 29692, 26722, 22725, 17855, 12299, 6270>(p[7], acc); bump(7, acc);
     __syncthreads();
     uint32_t* const dst = a.partial + (static_cast<size_t>(frame) * a.nseg + seg) * kHistoWords;
-    for (int i = tid; i < kHistoWords; i += kThreads) dst[i] = lh[i];
+    for (int i = tid; i < kHistoWords; i += kScanThreads) dst[i] = lh[i];
     return;
   }
   uint32_t nz_lo = 0, nz_hi = 0;
@@ -623,6 +639,7 @@ __global__ __launch_bounds__(kThreads) void scan_segments(const ScanArgs a) {
 
   if (a.ablate == 2) { if (nz_lo + nz_hi + dc_val == 0x7fffffff) a.seg_nbits[0] = 1; return; }
 
+  stamp(2);
   // ---- P3: entropy coding ----------------------------------------------------------------
   // DC prediction (src/entropy.cc:133-150) through the 16 spare bytes of each slot.
   uint32_t* const tail = reinterpret_cast<uint32_t*>(slot + 128);
@@ -654,8 +671,8 @@ __global__ __launch_bounds__(kThreads) void scan_segments(const ScanArgs a) {
     // Symbol statistics for optimised Huffman tables (reference AddEntropyStats,
     // src/entropy.cc:208-227): per table, counts of AC symbols (run << 4 | size, ZRL, EOB) and
     // of DC size categories.  LDS counters, flushed as this workgroup's partial.
-    uint32_t* const lf = win;                      // [2][272]: 256 AC then 16 DC
-    for (int i = tid; i < kStatsWords; i += kThreads) lf[i] = 0;
+    uint32_t* const lf = reinterpret_cast<uint32_t*>(smem + kOffStats);   // [2][272]: 256 AC then 16 DC
+    for (int i = tid; i < kStatsWords; i += kScanThreads) lf[i] = 0;
     __syncthreads();
     if (emits) {
       uint32_t* const f = lf + tbl * 272;
@@ -680,7 +697,7 @@ __global__ __launch_bounds__(kThreads) void scan_segments(const ScanArgs a) {
     }
     __syncthreads();
     uint32_t* const dst = a.partial + (static_cast<size_t>(frame) * a.nseg + seg) * kStatsWords;
-    for (int i = tid; i < kStatsWords; i += kThreads) dst[i] = lf[i];
+    for (int i = tid; i < kStatsWords; i += kScanThreads) dst[i] = lf[i];
     return;
   }
 
@@ -691,7 +708,7 @@ __global__ __launch_bounds__(kThreads) void scan_segments(const ScanArgs a) {
   // consecutive blocks.  hist/perm live in the bit window, idle until pass 2.
   uint32_t* const hist = win;                      // [64]
   uint32_t* const bin_start = win + 64;            // [64]
-  uint32_t* const perm = win + 128;                // [kThreads]
+  uint32_t* const perm = win + 128;                // [kScanThreads]
   const uint32_t cnt = emits ? static_cast<uint32_t>(__popc(nz_lo) + __popc(nz_hi)) : 0u;
   if (tid < 64) hist[tid] = 0;
   __syncthreads();
@@ -710,7 +727,8 @@ __global__ __launch_bounds__(kThreads) void scan_segments(const ScanArgs a) {
   __syncthreads();
   perm[bin_start[cnt] + rank] = tid;
   __syncthreads();
-  const int blk = perm[tid];                        // the block this thread entropy-codes
+  stamp(3);
+  const int blk = (a.ablate == 20) ? tid : static_cast<int>(perm[tid]);   // the block this thread entropy-codes
   unsigned char* const bslot = smem + blk * kSlotBytes;
   uint32_t* const btail = reinterpret_cast<uint32_t*>(bslot + 128);
   const uint32_t b_dc = btail[2];
@@ -762,15 +780,17 @@ __global__ __launch_bounds__(kThreads) void scan_segments(const ScanArgs a) {
   }
   btail[3] = len;
   __syncthreads();
+  stamp(4);
   // offsets are a prefix sum in STREAM order (thread tid owns block tid here)
   uint32_t total;
-  const uint32_t my_start = wg_exclusive_scan(tail[3], misc, &total);
+  const uint32_t my_start = wg_exclusive_scan<kScanThreads>(tail[3], misc, &total);
   if (a.ablate == 3) { if (tid == 0) a.seg_nbits[static_cast<size_t>(frame) * a.nseg + seg] = total; return; }
   tail[3] = my_start;
   __syncthreads();
   const uint32_t start = btail[3];
   const uint32_t end = start + len;
 
+  stamp(5);
   // pass 2: emit into the LDS window, round by round (one round unless the segment
   // overflows the window); words are MSB-first, flushed coalesced to the segment's slot.
   uint32_t* const out_words = a.seg_words + (static_cast<size_t>(frame) * a.nseg + seg) * a.slot_words;
@@ -778,7 +798,7 @@ __global__ __launch_bounds__(kThreads) void scan_segments(const ScanArgs a) {
   uint32_t carry = 0;
   bool done = !b_emits;
   for (;;) {
-    for (int i = tid; i < kWinWords + 1; i += kThreads) win[i] = 0;
+    for (int i = tid; i < kWinWords + 1; i += kScanThreads) win[i] = 0;
     if (tid == 0) misc[8] = total;
     __syncthreads();
     if (tid == 0 && carry != 0) atomicOr(&win[0], carry);
@@ -841,16 +861,18 @@ __global__ __launch_bounds__(kThreads) void scan_segments(const ScanArgs a) {
       done = true;
     }
     __syncthreads();
+    stamp(6);
     const uint32_t filled = limit - base;          // bits valid in the window
     const bool last = (limit == total);
     const uint32_t nfull = last ? (filled + 31) >> 5 : filled >> 5;
-    for (uint32_t i = tid; i < nfull; i += kThreads) out_words[(base >> 5) + i] = win[i];
+    for (uint32_t i = tid; i < nfull; i += kScanThreads) out_words[(base >> 5) + i] = win[i];
     if (last) break;
     carry = win[filled >> 5];                      // partial word carried into the next window
     base += filled & ~31u;
     __syncthreads();
   }
   if (tid == 0) a.seg_nbits[static_cast<size_t>(frame) * a.nseg + seg] = total;
+  stamp(7);
 }
 
 // ------------------------------------------------------------------------------------
@@ -910,7 +932,7 @@ __global__ __launch_bounds__(kThreads) void scan_seg_offsets(const StitchArgs a)
     const int i = base + threadIdx.x;
     const uint32_t x = i < a.nseg ? nb[i] : 0u;
     uint32_t total;
-    const uint32_t ex = wg_exclusive_scan(x, scratch, &total);
+    const uint32_t ex = wg_exclusive_scan<kThreads>(x, scratch, &total);
     if (i < a.nseg) off[i] = running + ex;
     running += total;
   }
@@ -1006,7 +1028,7 @@ __global__ __launch_bounds__(kThreads) void scan_chunk_offsets(const StitchArgs 
     const uint32_t i = base + threadIdx.x;
     const uint32_t x = i < nchunks ? ff[i] : 0u;
     uint32_t total;
-    const uint32_t ex = wg_exclusive_scan(x, scratch, &total);
+    const uint32_t ex = wg_exclusive_scan<kThreads>(x, scratch, &total);
     if (i < nchunks) co[i] = running + ex;
     running += total;
   }
@@ -1055,7 +1077,7 @@ __global__ __launch_bounds__(kThreads) void stuff_chunks(const StitchArgs a) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) ffs += count_ff(w[j], valid - 4 * j);
     uint32_t total;
-    const uint32_t ex = wg_exclusive_scan(ffs, scratch, &total);
+    const uint32_t ex = wg_exclusive_scan<kThreads>(ffs, scratch, &total);
     uint8_t* d = dst0 + byte0 + co[chunk] + ex;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
@@ -1134,7 +1156,9 @@ struct sjpeg_hip_engine {
   DevBuf<DevTables> tables;
   DevBuf<uint8_t> header;
   DevBuf<uint32_t> seg_words, seg_nbits, ubuf, chunk_ff, partial;
-  DevBuf<unsigned long long> seg_off, chunk_off;
+  DevBuf<unsigned long long> seg_off, chunk_off, stamps;
+  bool want_stamps = false;
+  size_t stamps_n = 0;
   bool timing = false;
   int ablate = 0;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -1158,16 +1182,16 @@ void digest_tables(const sjpeg_hip_scan_tables* t, DevTables* d) {
 template <int TAP>
 int launch_scan(int mode, dim3 grid, hipStream_t st, const ScanArgs& a) {
   static const int kLdsPad = getenv("SJPEG_HIP_LDS_PAD") ? atoi(getenv("SJPEG_HIP_LDS_PAD")) : 0;  // occupancy experiments
-  const int kLdsBytes = ::kLdsBytes + kLdsPad;
+  const int kLdsBytes = (TAP == kKindStats ? ::kLdsBytesStats : ::kLdsBytes) + kLdsPad;
   switch (mode) {
     case SJPEG_HIP_YUV420:
-      hipLaunchKernelGGL((scan_segments<SJPEG_HIP_YUV420, TAP>), grid, dim3(kThreads), kLdsBytes, st, a);
+      hipLaunchKernelGGL((scan_segments<SJPEG_HIP_YUV420, TAP>), grid, dim3(kScanThreads), kLdsBytes, st, a);
       break;
     case SJPEG_HIP_YUV444:
-      hipLaunchKernelGGL((scan_segments<SJPEG_HIP_YUV444, TAP>), grid, dim3(kThreads), kLdsBytes, st, a);
+      hipLaunchKernelGGL((scan_segments<SJPEG_HIP_YUV444, TAP>), grid, dim3(kScanThreads), kLdsBytes, st, a);
       break;
     default:
-      hipLaunchKernelGGL((scan_segments<SJPEG_HIP_YUV400, TAP>), grid, dim3(kThreads), kLdsBytes, st, a);
+      hipLaunchKernelGGL((scan_segments<SJPEG_HIP_YUV400, TAP>), grid, dim3(kScanThreads), kLdsBytes, st, a);
       break;
   }
   HIP_TRY(hipGetLastError());
@@ -1205,6 +1229,12 @@ int prepare_scan(sjpeg_hip_engine* e, const void* d_rgb, int64_t row_stride, int
   a->coeffs = nullptr;
   a->partial = nullptr;
   a->ablate = e->ablate;
+  a->stamps = nullptr;
+  if (e->want_stamps) {
+    if (int rc2 = e->stamps.ensure(total_segs * 8)) return rc2;
+    a->stamps = e->stamps.p;
+    e->stamps_n = total_segs * 8;
+  }
   return 0;
 }
 
@@ -1241,6 +1271,7 @@ int sjpeg_hip_engine_create(int device, sjpeg_hip_engine** engine) {
   if (e == nullptr) return fail(SJPEG_HIP_ENOMEM, "host allocation failed");
   e->device = device;
   if (const char* ab = getenv("SJPEG_HIP_ABLATE")) e->ablate = atoi(ab);   // profiling only
+  e->want_stamps = getenv("SJPEG_HIP_STAMPS") != nullptr;
   *engine = e;
   return 0;
 }
@@ -1260,6 +1291,14 @@ size_t sjpeg_hip_frame_bound(int width, int height, int yuv_mode, size_t header_
   // un-stuffed worst case = slots; stuffing at most doubles it
   const size_t unstuffed = static_cast<size_t>(g.nseg) * g.slot_words * 4;
   return header_size + 2 * unstuffed + 2 + 64;
+}
+
+// profiling only (not in the public header): copies the per-workgroup cycle stamps of the last scan
+size_t sjpeg_hip_debug_stamps(sjpeg_hip_engine* e, unsigned long long* out, size_t cap) {
+  if (e == nullptr || !e->want_stamps || e->stamps.p == nullptr) return 0;
+  const size_t n = e->stamps_n < cap ? e->stamps_n : cap;
+  if (hipMemcpy(out, e->stamps.p, n * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return 0;
+  return n;
 }
 
 int sjpeg_hip_engine_set_timing(sjpeg_hip_engine* e, int enable) {
