@@ -965,15 +965,39 @@ __global__ __launch_bounds__(kThreads) void concat_chunks(const StitchArgs a) {
     unsigned long long pos = w0 * 32;
     uint32_t ffs = 0;
     if (pos < U * 8) {
-      // segment containing bit `pos`: largest s with off[s] <= pos
-      int lo = 0, hi = a.nseg - 1;
-      while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (off[mid] <= pos) lo = mid; else hi = mid - 1;
+      // segment containing bit `pos`: largest s with off[s] <= pos.  Segments have similar
+      // lengths, so interpolate and walk a few steps; bisect only if the guess is far off.
+      int s = static_cast<int>(static_cast<float>(pos) / static_cast<float>(T) * static_cast<float>(a.nseg));
+      s = min(max(s, 0), a.nseg - 1);
+      int steps = 0;
+      while (steps < 6 && off[s] > pos) { --s; ++steps; }
+      while (steps < 6 && off[s + 1] <= pos) { ++s; ++steps; }
+      if (off[s] > pos || off[s + 1] <= pos) {
+        int lo = 0, hi = a.nseg - 1;
+        while (lo < hi) {
+          const int mid = (lo + hi + 1) >> 1;
+          if (off[mid] <= pos) lo = mid; else hi = mid - 1;
+        }
+        s = lo;
       }
-      int s = lo;
       unsigned long long s_beg = off[s], s_end = off[s + 1];
       uint32_t words[4];
+      if (pos + 128 <= s_end) {
+        // common case: the 128 bits come from ONE segment -> five source words, funnel shifts
+        const uint32_t r = static_cast<uint32_t>(pos - s_beg);
+        const uint32_t* src = segw + static_cast<size_t>(s) * a.slot_words + (r >> 5);
+        const uint32_t sh = r & 31u;
+        uint32_t v[5];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) v[j] = src[j];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          words[j] = __builtin_amdgcn_alignbit(v[j], v[j + 1], 32u - sh);   // (v[j]:v[j+1]) >> (32 - sh)
+          if (sh == 0) words[j] = v[j];
+          ffs += count_ff(words[j], 4);
+        }
+        pos += 128;
+      } else
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         uint32_t outw = 0;
@@ -1055,6 +1079,9 @@ __global__ __launch_bounds__(kThreads) void scan_chunk_offsets(const StitchArgs 
 
 __global__ __launch_bounds__(kThreads) void stuff_chunks(const StitchArgs a) {
   __shared__ uint32_t scratch[16];
+  // stuffed bytes of one chunk (<= 2 * 4 KiB), placed so that LDS words line up with the
+  // 4-byte words of the destination: the copy-out is aligned dword stores
+  __shared__ __attribute__((aligned(16))) uint8_t stage[2 * kChunkBytes + 16];
   const int frame = blockIdx.y;
   const unsigned long long T = a.seg_off[static_cast<size_t>(frame) * (a.nseg + 1) + a.nseg];
   const unsigned long long U = (T + 7) >> 3;
@@ -1076,17 +1103,37 @@ __global__ __launch_bounds__(kThreads) void stuff_chunks(const StitchArgs a) {
     uint32_t ffs = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) ffs += count_ff(w[j], valid - 4 * j);
-    uint32_t total;
-    const uint32_t ex = wg_exclusive_scan<kThreads>(ffs, scratch, &total);
-    uint8_t* d = dst0 + byte0 + co[chunk] + ex;
+    uint32_t total_ff;
+    const uint32_t ex = wg_exclusive_scan<kThreads>(ffs, scratch, &total_ff);
+    uint8_t* const dchunk = dst0 + static_cast<unsigned long long>(chunk) * kChunkBytes + co[chunk];
+    const uint32_t mis = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(dchunk) & 3u);
+    uint8_t* sp = stage + mis + threadIdx.x * 16 + ex;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
       if (j < valid) {
         const uint8_t b = static_cast<uint8_t>(w[j >> 2] >> (24 - 8 * (j & 3)));
-        *d++ = b;
-        if (b == 0xff) *d++ = 0x00;
+        *sp++ = b;
+        if (b == 0xff) *sp++ = 0x00;
       }
     }
+    __syncthreads();
+    const unsigned long long rest = U - static_cast<unsigned long long>(chunk) * kChunkBytes;
+    const uint32_t nbytes = static_cast<uint32_t>(rest < kChunkBytes ? rest : kChunkBytes) + total_ff;
+    // bytes [mis, mis + nbytes) of `stage` go to dchunk - mis + [mis, ...): whole words in
+    // the middle, single bytes at the two ragged ends
+    uint8_t* const dalign = dchunk - mis;
+    const uint32_t lo = mis, hi = mis + nbytes;
+    const uint32_t first_full = (lo + 3u) & ~3u, last_full = hi & ~3u;
+    if (first_full <= last_full) {
+      for (uint32_t i = first_full / 4 + threadIdx.x; i < last_full / 4; i += kThreads) {
+        reinterpret_cast<uint32_t*>(dalign)[i] = reinterpret_cast<const uint32_t*>(stage)[i];
+      }
+      if (threadIdx.x < first_full - lo) dalign[lo + threadIdx.x] = stage[lo + threadIdx.x];
+      if (threadIdx.x < hi - last_full) dalign[last_full + threadIdx.x] = stage[last_full + threadIdx.x];
+    } else {
+      if (threadIdx.x < nbytes) dalign[lo + threadIdx.x] = stage[lo + threadIdx.x];
+    }
+    __syncthreads();
   }
 }
 
@@ -1428,6 +1475,7 @@ int sjpeg_hip_encode_scan(sjpeg_hip_engine* e, const void* d_rgb, int64_t row_st
 
   hipLaunchKernelGGL(scan_seg_offsets, dim3(nframes), dim3(kThreads), 0, st, s);
   HIP_TRY(hipGetLastError());
+  // the chunk count is only known on the device: a fixed grid strides over the chunks
   uint32_t gx = 4096u / static_cast<uint32_t>(nframes);
   if (gx < 64) gx = 64;
   if (gx > max_chunks) gx = max_chunks;
