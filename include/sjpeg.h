@@ -139,6 +139,34 @@ size_t Encode(const uint8_t* rgb, int width, int height, int stride,
 bool Encode(const uint8_t* rgb, int width, int height, int stride,
             const EncoderParam& param, sjpeg::ByteSink* sink);
 
+// Other input layouts, reference: src/sjpeg.h:300-349.  BGRA/RGBA: 4 bytes per pixel, alpha
+// ignored, stride >= 4*width.  Gray: luma samples as they are (YUV 4:0:0).  NV12/NV21: luma
+// plane + interleaved U,V (resp. V,U) plane of (width+1)/2 x (height+1)/2 pairs (YUV 4:2:0).
+// YUV444 / YUV420: three planes.  The colour mode is implied by the layout for all but
+// BGRA/RGBA (where param.yuv_mode selects 420 / 444 / 400).
+bool EncodeBGRA(const uint8_t* bgra, int width, int height, int stride,
+                const EncoderParam& param, sjpeg::ByteSink* sink);
+bool EncodeBGRA(const uint8_t* bgra, int width, int height, int stride,
+                const EncoderParam& param, std::string* output);
+bool EncodeRGBA(const uint8_t* rgba, int width, int height, int stride,
+                const EncoderParam& param, sjpeg::ByteSink* sink);
+bool EncodeRGBA(const uint8_t* rgba, int width, int height, int stride,
+                const EncoderParam& param, std::string* output);
+bool EncodeGray(const uint8_t* gray, int width, int height, int stride,
+                const EncoderParam& param, sjpeg::ByteSink* sink);
+bool EncodeGray(const uint8_t* gray, int width, int height, int stride,
+                const EncoderParam& param, std::string* output);
+bool EncodeNV21(const uint8_t* y, int y_stride, const uint8_t* vu, int vu_stride,
+                int width, int height, const EncoderParam& param, sjpeg::ByteSink* output);
+bool EncodeNV12(const uint8_t* y, int y_stride, const uint8_t* uv, int uv_stride,
+                int width, int height, const EncoderParam& param, sjpeg::ByteSink* output);
+bool EncodeYUV444(const uint8_t* Y, int Y_stride, const uint8_t* U, int U_stride,
+                  const uint8_t* V, int V_stride, int width, int height,
+                  const EncoderParam& param, sjpeg::ByteSink* output);
+bool EncodeYUV420(const uint8_t* Y, int Y_stride, const uint8_t* U, int U_stride,
+                  const uint8_t* V, int V_stride, int width, int height,
+                  const EncoderParam& param, sjpeg::ByteSink* output);
+
 // reference: src/sjpeg.h:355-373
 struct SearchHook {
   float q;

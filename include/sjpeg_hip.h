@@ -59,6 +59,29 @@ typedef struct sjpeg_hip_scan_tables {
   uint32_t ac_codes[2][256];
 } sjpeg_hip_scan_tables;
 
+/* Pixel sources.  Packed colour and gray use plane[0]; planar YUV uses Y, U, V; NV12/NV21 use
+ * Y and the interleaved chroma plane in plane[1].  Chroma planes of the 4:2:0 layouts are
+ * (width+1)/2 x (height+1)/2 samples.  These replace the reference's input adapters
+ * Encoder420/444/400 (src/encoders.cc:157-253, packed RGB/BGRA/RGBA), Encoder400G (:256-276),
+ * EncoderNV12 (:281-344), EncoderYUV444 (:384-419) and EncoderYUV420 (:442-490). */
+enum {
+  SJPEG_HIP_SRC_RGB = 0,       /* 3 bytes/pixel R,G,B     -> any of 420 / 444 / 400 */
+  SJPEG_HIP_SRC_BGRA = 1,      /* 4 bytes/pixel B,G,R,A   -> any of 420 / 444 / 400 */
+  SJPEG_HIP_SRC_RGBA = 2,      /* 4 bytes/pixel R,G,B,A   -> any of 420 / 444 / 400 */
+  SJPEG_HIP_SRC_GRAY = 3,      /* 1 plane                 -> 400 */
+  SJPEG_HIP_SRC_YUV444 = 4,    /* 3 full-size planes      -> 444 */
+  SJPEG_HIP_SRC_YUV420 = 5,    /* Y + subsampled U, V     -> 420 */
+  SJPEG_HIP_SRC_NV12 = 6,      /* Y + interleaved U,V     -> 420 */
+  SJPEG_HIP_SRC_NV21 = 7       /* Y + interleaved V,U     -> 420 */
+};
+typedef struct sjpeg_hip_source {
+  int32_t format;              /* SJPEG_HIP_SRC_* */
+  int32_t reserved;            /* 0 */
+  const void* plane[3];        /* DEVICE pointers */
+  int64_t row_stride[3];       /* bytes between rows of each plane; may be negative */
+  int64_t frame_stride[3];     /* bytes between consecutive frames of a batch, per plane */
+} sjpeg_hip_source;
+
 /* A Huffman table in DHT form: BITS (number of codes of each length 1..16) and HUFFVAL
  * (symbols by increasing code length), reference struct HuffmanTable (src/sjpegi.h:221-225). */
 typedef struct sjpeg_hip_huffman_spec {
@@ -142,6 +165,24 @@ int sjpeg_hip_scan_symbol_stats(sjpeg_hip_engine* engine,
                                 int width, int height, int yuv_mode, int nframes,
                                 const sjpeg_hip_scan_tables* tables,
                                 uint32_t* d_freq, void* stream);
+
+/* The same four operations for any pixel source (the functions above are these with
+ * format = SJPEG_HIP_SRC_RGB).  yuv_mode must match the source where it is implied. */
+int sjpeg_hip_encode_scan_src(sjpeg_hip_engine* engine, const sjpeg_hip_source* src,
+                              int width, int height, int yuv_mode, int nframes,
+                              const sjpeg_hip_scan_tables* tables,
+                              const void* header, size_t header_size, int append_eoi,
+                              void* d_out, size_t out_stride, uint64_t* d_sizes, void* stream);
+int sjpeg_hip_scan_coeffs_src(sjpeg_hip_engine* engine, const sjpeg_hip_source* src,
+                              int width, int height, int yuv_mode, int nframes,
+                              const sjpeg_hip_scan_tables* tables, int16_t* d_coeffs, void* stream);
+int sjpeg_hip_scan_histogram_src(sjpeg_hip_engine* engine, const sjpeg_hip_source* src,
+                                 int width, int height, int yuv_mode, int nframes,
+                                 uint32_t* d_hist, void* stream);
+int sjpeg_hip_scan_symbol_stats_src(sjpeg_hip_engine* engine, const sjpeg_hip_source* src,
+                                    int width, int height, int yuv_mode, int nframes,
+                                    const sjpeg_hip_scan_tables* tables, uint32_t* d_freq,
+                                    void* stream);
 
 /* ---- host-side helpers (tiny CPU work, no device needed) -----------------------------
  * They produce exactly what the reference's host code would hand to its hot loop, so that

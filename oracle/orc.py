@@ -17,6 +17,26 @@ def build():
     subprocess.check_call(["make", "-s", "-C", _HERE, "all"])
 
 
+SRC_RGB, SRC_BGRA, SRC_RGBA, SRC_GRAY, SRC_YUV444, SRC_YUV420, SRC_NV12, SRC_NV21 = range(8)
+
+
+class Source(C.Structure):
+    """orc_source (oracle/sjpeg_oracle.h)."""
+    _fields_ = [("format", C.c_int), ("plane", C.c_void_p * 3), ("stride", C.c_int * 3)]
+
+
+def make_source(fmt, planes):
+    """planes: list of 2-D (or 3-D packed) uint8 arrays with contiguous rows; returns
+    (Source, keepalive)."""
+    ps = [np.ascontiguousarray(p, np.uint8) for p in planes]
+    s = Source()
+    s.format = fmt
+    for i, p in enumerate(ps):
+        s.plane[i] = p.ctypes.data
+        s.stride[i] = p.strides[0]
+    return s, ps
+
+
 class Quantizer(C.Structure):
     """orc_quantizer (oracle/sjpeg_oracle.h) == reference struct Quantizer minus codes_."""
     _fields_ = [("quant", C.c_uint8 * 64), ("min_quant", C.c_uint8 * 64),
@@ -57,6 +77,15 @@ class Oracle:
         lib.orc_encode_full.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                         C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_u8p)]
         lib.orc_histogram.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        lib.orc_encode_src.restype = C.c_size_t
+        lib.orc_encode_src.argtypes = [C.POINTER(Source), C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                       C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_u8p)]
+        lib.orc_histogram_src.argtypes = [C.POINTER(Source), C.c_int, C.c_int, C.c_int, C.c_void_p]
+        lib.orc_symbol_stats_src.argtypes = [C.POINTER(Source), C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                             C.c_int, C.c_void_p]
+        lib.orc_scan_coeffs_src.restype = C.c_size_t
+        lib.orc_scan_coeffs_src.argtypes = [C.POINTER(Source), C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                            C.c_int, C.c_void_p]
         lib.orc_symbol_stats.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                          C.c_int, C.c_void_p]
         lib.orc_build_optimal.restype = C.c_int
@@ -117,6 +146,17 @@ class Oracle:
         n = self.lib.orc_encode_full(rgb.ctypes.data, w, h, stride, q.ctypes.data,
                                      mq.ctypes.data if mq is not None else None, q_bias, dmax_luma,
                                      dmax_chroma, yuv_mode, method, C.byref(out))
+        return self._take(n, out)
+
+    def encode_src(self, fmt, planes, w, h, quant, min_quant=None, q_bias=0x78, dmax_luma=12,
+                   dmax_chroma=1, yuv_mode=YUV_420, method=0):
+        src, keep = make_source(fmt, planes)
+        q = np.ascontiguousarray(quant, np.uint8).reshape(2, 64)
+        mq = None if min_quant is None else np.ascontiguousarray(min_quant, np.uint8).reshape(2, 64)
+        out = _u8p()
+        n = self.lib.orc_encode_src(C.byref(src), w, h, q.ctypes.data,
+                                    mq.ctypes.data if mq is not None else None, q_bias, dmax_luma,
+                                    dmax_chroma, yuv_mode, method, C.byref(out))
         return self._take(n, out)
 
     def histogram(self, rgb, yuv_mode=YUV_420, stride=None):

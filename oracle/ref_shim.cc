@@ -55,6 +55,35 @@ size_t ref_compress(const uint8_t* rgb, int w, int h, float quality,
 
 void ref_free(uint8_t* p) { SjpegFreeBuffer(p); }
 
+// The other input layouts of the public API (src/sjpeg.h:300-349), all through a string sink.
+// format: 1 BGRA, 2 RGBA, 3 gray, 4 planar 4:4:4, 5 planar 4:2:0, 6 NV12, 7 NV21 (= oracle ORC_SRC_*).
+size_t ref_encode_src(int format, const uint8_t* p0, const uint8_t* p1, const uint8_t* p2,
+                      int s0, int s1, int s2, int w, int h, float quality, int yuv_mode,
+                      int huffman, int adaptive, uint8_t** out) {
+  sjpeg::EncoderParam param(quality);
+  param.yuv_mode = static_cast<SjpegYUVMode>(yuv_mode);
+  param.Huffman_compress = (huffman != 0);
+  param.adaptive_quantization = (adaptive != 0);
+  std::string str;
+  std::shared_ptr<sjpeg::ByteSink> sink = sjpeg::MakeByteSink(&str);
+  bool ok = false;
+  switch (format) {
+    case 1: ok = sjpeg::EncodeBGRA(p0, w, h, s0, param, sink.get()); break;
+    case 2: ok = sjpeg::EncodeRGBA(p0, w, h, s0, param, sink.get()); break;
+    case 3: ok = sjpeg::EncodeGray(p0, w, h, s0, param, sink.get()); break;
+    case 4: ok = sjpeg::EncodeYUV444(p0, s0, p1, s1, p2, s2, w, h, param, sink.get()); break;
+    case 5: ok = sjpeg::EncodeYUV420(p0, s0, p1, s1, p2, s2, w, h, param, sink.get()); break;
+    case 6: ok = sjpeg::EncodeNV12(p0, s0, p1, s1, w, h, param, sink.get()); break;
+    case 7: ok = sjpeg::EncodeNV21(p0, s0, p1, s1, w, h, param, sink.get()); break;
+    default: break;
+  }
+  *out = nullptr;
+  if (!ok || str.empty()) return 0;
+  *out = new uint8_t[str.size()];
+  memcpy(*out, str.data(), str.size());
+  return str.size();
+}
+
 // Stage seams (SURVEY.md §8c "Stage-level access").
 void ref_get_block(int yuv_mode, const uint8_t* rgb, int step, int16_t* out) {
   sjpeg::GetBlockFunc(static_cast<SjpegYUVMode>(yuv_mode))(rgb, step, out);

@@ -29,6 +29,10 @@ class Ref:
         lib.ref_encode_param.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float,
                                          C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                          C.c_float, C.c_int, C.c_int, C.POINTER(_u8p)]
+        lib.ref_encode_src.restype = C.c_size_t
+        lib.ref_encode_src.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                       C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int,
+                                       C.c_int, C.POINTER(_u8p)]
         lib.ref_compress.restype = C.c_size_t
         lib.ref_compress.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.POINTER(_u8p)]
         lib.ref_free.argtypes = [_u8p]
@@ -79,6 +83,18 @@ class Ref:
                                       int(huffman), int(adaptive), int(trellis),
                                       q.ctypes.data if q is not None else None, reduction,
                                       int(limit_quant), quant_bias, C.byref(out))
+        return self._take(n, out)
+
+    def encode_src(self, fmt, planes, w, h, quality=75.0, yuv_mode=YUV_420, huffman=False,
+                   adaptive=False):
+        """EncodeBGRA/RGBA/Gray/YUV444/YUV420/NV12/NV21 of the reference; planes = list of 2-D
+        uint8 arrays (rows contiguous), format numbering = oracle ORC_SRC_*."""
+        ps = [np.ascontiguousarray(p, np.uint8) for p in planes] + [None, None]
+        ptr = [p.ctypes.data if p is not None else None for p in ps[:3]]
+        st = [p.strides[0] if p is not None else 0 for p in ps[:3]]
+        out = _u8p()
+        n = self.lib.ref_encode_src(fmt, ptr[0], ptr[1], ptr[2], st[0], st[1], st[2], w, h, quality,
+                                    yuv_mode, int(huffman), int(adaptive), C.byref(out))
         return self._take(n, out)
 
     def compress(self, rgb, quality=75.0):

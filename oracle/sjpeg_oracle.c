@@ -226,49 +226,95 @@ static void block_fill(int16_t* b, int v) {
   for (int i = 0; i < 64; ++i) b[i] = (int16_t)v;
 }
 
-void orc_get_samples(int yuv_mode, const uint8_t* rgb, int W, int H, int stride,
-                     int mb_x, int mb_y, int16_t* out) {
+/* 8x8 block of an 8-bit plane, level shifted; coordinates clamp to the plane (this is what
+ * Convert8To16bClipped / Replicate8b do: src/colors_rgb.cc:1212-1260). step = bytes per sample. */
+static void plane_block(const uint8_t* p, int stride, int step, int pw, int ph, int x0, int y0,
+                        int16_t* out) {
+  for (int y = 0; y < 8; ++y) {
+    const int sy = (y0 + y < ph) ? y0 + y : ph - 1;
+    for (int x = 0; x < 8; ++x) {
+      const int sx = (x0 + x < pw) ? x0 + x : pw - 1;
+      out[y * 8 + x] = (int16_t)(p[(ptrdiff_t)sy * stride + (ptrdiff_t)sx * step] - 128);
+    }
+  }
+}
+
+static void luma_fixup_420(int sub_w, int sub_h, int16_t* out) {
+  /* src/encoders.cc:107-125: luma blocks lying wholly outside the picture become flat at
+   * the average of a neighbouring real block. */
+  int dc = block_avg(out);
+  if (sub_w <= 8) block_fill(out + 64, dc);
+  if (sub_h <= 8) {
+    if (sub_w > 8) dc = block_avg(out + 64);
+    block_fill(out + 128, dc);
+    block_fill(out + 192, dc);
+  } else if (sub_w <= 8) {
+    block_fill(out + 192, block_avg(out + 128));
+  }
+}
+
+void orc_get_samples_src(const orc_source* S, int yuv_mode, int W, int H, int mb_x, int mb_y,
+                         int16_t* out) {
   orc_layout L;
   if (!layout_for(yuv_mode, &L)) return;
   const int bw = L.block_w, bh = L.block_h;
   /* src/enc.cc:280-281,292: an MCU is "clipped" iff it is the partial last column/row */
   const int clipped = (mb_y == H / bh) || (mb_x == W / bw);
-  const uint8_t* src = rgb + (ptrdiff_t)(3 * mb_x) * bw + (ptrdiff_t)mb_y * stride * bh;
-  int step = stride;
-  uint8_t tmp[16 * 16 * 3];
   const int sub_w = W - mb_x * bw, sub_h = H - mb_y * bh;
-  if (clipped) {
-    /* src/colors_rgb.cc:1212-1232: copy the valid sub_w x sub_h corner, repeat the last
-     * valid column to the right, then the last (already widened) row downwards. */
-    const int vw = sub_w > bw ? bw : sub_w, vh = sub_h > bh ? bh : sub_h;
+  if (S->format <= ORC_SRC_RGBA) {
+    /* packed colour: 3 or 4 bytes per pixel (src/encoders.cc:157-253, colors_rgb.cc:882-1025) */
+    const int px = (S->format == ORC_SRC_RGB) ? 3 : 4;
+    const int ro = (S->format == ORC_SRC_BGRA) ? 2 : 0, bo = (S->format == ORC_SRC_BGRA) ? 0 : 2;
+    const int stride = S->stride[0];
+    const uint8_t* src = S->plane[0] + (ptrdiff_t)(px * mb_x) * bw + (ptrdiff_t)mb_y * stride * bh;
+    /* gather the MCU as tight RGB, clamping coordinates when clipped (Replicate8b) */
+    uint8_t tmp[16 * 16 * 3];
+    const int vw = (clipped && sub_w < bw) ? sub_w : bw, vh = (clipped && sub_h < bh) ? sub_h : bh;
     for (int y = 0; y < bh; ++y) {
       const int sy = y < vh ? y : vh - 1;
       for (int x = 0; x < bw; ++x) {
         const int sx = x < vw ? x : vw - 1;
-        memcpy(tmp + (y * bw + x) * 3, src + (ptrdiff_t)sy * stride + 3 * sx, 3);
+        const uint8_t* q = src + (ptrdiff_t)sy * stride + px * sx;
+        uint8_t* d = tmp + (y * bw + x) * 3;
+        d[0] = q[ro]; d[1] = q[1]; d[2] = q[bo];
       }
     }
-    src = tmp;
-    step = 3 * bw;
+    if (yuv_mode == ORC_YUV_420) {
+      mcu420_from_rgb(tmp, 3 * bw, out);
+      if (clipped) luma_fixup_420(sub_w, sub_h, out);
+    } else {
+      block8_from_rgb(tmp, 3 * bw, out, yuv_mode == ORC_YUV_444);
+    }
+    return;
   }
-  if (yuv_mode == ORC_YUV_420) {
-    mcu420_from_rgb(src, step, out);
-    if (clipped) {
-      /* src/encoders.cc:107-125: luma blocks lying wholly outside the picture become
-       * flat at the average of a neighbouring real block. */
-      int dc = block_avg(out);
-      if (sub_w <= 8) block_fill(out + 64, dc);
-      if (sub_h <= 8) {
-        if (sub_w > 8) dc = block_avg(out + 64);
-        block_fill(out + 128, dc);
-        block_fill(out + 192, dc);
-      } else if (sub_w <= 8) {
-        block_fill(out + 192, block_avg(out + 128));
-      }
-    }
+  /* 8-bit planes: samples are used as they are, minus 128 (src/encoders.cc:256-490) */
+  if (S->format == ORC_SRC_GRAY) {
+    plane_block(S->plane[0], S->stride[0], 1, W, H, mb_x * 8, mb_y * 8, out);
+  } else if (S->format == ORC_SRC_YUV444) {
+    for (int c = 0; c < 3; ++c) plane_block(S->plane[c], S->stride[c], 1, W, H, mb_x * 8, mb_y * 8, out + 64 * c);
   } else {
-    block8_from_rgb(src, step, out, yuv_mode == ORC_YUV_444);
+    for (int k = 0; k < 4; ++k) {
+      plane_block(S->plane[0], S->stride[0], 1, W, H, mb_x * 16 + 8 * (k & 1), mb_y * 16 + 8 * (k >> 1), out + 64 * k);
+    }
+    if (clipped) luma_fixup_420(sub_w, sub_h, out);
+    const int cw = (W + 1) >> 1, ch = (H + 1) >> 1;
+    if (S->format == ORC_SRC_YUV420) {
+      plane_block(S->plane[1], S->stride[1], 1, cw, ch, mb_x * 8, mb_y * 8, out + 4 * 64);
+      plane_block(S->plane[2], S->stride[2], 1, cw, ch, mb_x * 8, mb_y * 8, out + 5 * 64);
+    } else {   /* NV12: U,V,U,V...  NV21: V,U,V,U... */
+      const int uo = (S->format == ORC_SRC_NV12) ? 0 : 1;
+      plane_block(S->plane[1] + uo, S->stride[1], 2, cw, ch, mb_x * 8, mb_y * 8, out + 4 * 64);
+      plane_block(S->plane[1] + (1 - uo), S->stride[1], 2, cw, ch, mb_x * 8, mb_y * 8, out + 5 * 64);
+    }
   }
+}
+
+void orc_get_samples(int yuv_mode, const uint8_t* rgb, int W, int H, int stride,
+                     int mb_x, int mb_y, int16_t* out) {
+  orc_source S;
+  memset(&S, 0, sizeof(S));
+  S.format = ORC_SRC_RGB; S.plane[0] = rgb; S.stride[0] = stride;
+  orc_get_samples_src(&S, yuv_mode, W, H, mb_x, mb_y, out);
 }
 
 /* ---------------------------------------------------------------- forward DCT */
@@ -454,6 +500,14 @@ static void code_block(orc_bw* w, const int16_t zz[64], int* dc_pred,
 
 /* ---------------------------------------------------------------- scan drivers */
 
+static orc_source rgb_source(const uint8_t* rgb, int stride) {
+  orc_source S;
+  memset(&S, 0, sizeof(S));
+  S.format = ORC_SRC_RGB; S.plane[0] = rgb; S.stride[0] = stride;
+  return S;
+}
+
+
 typedef struct {
   orc_layout L;
   orc_quantizer q[2];
@@ -480,13 +534,19 @@ static int scan_init(orc_scan* s, int W, int H, int yuv_mode, const uint8_t quan
 
 size_t orc_scan_coeffs(const uint8_t* rgb, int W, int H, int stride, int yuv_mode,
                        const uint8_t quant[2][64], int q_bias, int16_t* zz) {
+  const orc_source S = rgb_source(rgb, stride);
+  return orc_scan_coeffs_src(&S, W, H, yuv_mode, quant, q_bias, zz);
+}
+
+size_t orc_scan_coeffs_src(const orc_source* S, int W, int H, int yuv_mode,
+                           const uint8_t quant[2][64], int q_bias, int16_t* zz) {
   orc_scan s;
   if (!scan_init(&s, W, H, yuv_mode, quant, NULL, q_bias)) return 0;
   size_t nb = 0;
   int16_t in[6 * 64];
   for (int my = 0; my < s.mb_h; ++my) {
     for (int mx = 0; mx < s.mb_w; ++mx) {
-      orc_get_samples(yuv_mode, rgb, W, H, stride, mx, my, in);
+      orc_get_samples_src(S, yuv_mode, W, H, mx, my, in);
       orc_fdct(in, s.L.mcu_blocks);
       const int16_t* blk = in;
       for (int c = 0; c < s.L.nb_comps; ++c) {
@@ -500,13 +560,13 @@ size_t orc_scan_coeffs(const uint8_t* rgb, int W, int H, int stride, int yuv_mod
 }
 
 /* The hot loop: src/enc.cc:276-307 */
-static void scan_emit(orc_scan* s, const uint8_t* rgb, int stride, int yuv_mode, orc_bw* w,
+static void scan_emit(orc_scan* s, const orc_source* S, int yuv_mode, orc_bw* w,
                       uint32_t dc_codes[2][12], uint32_t ac_codes[2][256]) {
   int pred[3] = {0, 0, 0};                       /* ResetDCs, src/entropy.cc:155-159 */
   int16_t in[6 * 64], zz[64];
   for (int my = 0; my < s->mb_h; ++my) {
     for (int mx = 0; mx < s->mb_w; ++mx) {
-      orc_get_samples(yuv_mode, rgb, s->W, s->H, stride, mx, my, in);
+      orc_get_samples_src(S, yuv_mode, s->W, s->H, mx, my, in);
       orc_fdct(in, s->L.mcu_blocks);
       const int16_t* blk = in;
       for (int c = 0; c < s->L.nb_comps; ++c) {
@@ -530,7 +590,8 @@ size_t orc_scan_bits(const uint8_t* rgb, int W, int H, int stride, int yuv_mode,
   orc_default_codes(dc, ac);
   orc_bw w;
   memset(&w, 0, sizeof(w));
-  scan_emit(&s, rgb, stride, yuv_mode, &w, dc, ac);
+  const orc_source S = rgb_source(rgb, stride);
+  scan_emit(&s, &S, yuv_mode, &w, dc, ac);
   *out = w.buf;
   return w.size;
 }
@@ -614,7 +675,8 @@ size_t orc_encode_matrices(const uint8_t* rgb, int W, int H, int stride,
   orc_bw w;
   memset(&w, 0, sizeof(w));
   write_headers(&w, &s, yuv_mode);                          /* src/enc.cc:415-443 order */
-  scan_emit(&s, rgb, stride, yuv_mode, &w, dc, ac);
+  const orc_source S = rgb_source(rgb, stride);
+  scan_emit(&s, &S, yuv_mode, &w, dc, ac);
   put16(&w, 0xffd9);                                        /* src/headers.cc:262-268 */
   *out = w.buf;
   return w.size;
@@ -631,6 +693,11 @@ size_t orc_encode(const uint8_t* rgb, int W, int H, int stride, float quality,
 
 /* src/histogram.cc:98-108 (plain-C variant: bins >= 128 are dropped), :317-339 */
 void orc_histogram(const uint8_t* rgb, int W, int H, int stride, int yuv_mode, uint32_t* hist) {
+  const orc_source S = rgb_source(rgb, stride);
+  orc_histogram_src(&S, W, H, yuv_mode, hist);
+}
+
+void orc_histogram_src(const orc_source* S, int W, int H, int yuv_mode, uint32_t* hist) {
   orc_layout L;
   memset(hist, 0, 2 * 64 * 128 * sizeof(uint32_t));
   if (!layout_for(yuv_mode, &L)) return;
@@ -638,7 +705,7 @@ void orc_histogram(const uint8_t* rgb, int W, int H, int stride, int yuv_mode, u
   int16_t in[6 * 64];
   for (int my = 0; my < mb_h; ++my) {
     for (int mx = 0; mx < mb_w; ++mx) {
-      orc_get_samples(yuv_mode, rgb, W, H, stride, mx, my, in);
+      orc_get_samples_src(S, yuv_mode, W, H, mx, my, in);
       orc_fdct(in, L.mcu_blocks);
       const int16_t* blk = in;
       for (int c = 0; c < L.nb_comps; ++c) {
@@ -747,13 +814,13 @@ static void block_stats(const int16_t zz[64], int* dc_pred, uint32_t* f /*[272]*
   if (run > 0) ++f[0x00];
 }
 
-static void scan_stats(orc_scan* s, const uint8_t* rgb, int stride, int yuv_mode, uint32_t* freq) {
+static void scan_stats(orc_scan* s, const orc_source* S, int yuv_mode, uint32_t* freq) {
   int pred[3] = {0, 0, 0};
   int16_t in[6 * 64], zz[64];
   memset(freq, 0, 2 * 272 * sizeof(uint32_t));
   for (int my = 0; my < s->mb_h; ++my) {
     for (int mx = 0; mx < s->mb_w; ++mx) {
-      orc_get_samples(yuv_mode, rgb, s->W, s->H, stride, mx, my, in);
+      orc_get_samples_src(S, yuv_mode, s->W, s->H, mx, my, in);
       orc_fdct(in, s->L.mcu_blocks);
       const int16_t* blk = in;
       for (int c = 0; c < s->L.nb_comps; ++c) {
@@ -769,9 +836,15 @@ static void scan_stats(orc_scan* s, const uint8_t* rgb, int stride, int yuv_mode
 
 void orc_symbol_stats(const uint8_t* rgb, int W, int H, int stride, int yuv_mode,
                       const uint8_t quant[2][64], int q_bias, uint32_t* freq) {
+  const orc_source S = rgb_source(rgb, stride);
+  orc_symbol_stats_src(&S, W, H, yuv_mode, quant, q_bias, freq);
+}
+
+void orc_symbol_stats_src(const orc_source* S, int W, int H, int yuv_mode,
+                          const uint8_t quant[2][64], int q_bias, uint32_t* freq) {
   orc_scan s;
   if (!scan_init(&s, W, H, yuv_mode, quant, NULL, q_bias)) return;
-  scan_stats(&s, rgb, stride, yuv_mode, freq);
+  scan_stats(&s, S, yuv_mode, freq);
 }
 
 /* src/entropy.cc:254-430: Huffman's merging with the all-ones code reserved and lengths
@@ -839,16 +912,28 @@ int orc_build_optimal(const uint32_t* freq, int size, uint8_t out_bits[16], uint
 size_t orc_encode_full(const uint8_t* rgb, int W, int H, int stride, const uint8_t quant[2][64],
                        const uint8_t* min_quant, int q_bias, int qdelta_max_luma,
                        int qdelta_max_chroma, int yuv_mode, int method, uint8_t** out) {
-  orc_scan s;
   *out = NULL;
   if (rgb == NULL || abs(stride) < 3 * W) return 0;
+  const orc_source S = rgb_source(rgb, stride);
+  return orc_encode_src(&S, W, H, quant, min_quant, q_bias, qdelta_max_luma, qdelta_max_chroma,
+                        yuv_mode, method, out);
+}
+
+size_t orc_encode_src(const orc_source* S, int W, int H, const uint8_t quant[2][64],
+                      const uint8_t* min_quant, int q_bias, int qdelta_max_luma,
+                      int qdelta_max_chroma, int yuv_mode, int method, uint8_t** out) {
+  orc_scan s;
+  *out = NULL;
+  if (S->format == ORC_SRC_GRAY) yuv_mode = ORC_YUV_400;
+  else if (S->format == ORC_SRC_YUV444) yuv_mode = ORC_YUV_444;
+  else if (S->format >= ORC_SRC_YUV420) yuv_mode = ORC_YUV_420;
   if (method < 0) method = 0;
   if (method > 6) return 0;                       /* trellis: outside the oracle's scope */
   if (!scan_init(&s, W, H, yuv_mode, quant, min_quant, q_bias)) return 0;
   const int adaptive = method >= 3, optimize = (method != 0 && method != 3);
   if (adaptive) {
     uint32_t* hist = (uint32_t*)malloc(2 * 64 * 128 * sizeof(uint32_t));
-    orc_histogram(rgb, W, H, stride, yuv_mode, hist);
+    orc_histogram_src(S, W, H, yuv_mode, hist);
     orc_adapt_quant(hist, s.L.nb_comps, s.q, q_bias, qdelta_max_luma, qdelta_max_chroma);
     free(hist);
   }
@@ -857,7 +942,7 @@ size_t orc_encode_full(const uint8_t* rgb, int W, int H, int stride, const uint8
   uint32_t dc[2][12], ac[2][256];
   if (optimize) {
     uint32_t freq[2][272];
-    scan_stats(&s, rgb, stride, yuv_mode, &freq[0][0]);
+    scan_stats(&s, S, yuv_mode, &freq[0][0]);
     const int nt = s.L.nb_comps == 1 ? 1 : 2;
     for (int t = 0; t < nt; ++t) {
       memset(&h[t], 0, sizeof(h[t])); memset(&h[2 + t], 0, sizeof(h[2 + t]));
@@ -873,7 +958,7 @@ size_t orc_encode_full(const uint8_t* rgb, int W, int H, int stride, const uint8
   orc_bw w;
   memset(&w, 0, sizeof(w));
   write_headers_huff(&w, &s, yuv_mode, h);
-  scan_emit(&s, rgb, stride, yuv_mode, &w, dc, ac);
+  scan_emit(&s, S, yuv_mode, &w, dc, ac);
   put16(&w, 0xffd9);
   *out = w.buf;
   return w.size;

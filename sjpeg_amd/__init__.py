@@ -30,6 +30,30 @@ class ScanTables(C.Structure):
                 ("ac_codes", (C.c_uint32 * 256) * 2)]
 
 
+SRC_RGB, SRC_BGRA, SRC_RGBA, SRC_GRAY, SRC_YUV444, SRC_YUV420, SRC_NV12, SRC_NV21 = range(8)
+_IMPLIED_MODE = {SRC_GRAY: YUV_400, SRC_YUV444: YUV_444, SRC_YUV420: YUV_420, SRC_NV12: YUV_420,
+                 SRC_NV21: YUV_420}
+
+
+class Source(C.Structure):
+    """struct sjpeg_hip_source (include/sjpeg_hip.h)."""
+    _fields_ = [("format", C.c_int32), ("reserved", C.c_int32), ("plane", C.c_void_p * 3),
+                ("row_stride", C.c_int64 * 3), ("frame_stride", C.c_int64 * 3)]
+
+
+def make_source(fmt, planes):
+    """planes: CUDA uint8 tensors [F, rows, row_bytes] (one per plane of the layout).
+    Returns (Source, nframes); the tensors must outlive the calls that use it."""
+    s = Source()
+    s.format = fmt
+    for i, t in enumerate(planes):
+        assert t.is_cuda and t.dim() == 3 and t.stride(2) == 1
+        s.plane[i] = t.data_ptr()
+        s.row_stride[i] = t.stride(1)
+        s.frame_stride[i] = t.stride(0)
+    return s, planes[0].shape[0]
+
+
 class HuffmanSpec(C.Structure):
     """struct sjpeg_hip_huffman_spec (include/sjpeg_hip.h)."""
     _fields_ = [("bits", C.c_uint8 * 16), ("syms", C.c_uint8 * 256), ("nsyms", C.c_int32)]
@@ -101,6 +125,16 @@ def lib() -> C.CDLL:
     L.sjpeg_hip_scan_symbol_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int,
                                               C.c_int, C.c_int, C.c_int, C.POINTER(ScanTables),
                                               C.c_void_p, C.c_void_p]
+    srcp = C.POINTER(Source)
+    L.sjpeg_hip_encode_scan_src.argtypes = [C.c_void_p, srcp, C.c_int, C.c_int, C.c_int, C.c_int,
+                                            C.POINTER(ScanTables), C.c_void_p, C.c_size_t, C.c_int,
+                                            C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    L.sjpeg_hip_scan_coeffs_src.argtypes = [C.c_void_p, srcp, C.c_int, C.c_int, C.c_int, C.c_int,
+                                            C.POINTER(ScanTables), C.c_void_p, C.c_void_p]
+    L.sjpeg_hip_scan_histogram_src.argtypes = [C.c_void_p, srcp, C.c_int, C.c_int, C.c_int, C.c_int,
+                                               C.c_void_p, C.c_void_p]
+    L.sjpeg_hip_scan_symbol_stats_src.argtypes = [C.c_void_p, srcp, C.c_int, C.c_int, C.c_int, C.c_int,
+                                                  C.POINTER(ScanTables), C.c_void_p, C.c_void_p]
     L.sjpeg_hip_adapt_quant.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                         C.c_int, C.c_int, C.POINTER(ScanTables)]
     L.sjpeg_hip_optimize_huffman.argtypes = [C.c_void_p, C.c_int, C.POINTER(HuffmanSpec),
@@ -127,6 +161,8 @@ EXPORTED_C_SYMBOLS = [
     "sjpeg_hip_encode_scan", "sjpeg_hip_scan_coeffs", "sjpeg_hip_quality_matrices",
     "sjpeg_hip_finalize_quant", "sjpeg_hip_default_huffman", "sjpeg_hip_make_header",
     "sjpeg_hip_scan_histogram", "sjpeg_hip_scan_symbol_stats", "sjpeg_hip_adapt_quant",
+    "sjpeg_hip_encode_scan_src", "sjpeg_hip_scan_coeffs_src", "sjpeg_hip_scan_histogram_src",
+    "sjpeg_hip_scan_symbol_stats_src",
     "sjpeg_hip_optimize_huffman", "sjpeg_hip_make_header_ex",
     "sjpeg_hip_engine_set_timing", "sjpeg_hip_engine_last_scan_ms",
     "sjpeg_hip_engine_last_total_ms",
@@ -286,6 +322,41 @@ class Engine:
             raise SjpegError(f"sjpeg_hip_encode_scan: {lib().sjpeg_hip_last_error().decode()}")
         return out, sizes
 
+    # ---- any pixel source (sjpeg_hip_source) -------------------------------------------------
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise SjpegError(f"{what}: {lib().sjpeg_hip_last_error().decode()}")
+
+    def encode_source(self, src: Source, nframes, w, h, tables: ScanTables, header: bytes, yuv_mode,
+                      out_stride=None, append_eoi=True, device="cuda"):
+        import torch
+        if out_stride is None:
+            out_stride = frame_bound(w, h, yuv_mode, len(header))
+        out = torch.empty((nframes, out_stride), dtype=torch.uint8, device=device)
+        sizes = torch.zeros(nframes, dtype=torch.int64, device=device)
+        self._chk(lib().sjpeg_hip_encode_scan_src(self._h, C.byref(src), w, h, yuv_mode, nframes,
+                                                  C.byref(tables), header, len(header),
+                                                  int(append_eoi), out.data_ptr(), out_stride,
+                                                  sizes.data_ptr(), self._stream()),
+                  "sjpeg_hip_encode_scan_src")
+        return out, sizes
+
+    def scan_histogram_source(self, src: Source, nframes, w, h, yuv_mode, device="cuda"):
+        import torch
+        out = torch.zeros((nframes, 2, 64, 128), dtype=torch.int32, device=device)
+        self._chk(lib().sjpeg_hip_scan_histogram_src(self._h, C.byref(src), w, h, yuv_mode, nframes,
+                                                     out.data_ptr(), self._stream()),
+                  "sjpeg_hip_scan_histogram_src")
+        return out
+
+    def scan_symbol_stats_source(self, src: Source, nframes, w, h, tables, yuv_mode, device="cuda"):
+        import torch
+        out = torch.zeros((nframes, 2, 272), dtype=torch.int32, device=device)
+        self._chk(lib().sjpeg_hip_scan_symbol_stats_src(self._h, C.byref(src), w, h, yuv_mode, nframes,
+                                                        C.byref(tables), out.data_ptr(), self._stream()),
+                  "sjpeg_hip_scan_symbol_stats_src")
+        return out
+
     def scan_histogram(self, frames, yuv_mode: int):
         """[F, 2, 64, 128] uint32 (as int32 tensor) coefficient histograms (adaptive quantization)."""
         import torch
@@ -353,6 +424,31 @@ def encode_device_method(frames, quality=75.0, yuv_mode=YUV_420, method=4, engin
         torch.cuda.synchronize()
         out_frames.append(bytes(out[0, :int(sizes[0])].cpu().numpy()))
     return out_frames
+
+
+def encode_source_method(fmt, planes, w, h, quality=75.0, yuv_mode=YUV_420, method=0, engine=None,
+                         quant=None, min_quant=None, q_bias=0x78, dmax_luma=12, dmax_chroma=1):
+    """One frame in any source layout (planes: CUDA uint8 tensors [1, rows, row_bytes]) with the
+    reference's method 0..6 semantics, through the C-ABI.  Returns the JPEG bytes."""
+    import torch
+    eng = engine or Engine(planes[0].device.index or 0)
+    yuv_mode = _IMPLIED_MODE.get(fmt, yuv_mode)
+    method = max(0, min(int(method), 8))
+    adaptive, optimize = method >= 3, method not in (0, 3)
+    src, n = make_source(fmt, planes)
+    assert n == 1
+    tables, q = make_tables(quality=quality, quant=quant, min_quant=min_quant, q_bias=q_bias)
+    if adaptive:
+        hist = eng.scan_histogram_source(src, 1, w, h, yuv_mode).cpu().numpy().view(np.uint32)[0]
+        tables, q = adapt_quant(hist, yuv_mode, q, min_quant, q_bias, dmax_luma, dmax_chroma)
+    specs = None
+    if optimize:
+        freq = eng.scan_symbol_stats_source(src, 1, w, h, tables, yuv_mode).cpu().numpy().view(np.uint32)[0]
+        specs = optimize_huffman(freq, yuv_mode, tables)
+    header = make_header_ex(w, h, yuv_mode, q, specs)
+    out, sizes = eng.encode_source(src, 1, w, h, tables, header, yuv_mode)
+    torch.cuda.synchronize()
+    return bytes(out[0, :int(sizes[0])].cpu().numpy())
 
 
 def encode_device(frames, quality=75.0, yuv_mode=YUV_420, engine=None, quant=None):

@@ -144,9 +144,17 @@ namespace sjpeg {
 
 // The name and the friendship with EncoderParam come from the reference header; here it is
 // a one-shot plan: resolved parameters -> tables + header -> device call -> sink.
+struct HostSource {            // pixels in host memory, one of SJPEG_HIP_SRC_*
+  int format;
+  const uint8_t* plane[3];
+  int stride[3];
+};
+
 struct Encoder {
   Encoder(const uint8_t* rgb, int W, int H, int stride, ByteSink* sink, MemoryManager* mem)
-      : rgb_(rgb), W_(W), H_(H), stride_(stride), sink_(sink),
+      : Encoder(HostSource{SJPEG_HIP_SRC_RGB, {rgb, nullptr, nullptr}, {stride, 0, 0}}, W, H, sink, mem) {}
+  Encoder(const HostSource& src, int W, int H, ByteSink* sink, MemoryManager* mem)
+      : src_(src), W_(W), H_(H), sink_(sink),
         mem_(mem ? mem : &g_default_memory), q_bias_(kDefaultBias), method_(4),
         yuv_mode_(SJPEG_YUV_420), passes_(1), qdelta_luma_(kDefaultDeltaMaxLuma),
         qdelta_chroma_(kDefaultDeltaMaxChroma) {
@@ -188,8 +196,8 @@ struct Encoder {
   bool Run();
 
  private:
-  const uint8_t* rgb_;
-  int W_, H_, stride_;
+  HostSource src_;
+  int W_, H_;
   ByteSink* sink_;
   MemoryManager* mem_;
   uint8_t quant_[2][64], min_quant_[2][64];
@@ -203,6 +211,9 @@ struct Encoder {
 bool Encoder::Run() {
   sink_->Reset();                                                   // src/enc.cc:90
   if (W_ > 65535 || H_ > 65535) return Fail("dimension > 65535");   // src/enc.cc:406
+  if (src_.format == SJPEG_HIP_SRC_GRAY) yuv_mode_ = SJPEG_YUV_400;                 // src/encoders.cc:256-276
+  else if (src_.format == SJPEG_HIP_SRC_YUV444) yuv_mode_ = SJPEG_YUV_444;          // :384-419
+  else if (src_.format >= SJPEG_HIP_SRC_YUV420) yuv_mode_ = SJPEG_YUV_420;          // :281-344, :442-490
   int mode;
   switch (yuv_mode_) {
     case SJPEG_YUV_420: mode = SJPEG_HIP_YUV420; break;
@@ -231,19 +242,54 @@ bool Encoder::Run() {
   if (!ctx.Init()) return false;
   if (hipSetDevice(ctx.device) != hipSuccess) return Fail("hipSetDevice failed");
 
-  // pixels -> device.  Rows keep their pitch; a bottom-up picture (negative stride) is
-  // copied as the memory block it is and addressed with a negative device stride.
-  const size_t pitch = static_cast<size_t>(stride_ < 0 ? -static_cast<long long>(stride_) : stride_);
-  const size_t row_bytes = 3 * static_cast<size_t>(W_);
-  const size_t dev_pitch = (row_bytes + 15) & ~static_cast<size_t>(15);
-  if (!ctx.Ensure(&ctx.d_in, &ctx.in_cap, dev_pitch * H_ + 64)) return false;
-  const uint8_t* lowest = stride_ < 0 ? rgb_ + static_cast<long long>(H_ - 1) * stride_ : rgb_;
-  if (hipMemcpy2D(ctx.d_in, dev_pitch, lowest, pitch, row_bytes, H_, hipMemcpyHostToDevice) != hipSuccess) {
-    return Fail("hipMemcpy2D(host -> device) failed");
+  // pixels -> device, plane by plane.  Rows keep a 16-byte aligned pitch; a bottom-up plane
+  // (negative stride) is copied as the memory block it is and addressed with a negative stride.
+  sjpeg_hip_source dsrc;
+  memset(&dsrc, 0, sizeof(dsrc));
+  dsrc.format = src_.format;
+  {
+    const size_t cw = (static_cast<size_t>(W_) + 1) / 2, ch = (static_cast<size_t>(H_) + 1) / 2;
+    size_t row_bytes[3] = {0, 0, 0}, rows[3] = {0, 0, 0};
+    int nplanes = 1;
+    switch (src_.format) {
+      case SJPEG_HIP_SRC_RGB: row_bytes[0] = 3 * static_cast<size_t>(W_); rows[0] = H_; break;
+      case SJPEG_HIP_SRC_BGRA:
+      case SJPEG_HIP_SRC_RGBA: row_bytes[0] = 4 * static_cast<size_t>(W_); rows[0] = H_; break;
+      case SJPEG_HIP_SRC_GRAY: row_bytes[0] = W_; rows[0] = H_; break;
+      case SJPEG_HIP_SRC_YUV444:
+        nplanes = 3;
+        for (int i = 0; i < 3; ++i) { row_bytes[i] = W_; rows[i] = H_; }
+        break;
+      case SJPEG_HIP_SRC_YUV420:
+        nplanes = 3;
+        row_bytes[0] = W_; rows[0] = H_;
+        row_bytes[1] = row_bytes[2] = cw; rows[1] = rows[2] = ch;
+        break;
+      default:   // NV12 / NV21
+        nplanes = 2;
+        row_bytes[0] = W_; rows[0] = H_;
+        row_bytes[1] = 2 * cw; rows[1] = ch;
+        break;
+    }
+    size_t offset[3] = {0, 0, 0}, pitch[3] = {0, 0, 0}, total = 0;
+    for (int i = 0; i < nplanes; ++i) {
+      pitch[i] = (row_bytes[i] + 15) & ~static_cast<size_t>(15);
+      offset[i] = total;
+      total += pitch[i] * rows[i] + 64;
+    }
+    if (!ctx.Ensure(&ctx.d_in, &ctx.in_cap, total)) return false;
+    for (int i = 0; i < nplanes; ++i) {
+      const long long st = src_.stride[i];
+      const size_t host_pitch = static_cast<size_t>(st < 0 ? -st : st);
+      const uint8_t* lowest = st < 0 ? src_.plane[i] + static_cast<long long>(rows[i] - 1) * st : src_.plane[i];
+      uint8_t* d = static_cast<uint8_t*>(ctx.d_in) + offset[i];
+      if (hipMemcpy2D(d, pitch[i], lowest, host_pitch, row_bytes[i], rows[i], hipMemcpyHostToDevice) != hipSuccess) {
+        return Fail("hipMemcpy2D(host -> device) failed");
+      }
+      dsrc.plane[i] = st < 0 ? d + pitch[i] * (rows[i] - 1) : d;
+      dsrc.row_stride[i] = st < 0 ? -static_cast<long long>(pitch[i]) : static_cast<long long>(pitch[i]);
+    }
   }
-  const uint8_t* d_first = static_cast<const uint8_t*>(ctx.d_in);
-  long long d_stride = static_cast<long long>(dev_pitch);
-  if (stride_ < 0) { d_first += dev_pitch * (H_ - 1); d_stride = -d_stride; }
   const int nb_comps = (mode == SJPEG_HIP_YUV400) ? 1 : 3;
 
   // quantizers (src/enc.cc:394-397)
@@ -255,7 +301,7 @@ bool Encoder::Run() {
 
   if (adaptive) {
     // CollectHistograms on the GPU, AnalyseHisto on the host (src/enc.cc:425-429)
-    if (sjpeg_hip_scan_histogram(ctx.engine, d_first, d_stride, 0, W_, H_, mode, 1,
+    if (sjpeg_hip_scan_histogram_src(ctx.engine, &dsrc, W_, H_, mode, 1,
                                  static_cast<uint32_t*>(ctx.d_stats), nullptr) != 0) {
       return FailHip("sjpeg_hip_scan_histogram");
     }
@@ -278,7 +324,7 @@ bool Encoder::Run() {
   if (optimize) {
     // statistics half of SinglePassScanOptimized on the GPU (src/enc.cc:323-372),
     // CompileEntropyStats on the host (src/entropy.cc:432-444)
-    if (sjpeg_hip_scan_symbol_stats(ctx.engine, d_first, d_stride, 0, W_, H_, mode, 1, &tables,
+    if (sjpeg_hip_scan_symbol_stats_src(ctx.engine, &dsrc, W_, H_, mode, 1, &tables,
                                     static_cast<uint32_t*>(ctx.d_stats), nullptr) != 0) {
       return FailHip("sjpeg_hip_scan_symbol_stats");
     }
@@ -312,7 +358,7 @@ bool Encoder::Run() {
 
   const size_t bound = sjpeg_hip_frame_bound(W_, H_, mode, header.size());
   if (bound == 0 || !ctx.Ensure(&ctx.d_out, &ctx.out_cap, bound)) return false;
-  if (sjpeg_hip_encode_scan(ctx.engine, d_first, d_stride, 0, W_, H_, mode, 1, &tables,
+  if (sjpeg_hip_encode_scan_src(ctx.engine, &dsrc, W_, H_, mode, 1, &tables,
                             staged_header, header.size(), /*append_eoi=*/1, ctx.d_out, bound,
                             ctx.d_size, nullptr) != 0) {
     return FailHip("sjpeg_hip_encode_scan");
@@ -451,6 +497,86 @@ bool Encode(const uint8_t* rgb, int width, int height, int stride,
   ContainerSink<std::string> sink(output);
   return Encode(rgb, width, height, stride, param, &sink);
 }
+
+// ---- other input layouts (reference: src/api.cc:201-304, src/encoders.cc:346-490) ------------
+
+static bool EncodeSource(const HostSource& src, int width, int height, const EncoderParam& param,
+                         ByteSink* sink) {
+  Encoder enc(src, width, height, sink, param.memory);
+  enc.InitFromParam(param);
+  return enc.Run();
+}
+
+bool EncodeBGRA(const uint8_t* bgra, int width, int height, int stride,
+                const EncoderParam& param, ByteSink* sink) {
+  if (bgra == nullptr || sink == nullptr) return Fail("null argument");
+  if (width <= 0 || height <= 0 || std::abs(stride) < 4 * width) return Fail("bad dimensions or stride");
+  return EncodeSource(HostSource{SJPEG_HIP_SRC_BGRA, {bgra, nullptr, nullptr}, {stride, 0, 0}}, width, height, param, sink);
+}
+
+bool EncodeRGBA(const uint8_t* rgba, int width, int height, int stride,
+                const EncoderParam& param, ByteSink* sink) {
+  if (rgba == nullptr || sink == nullptr) return Fail("null argument");
+  if (width <= 0 || height <= 0 || std::abs(stride) < 4 * width) return Fail("bad dimensions or stride");
+  return EncodeSource(HostSource{SJPEG_HIP_SRC_RGBA, {rgba, nullptr, nullptr}, {stride, 0, 0}}, width, height, param, sink);
+}
+
+bool EncodeGray(const uint8_t* gray, int width, int height, int stride,
+                const EncoderParam& param, ByteSink* sink) {
+  if (gray == nullptr || sink == nullptr) return Fail("null argument");
+  if (width <= 0 || height <= 0 || std::abs(stride) < width) return Fail("bad dimensions or stride");
+  return EncodeSource(HostSource{SJPEG_HIP_SRC_GRAY, {gray, nullptr, nullptr}, {stride, 0, 0}}, width, height, param, sink);
+}
+
+static bool EncodeNV(const uint8_t* y, int y_stride, const uint8_t* uv, int uv_stride, int width,
+                     int height, int format, const EncoderParam& param, ByteSink* sink) {
+  if (y == nullptr || uv == nullptr || sink == nullptr) return Fail("null argument");
+  if (width <= 0 || height <= 0) return Fail("bad dimensions");
+  if (std::abs(y_stride) < width || std::abs(uv_stride) < 2 * ((width + 1) / 2)) return Fail("bad stride");
+  return EncodeSource(HostSource{format, {y, uv, nullptr}, {y_stride, uv_stride, 0}}, width, height, param, sink);
+}
+
+bool EncodeNV12(const uint8_t* y, int y_stride, const uint8_t* uv, int uv_stride,
+                int width, int height, const EncoderParam& param, ByteSink* output) {
+  return EncodeNV(y, y_stride, uv, uv_stride, width, height, SJPEG_HIP_SRC_NV12, param, output);
+}
+
+bool EncodeNV21(const uint8_t* y, int y_stride, const uint8_t* vu, int vu_stride,
+                int width, int height, const EncoderParam& param, ByteSink* output) {
+  return EncodeNV(y, y_stride, vu, vu_stride, width, height, SJPEG_HIP_SRC_NV21, param, output);
+}
+
+bool EncodeYUV444(const uint8_t* Y, int Y_stride, const uint8_t* U, int U_stride,
+                  const uint8_t* V, int V_stride, int width, int height,
+                  const EncoderParam& param, ByteSink* output) {
+  if (Y == nullptr || U == nullptr || V == nullptr || output == nullptr) return Fail("null argument");
+  if (width <= 0 || height <= 0) return Fail("bad dimensions");
+  if (std::abs(Y_stride) < width || std::abs(U_stride) < width || std::abs(V_stride) < width) return Fail("bad stride");
+  return EncodeSource(HostSource{SJPEG_HIP_SRC_YUV444, {Y, U, V}, {Y_stride, U_stride, V_stride}}, width, height, param, output);
+}
+
+bool EncodeYUV420(const uint8_t* Y, int Y_stride, const uint8_t* U, int U_stride,
+                  const uint8_t* V, int V_stride, int width, int height,
+                  const EncoderParam& param, ByteSink* output) {
+  if (Y == nullptr || U == nullptr || V == nullptr || output == nullptr) return Fail("null argument");
+  if (width <= 0 || height <= 0) return Fail("bad dimensions");
+  const int cw = (width + 1) / 2;
+  if (std::abs(Y_stride) < width || std::abs(U_stride) < cw || std::abs(V_stride) < cw) return Fail("bad stride");
+  return EncodeSource(HostSource{SJPEG_HIP_SRC_YUV420, {Y, U, V}, {Y_stride, U_stride, V_stride}}, width, height, param, output);
+}
+
+#define SJPEG_STRING_VARIANT(NAME)                                                                  \
+  bool NAME(const uint8_t* px, int width, int height, int stride, const EncoderParam& param,        \
+            std::string* output) {                                                                   \
+    if (output == nullptr) return false;                                                             \
+    output->clear();                                                                                 \
+    ContainerSink<std::string> sink(output);                                                         \
+    return NAME(px, width, height, stride, param, &sink);                                            \
+  }
+SJPEG_STRING_VARIANT(EncodeBGRA)
+SJPEG_STRING_VARIANT(EncodeRGBA)
+SJPEG_STRING_VARIANT(EncodeGray)
+#undef SJPEG_STRING_VARIANT
 
 std::shared_ptr<ByteSink> MakeByteSink(std::string* output) {
   return std::shared_ptr<ByteSink>(new (std::nothrow) ContainerSink<std::string>(output));

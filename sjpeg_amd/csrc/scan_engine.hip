@@ -72,9 +72,14 @@ struct DevTables {
   uint32_t ac[2][256];
 };
 
+// source classes the colour phase is specialised for
+enum { kSrcRgb24 = 0, kSrcRgbx32 = 1, kSrcPlanes = 2 };
+
 struct ScanArgs {
-  const uint8_t* rgb;
-  long long row_stride, frame_stride;
+  const uint8_t* plane[3];      // packed colour / gray: [0]; planar YUV: Y, U, V; NV12/NV21: Y, UV
+  long long row_stride[3], frame_stride[3];
+  int rsh, bsh;                 // kSrcRgbx32: bit position of R and B inside a pixel dword (0 / 16)
+  int cstep, uoff, voff;        // kSrcPlanes: bytes per chroma sample (2 = interleaved) and U/V offsets
   int W, H, mb_w, n_mcus, nseg, has_clip;
   const DevTables* tables;
   uint32_t* seg_words;     // [nframes*nseg][slot_words]
@@ -357,6 +362,60 @@ __device__ __forceinline__ void load_row8(const uint8_t* frame, long long row_st
   }
 }
 
+// R, G, B of 8 consecutive pixels of row y (coordinates clamp to the picture)
+template <int SRC>
+__device__ __forceinline__ void fetch_rgb8(const ScanArgs& a, const uint8_t* frame_px, int x0, int y,
+                                           bool inside, int* r, int* g, int* b) {
+  if (SRC == kSrcRgb24) {
+    uint32_t w[6];
+    load_row8(frame_px, a.row_stride[0], a.W, a.H, x0, y, inside, w);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { r[i] = byte_of(w, 3 * i); g[i] = byte_of(w, 3 * i + 1); b[i] = byte_of(w, 3 * i + 2); }
+  } else {
+    // 4 bytes per pixel (BGRA / RGBA, alpha ignored: src/colors_rgb.cc:882-1025)
+    uint32_t w[8];
+    if (inside) {
+      __builtin_memcpy(w, frame_px + y * a.row_stride[0] + 4ll * x0, 32);
+    } else {
+      const int yy = y < a.H ? y : a.H - 1;
+      const uint8_t* row = frame_px + yy * a.row_stride[0];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int xx = (x0 + i) < a.W ? (x0 + i) : a.W - 1;
+        __builtin_memcpy(&w[i], row + 4ll * xx, 4);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      r[i] = static_cast<int>((w[i] >> a.rsh) & 0xffu);
+      g[i] = static_cast<int>((w[i] >> 8) & 0xffu);
+      b[i] = static_cast<int>((w[i] >> a.bsh) & 0xffu);
+    }
+  }
+}
+
+// 8 level-shifted samples of an 8-bit plane (sample pitch `step` bytes), clamped coordinates:
+// what Convert8To16b[Clipped] / Replicate8b produce (src/colors_rgb.cc:1212-1260)
+__device__ __forceinline__ void fetch_plane(const uint8_t* plane, long long stride, int step, int pw,
+                                            int ph, int x0, int y, int n, int* out) {
+  const int yy = y < ph ? y : ph - 1;
+  const uint8_t* row = plane + yy * stride;
+  if (step == 1 && n == 8 && x0 + 8 <= pw) {
+    uint32_t w[2];
+    __builtin_memcpy(w, row + x0, 8);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) out[i] = byte_of(w, i) - 128;
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      if (i < n) {
+        const int xx = (x0 + i) < pw ? (x0 + i) : pw - 1;
+        out[i] = static_cast<int>(row[static_cast<long long>(xx) * step]) - 128;
+      }
+    }
+  }
+}
+
 // workgroup exclusive scan of one uint32 per thread; returns exclusive prefix, *total = sum
 template <int NT>
 __device__ __forceinline__ uint32_t wg_exclusive_scan(uint32_t x, uint32_t* scratch /*>=8 u32*/,
@@ -389,7 +448,7 @@ enum { kKindEncode = 0, kKindTap = 1, kKindHisto = 2, kKindStats = 3 };
 constexpr int kHistoWords = 2 * 64 * 32;          // per-workgroup partial: u8 counters [2][64][128]
 constexpr int kStatsWords = 2 * 272;              // per-workgroup partial: u32 [2][256 AC + 16 DC]
 
-template <int MODE, int KIND>
+template <int MODE, int KIND, int SRC>
 __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) {
   using G = Geo<MODE>;
   constexpr int BPM = G::kBpm;
@@ -412,7 +471,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
   const int m_first = seg * G::kSegMcus;                       // first coded MCU of the segment
   const int n_coded = min(G::kSegMcus, a.n_mcus - m_first);
   const int halo = m_first > 0 ? 1 : 0;                        // previous MCU: DC predictors only
-  const uint8_t* const frame_px = a.rgb + frame * a.frame_stride;
+  const uint8_t* const frame_px = a.plane[0] + frame * a.frame_stride[0];
 
   // tables -> LDS
   {
@@ -444,11 +503,49 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
       const int x0 = mb_x * PX + xs * 8;
       const int y0 = mb_y * PX + yp * kRowsPerStrip;
       const bool inside = (x0 + 8 <= a.W) && (y0 + kRowsPerStrip <= a.H);
-      uint32_t w0[6];
-      load_row8(frame_px, a.row_stride, a.W, a.H, x0, y0, inside, w0);
+      if (SRC == kSrcPlanes) {
+        // 8-bit planes are used as they are, minus 128 (src/encoders.cc:256-490)
+        int ya[8];
+        fetch_plane(frame_px, a.row_stride[0], 1, a.W, a.H, x0, y0, 8, ya);
+        if (MODE == SJPEG_HIP_YUV420) {
+          int yb[8], U[8], V[8];
+          fetch_plane(frame_px, a.row_stride[0], 1, a.W, a.H, x0, y0 + 1, 8, yb);
+          const int cw = (a.W + 1) >> 1, ch = (a.H + 1) >> 1;
+          const uint8_t* pu = a.plane[1] + frame * a.frame_stride[1] + a.uoff;
+          const uint8_t* pv = a.plane[2] + frame * a.frame_stride[2] + a.voff;
+          fetch_plane(pu, a.row_stride[1], a.cstep, cw, ch, mb_x * 8 + xs * 4, mb_y * 8 + yp, 4, U);
+          fetch_plane(pv, a.row_stride[2], a.cstep, cw, ch, mb_x * 8 + xs * 4, mb_y * 8 + yp, 4, V);
+          const int k = (yp >> 2) * 2 + xs;
+          const int row = (yp & 3) * 2;
+          unsigned char* ys = smem + (ml * BPM + k) * kSlotBytes + row * 16;
+          *reinterpret_cast<uint4*>(ys) =
+              make_uint4(pack16(ya[0], ya[1]), pack16(ya[2], ya[3]), pack16(ya[4], ya[5]), pack16(ya[6], ya[7]));
+          *reinterpret_cast<uint4*>(ys + 16) =
+              make_uint4(pack16(yb[0], yb[1]), pack16(yb[2], yb[3]), pack16(yb[4], yb[5]), pack16(yb[6], yb[7]));
+          unsigned char* us = smem + (ml * BPM + 4) * kSlotBytes + yp * 16 + xs * 8;
+          *reinterpret_cast<uint2*>(us) = make_uint2(pack16(U[0], U[1]), pack16(U[2], U[3]));
+          *reinterpret_cast<uint2*>(us + kSlotBytes) = make_uint2(pack16(V[0], V[1]), pack16(V[2], V[3]));
+        } else {
+          unsigned char* ys = smem + (ml * BPM) * kSlotBytes + yp * 16;
+          *reinterpret_cast<uint4*>(ys) =
+              make_uint4(pack16(ya[0], ya[1]), pack16(ya[2], ya[3]), pack16(ya[4], ya[5]), pack16(ya[6], ya[7]));
+          if (MODE == SJPEG_HIP_YUV444) {
+            int uv[8], vv[8];
+            fetch_plane(a.plane[1] + frame * a.frame_stride[1], a.row_stride[1], 1, a.W, a.H, x0, y0, 8, uv);
+            fetch_plane(a.plane[2] + frame * a.frame_stride[2], a.row_stride[2], 1, a.W, a.H, x0, y0, 8, vv);
+            *reinterpret_cast<uint4*>(ys + kSlotBytes) =
+                make_uint4(pack16(uv[0], uv[1]), pack16(uv[2], uv[3]), pack16(uv[4], uv[5]), pack16(uv[6], uv[7]));
+            *reinterpret_cast<uint4*>(ys + 2 * kSlotBytes) =
+                make_uint4(pack16(vv[0], vv[1]), pack16(vv[2], vv[3]), pack16(vv[4], vv[5]), pack16(vv[6], vv[7]));
+          }
+        }
+        continue;
+      }
+      int r0[8], g0[8], b0[8];
+      fetch_rgb8<SRC>(a, frame_px, x0, y0, inside, r0, g0, b0);
       if (MODE == SJPEG_HIP_YUV420) {
-        uint32_t w1[6];
-        load_row8(frame_px, a.row_stride, a.W, a.H, x0, y0 + 1, inside, w1);
+        int r1[8], g1[8], b1[8];
+        fetch_rgb8<SRC>(a, frame_px, x0, y0 + 1, inside, r1, g1, b1);
         int ya[8], yb[8];
         int U[4], V[4];
 #pragma unroll
@@ -457,11 +554,9 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
 #pragma unroll
           for (int e = 0; e < 2; ++e) {
             const int i = 2 * c + e;
-            const int r0 = byte_of(w0, 3 * i), g0 = byte_of(w0, 3 * i + 1), b0 = byte_of(w0, 3 * i + 2);
-            const int r1 = byte_of(w1, 3 * i), g1 = byte_of(w1, 3 * i + 1), b1 = byte_of(w1, 3 * i + 2);
-            ya[i] = luma16(r0, g0, b0);
-            yb[i] = luma16(r1, g1, b1);
-            R += r0 + r1; Gs += g0 + g1; B += b0 + b1;
+            ya[i] = luma16(r0[i], g0[i], b0[i]);
+            yb[i] = luma16(r1[i], g1[i], b1[i]);
+            R += r0[i] + r1[i]; Gs += g0[i] + g1[i]; B += b0[i] + b1[i];
           }
           U[c] = cb16(R, Gs, B, 32768 << 2, 18);
           V[c] = cr16(R, Gs, B, 32768 << 2, 18);
@@ -480,11 +575,10 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
         int yv[8], uv[8], vv[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-          const int r = byte_of(w0, 3 * i), g = byte_of(w0, 3 * i + 1), b = byte_of(w0, 3 * i + 2);
-          yv[i] = luma16(r, g, b);
+          yv[i] = luma16(r0[i], g0[i], b0[i]);
           if (MODE == SJPEG_HIP_YUV444) {
-            uv[i] = cb16(r, g, b, 32768, 16);
-            vv[i] = cr16(r, g, b, 32768, 16);
+            uv[i] = cb16(r0[i], g0[i], b0[i], 32768, 16);
+            vv[i] = cr16(r0[i], g0[i], b0[i], 32768, 16);
           }
         }
         unsigned char* ys = smem + (ml * BPM) * kSlotBytes + yp * 16;
@@ -1226,34 +1320,89 @@ void digest_tables(const sjpeg_hip_scan_tables* t, DevTables* d) {
   memcpy(d->ac, t->ac_codes, sizeof(d->ac));
 }
 
-template <int TAP>
-int launch_scan(int mode, dim3 grid, hipStream_t st, const ScanArgs& a) {
+template <int KIND, int SRC>
+int launch_scan_src(int mode, dim3 grid, hipStream_t st, const ScanArgs& a) {
   static const int kLdsPad = getenv("SJPEG_HIP_LDS_PAD") ? atoi(getenv("SJPEG_HIP_LDS_PAD")) : 0;  // occupancy experiments
-  const int kLdsBytes = (TAP == kKindStats ? ::kLdsBytesStats : ::kLdsBytes) + kLdsPad;
+  const int lds = (KIND == kKindStats ? kLdsBytesStats : kLdsBytes) + kLdsPad;
   switch (mode) {
     case SJPEG_HIP_YUV420:
-      hipLaunchKernelGGL((scan_segments<SJPEG_HIP_YUV420, TAP>), grid, dim3(kScanThreads), kLdsBytes, st, a);
+      hipLaunchKernelGGL((scan_segments<SJPEG_HIP_YUV420, KIND, SRC>), grid, dim3(kScanThreads), lds, st, a);
       break;
     case SJPEG_HIP_YUV444:
-      hipLaunchKernelGGL((scan_segments<SJPEG_HIP_YUV444, TAP>), grid, dim3(kScanThreads), kLdsBytes, st, a);
+      hipLaunchKernelGGL((scan_segments<SJPEG_HIP_YUV444, KIND, SRC>), grid, dim3(kScanThreads), lds, st, a);
       break;
     default:
-      hipLaunchKernelGGL((scan_segments<SJPEG_HIP_YUV400, TAP>), grid, dim3(kScanThreads), kLdsBytes, st, a);
+      hipLaunchKernelGGL((scan_segments<SJPEG_HIP_YUV400, KIND, SRC>), grid, dim3(kScanThreads), lds, st, a);
       break;
   }
   HIP_TRY(hipGetLastError());
   return 0;
 }
 
-int prepare_scan(sjpeg_hip_engine* e, const void* d_rgb, int64_t row_stride, int64_t frame_stride,
+template <int KIND>
+int launch_scan(int mode, int src_class, dim3 grid, hipStream_t st, const ScanArgs& a) {
+  switch (src_class) {
+    case kSrcRgb24: return launch_scan_src<KIND, kSrcRgb24>(mode, grid, st, a);
+    case kSrcRgbx32: return launch_scan_src<KIND, kSrcRgbx32>(mode, grid, st, a);
+    default: return launch_scan_src<KIND, kSrcPlanes>(mode, grid, st, a);
+  }
+}
+
+sjpeg_hip_source rgb_source(const void* d_rgb, int64_t row_stride, int64_t frame_stride) {
+  sjpeg_hip_source s;
+  memset(&s, 0, sizeof(s));
+  s.format = SJPEG_HIP_SRC_RGB;
+  s.plane[0] = d_rgb; s.row_stride[0] = row_stride; s.frame_stride[0] = frame_stride;
+  return s;
+}
+
+int prepare_scan(sjpeg_hip_engine* e, const sjpeg_hip_source* src,
                  int W, int H, int mode, int nframes, const sjpeg_hip_scan_tables* tables,
-                 hipStream_t st, FrameGeo* g, ScanArgs* a) {
-  if (e == nullptr || d_rgb == nullptr || tables == nullptr || nframes <= 0) {
+                 hipStream_t st, FrameGeo* g, ScanArgs* a, int* src_class) {
+  if (e == nullptr || src == nullptr || src->plane[0] == nullptr || tables == nullptr || nframes <= 0) {
     return fail(SJPEG_HIP_EINVAL, "null argument or nframes <= 0");
   }
   if (!frame_geo(W, H, mode, g)) return fail(SJPEG_HIP_EINVAL, "bad dimensions or yuv_mode");
-  const int64_t abs_stride = row_stride < 0 ? -row_stride : row_stride;
-  if (abs_stride < 3ll * W) return fail(SJPEG_HIP_EINVAL, "|row_stride| < 3*width");
+  // per-plane minimum row size and the colour mode each layout implies
+  // (reference argument checks: src/api.cc:35-36,205-206,260; src/encoders.cc:352-355,427-432)
+  const int64_t cw = (W + 1) / 2;
+  int64_t need[3] = {0, 0, 0};
+  int nplanes = 1, implied = 0;
+  memset(a, 0, sizeof(*a));
+  switch (src->format) {
+    case SJPEG_HIP_SRC_RGB: need[0] = 3ll * W; *src_class = kSrcRgb24; break;
+    case SJPEG_HIP_SRC_BGRA: need[0] = 4ll * W; *src_class = kSrcRgbx32; a->rsh = 16; a->bsh = 0; break;
+    case SJPEG_HIP_SRC_RGBA: need[0] = 4ll * W; *src_class = kSrcRgbx32; a->rsh = 0; a->bsh = 16; break;
+    case SJPEG_HIP_SRC_GRAY: need[0] = W; *src_class = kSrcPlanes; implied = SJPEG_HIP_YUV400; break;
+    case SJPEG_HIP_SRC_YUV444:
+      need[0] = need[1] = need[2] = W; nplanes = 3; *src_class = kSrcPlanes; implied = SJPEG_HIP_YUV444;
+      a->cstep = 1;
+      break;
+    case SJPEG_HIP_SRC_YUV420:
+      need[0] = W; need[1] = need[2] = cw; nplanes = 3; *src_class = kSrcPlanes; implied = SJPEG_HIP_YUV420;
+      a->cstep = 1;
+      break;
+    case SJPEG_HIP_SRC_NV12:
+    case SJPEG_HIP_SRC_NV21:
+      need[0] = W; need[1] = 2 * cw; nplanes = 2; *src_class = kSrcPlanes; implied = SJPEG_HIP_YUV420;
+      a->cstep = 2;
+      a->uoff = (src->format == SJPEG_HIP_SRC_NV12) ? 0 : 1;
+      a->voff = 1 - a->uoff;
+      break;
+    default: return fail(SJPEG_HIP_EINVAL, "unknown source format");
+  }
+  if (implied != 0 && mode != implied) return fail(SJPEG_HIP_EINVAL, "yuv_mode does not match the source format");
+  for (int i = 0; i < nplanes; ++i) {
+    if (src->plane[i] == nullptr) return fail(SJPEG_HIP_EINVAL, "null plane pointer");
+    const int64_t st_abs = src->row_stride[i] < 0 ? -src->row_stride[i] : src->row_stride[i];
+    if (st_abs < need[i]) return fail(SJPEG_HIP_EINVAL, "|row_stride| smaller than a row of the plane");
+    a->plane[i] = static_cast<const uint8_t*>(src->plane[i]);
+    a->row_stride[i] = src->row_stride[i];
+    a->frame_stride[i] = src->frame_stride[i];
+  }
+  if (nplanes == 2) {          // interleaved chroma: U and V walk the same plane
+    a->plane[2] = a->plane[1]; a->row_stride[2] = a->row_stride[1]; a->frame_stride[2] = a->frame_stride[1];
+  }
   if (nframes > 65535) return fail(SJPEG_HIP_EINVAL, "nframes > 65535");
   HIP_TRY(hipSetDevice(e->device));
   int rc;
@@ -1264,9 +1413,6 @@ int prepare_scan(sjpeg_hip_engine* e, const void* d_rgb, int64_t row_stride, int
   DevTables host_tables;
   digest_tables(tables, &host_tables);
   HIP_TRY(hipMemcpyAsync(e->tables.p, &host_tables, sizeof(DevTables), hipMemcpyHostToDevice, st));
-  a->rgb = static_cast<const uint8_t*>(d_rgb);
-  a->row_stride = row_stride;
-  a->frame_stride = frame_stride;
   a->W = W; a->H = H; a->mb_w = g->mb_w; a->n_mcus = g->n_mcus; a->nseg = g->nseg;
   a->has_clip = (W % g->px != 0) || (H % g->px != 0);
   a->tables = e->tables.p;
@@ -1369,24 +1515,30 @@ static float elapsed(sjpeg_hip_engine* e, int i0, int i1) {
 float sjpeg_hip_engine_last_scan_ms(sjpeg_hip_engine* e) { return elapsed(e, 0, 1); }
 float sjpeg_hip_engine_last_total_ms(sjpeg_hip_engine* e) { return elapsed(e, 0, 2); }
 
-int sjpeg_hip_scan_coeffs(sjpeg_hip_engine* e, const void* d_rgb, int64_t row_stride,
-                          int64_t frame_stride, int width, int height, int yuv_mode, int nframes,
-                          const sjpeg_hip_scan_tables* tables, int16_t* d_coeffs, void* stream) {
+int sjpeg_hip_scan_coeffs_src(sjpeg_hip_engine* e, const sjpeg_hip_source* src, int width, int height,
+                              int yuv_mode, int nframes, const sjpeg_hip_scan_tables* tables,
+                              int16_t* d_coeffs, void* stream) {
   if (d_coeffs == nullptr) return fail(SJPEG_HIP_EINVAL, "d_coeffs == NULL");
   hipStream_t st = static_cast<hipStream_t>(stream);
   FrameGeo g;
   ScanArgs a;
-  const int rc = prepare_scan(e, d_rgb, row_stride, frame_stride, width, height, yuv_mode, nframes,
-                              tables, st, &g, &a);
+  int cls = 0;
+  const int rc = prepare_scan(e, src, width, height, yuv_mode, nframes, tables, st, &g, &a, &cls);
   if (rc) return rc;
   a.coeffs = d_coeffs;
-  return launch_scan<kKindTap>(yuv_mode, dim3(g.nseg, nframes), st, a);
+  return launch_scan<kKindTap>(yuv_mode, cls, dim3(g.nseg, nframes), st, a);
 }
 
-static int scan_statistics(sjpeg_hip_engine* e, const void* d_rgb, int64_t row_stride,
-                           int64_t frame_stride, int width, int height, int yuv_mode, int nframes,
-                           const sjpeg_hip_scan_tables* tables, bool histogram, uint32_t* d_out,
-                           void* stream) {
+int sjpeg_hip_scan_coeffs(sjpeg_hip_engine* e, const void* d_rgb, int64_t row_stride,
+                          int64_t frame_stride, int width, int height, int yuv_mode, int nframes,
+                          const sjpeg_hip_scan_tables* tables, int16_t* d_coeffs, void* stream) {
+  const sjpeg_hip_source s = rgb_source(d_rgb, row_stride, frame_stride);
+  return sjpeg_hip_scan_coeffs_src(e, &s, width, height, yuv_mode, nframes, tables, d_coeffs, stream);
+}
+
+static int scan_statistics(sjpeg_hip_engine* e, const sjpeg_hip_source* src, int width, int height,
+                           int yuv_mode, int nframes, const sjpeg_hip_scan_tables* tables,
+                           bool histogram, uint32_t* d_out, void* stream) {
   if (d_out == nullptr) return fail(SJPEG_HIP_EINVAL, "output pointer == NULL");
   hipStream_t st = static_cast<hipStream_t>(stream);
   sjpeg_hip_scan_tables dummy;
@@ -1396,14 +1548,14 @@ static int scan_statistics(sjpeg_hip_engine* e, const void* d_rgb, int64_t row_s
   }
   FrameGeo g;
   ScanArgs a;
-  int rc = prepare_scan(e, d_rgb, row_stride, frame_stride, width, height, yuv_mode, nframes,
-                        tables, st, &g, &a);
+  int cls = 0;
+  int rc = prepare_scan(e, src, width, height, yuv_mode, nframes, tables, st, &g, &a, &cls);
   if (rc) return rc;
   const int words = histogram ? kHistoWords : kStatsWords;
   if ((rc = e->partial.ensure(static_cast<size_t>(nframes) * g.nseg * words))) return rc;
   a.partial = e->partial.p;
-  if (histogram) rc = launch_scan<kKindHisto>(yuv_mode, dim3(g.nseg, nframes), st, a);
-  else rc = launch_scan<kKindStats>(yuv_mode, dim3(g.nseg, nframes), st, a);
+  if (histogram) rc = launch_scan<kKindHisto>(yuv_mode, cls, dim3(g.nseg, nframes), st, a);
+  else rc = launch_scan<kKindStats>(yuv_mode, cls, dim3(g.nseg, nframes), st, a);
   if (rc) return rc;
   const dim3 grid((words + kThreads - 1) / kThreads, nframes);
   if (histogram) {
@@ -1415,20 +1567,31 @@ static int scan_statistics(sjpeg_hip_engine* e, const void* d_rgb, int64_t row_s
   return 0;
 }
 
+int sjpeg_hip_scan_histogram_src(sjpeg_hip_engine* e, const sjpeg_hip_source* src, int width, int height,
+                                 int yuv_mode, int nframes, uint32_t* d_hist, void* stream) {
+  return scan_statistics(e, src, width, height, yuv_mode, nframes, nullptr, true, d_hist, stream);
+}
+
 int sjpeg_hip_scan_histogram(sjpeg_hip_engine* e, const void* d_rgb, int64_t row_stride,
                              int64_t frame_stride, int width, int height, int yuv_mode, int nframes,
                              uint32_t* d_hist, void* stream) {
-  return scan_statistics(e, d_rgb, row_stride, frame_stride, width, height, yuv_mode, nframes,
-                         nullptr, true, d_hist, stream);
+  const sjpeg_hip_source s = rgb_source(d_rgb, row_stride, frame_stride);
+  return scan_statistics(e, &s, width, height, yuv_mode, nframes, nullptr, true, d_hist, stream);
+}
+
+int sjpeg_hip_scan_symbol_stats_src(sjpeg_hip_engine* e, const sjpeg_hip_source* src, int width,
+                                    int height, int yuv_mode, int nframes,
+                                    const sjpeg_hip_scan_tables* tables, uint32_t* d_freq, void* stream) {
+  if (tables == nullptr) return fail(SJPEG_HIP_EINVAL, "tables == NULL");
+  return scan_statistics(e, src, width, height, yuv_mode, nframes, tables, false, d_freq, stream);
 }
 
 int sjpeg_hip_scan_symbol_stats(sjpeg_hip_engine* e, const void* d_rgb, int64_t row_stride,
                                 int64_t frame_stride, int width, int height, int yuv_mode,
                                 int nframes, const sjpeg_hip_scan_tables* tables, uint32_t* d_freq,
                                 void* stream) {
-  if (tables == nullptr) return fail(SJPEG_HIP_EINVAL, "tables == NULL");
-  return scan_statistics(e, d_rgb, row_stride, frame_stride, width, height, yuv_mode, nframes,
-                         tables, false, d_freq, stream);
+  const sjpeg_hip_source s = rgb_source(d_rgb, row_stride, frame_stride);
+  return sjpeg_hip_scan_symbol_stats_src(e, &s, width, height, yuv_mode, nframes, tables, d_freq, stream);
 }
 
 int sjpeg_hip_encode_scan(sjpeg_hip_engine* e, const void* d_rgb, int64_t row_stride,
@@ -1436,13 +1599,22 @@ int sjpeg_hip_encode_scan(sjpeg_hip_engine* e, const void* d_rgb, int64_t row_st
                           const sjpeg_hip_scan_tables* tables, const void* header,
                           size_t header_size, int append_eoi, void* d_out, size_t out_stride,
                           uint64_t* d_sizes, void* stream) {
+  const sjpeg_hip_source s = rgb_source(d_rgb, row_stride, frame_stride);
+  return sjpeg_hip_encode_scan_src(e, &s, width, height, yuv_mode, nframes, tables, header, header_size,
+                                   append_eoi, d_out, out_stride, d_sizes, stream);
+}
+
+int sjpeg_hip_encode_scan_src(sjpeg_hip_engine* e, const sjpeg_hip_source* src, int width, int height,
+                              int yuv_mode, int nframes, const sjpeg_hip_scan_tables* tables,
+                              const void* header, size_t header_size, int append_eoi, void* d_out,
+                              size_t out_stride, uint64_t* d_sizes, void* stream) {
   if (d_out == nullptr || d_sizes == nullptr) return fail(SJPEG_HIP_EINVAL, "d_out/d_sizes == NULL");
   if (header == nullptr) header_size = 0;
   hipStream_t st = static_cast<hipStream_t>(stream);
   FrameGeo g;
   ScanArgs a;
-  int rc = prepare_scan(e, d_rgb, row_stride, frame_stride, width, height, yuv_mode, nframes,
-                        tables, st, &g, &a);
+  int cls = 0;
+  int rc = prepare_scan(e, src, width, height, yuv_mode, nframes, tables, st, &g, &a, &cls);
   if (rc) return rc;
   if (out_stride < header_size + 2 + 64) {
     return fail(SJPEG_HIP_ECAPACITY, "out_stride " + std::to_string(out_stride) + " too small");
@@ -1470,7 +1642,7 @@ int sjpeg_hip_encode_scan(sjpeg_hip_engine* e, const void* d_rgb, int64_t row_st
   s.sizes = reinterpret_cast<unsigned long long*>(d_sizes);
 
   if (e->timing) HIP_TRY(hipEventRecord(e->ev[0], st));
-  if ((rc = launch_scan<kKindEncode>(yuv_mode, dim3(g.nseg, nframes), st, a))) return rc;
+  if ((rc = launch_scan<kKindEncode>(yuv_mode, cls, dim3(g.nseg, nframes), st, a))) return rc;
   if (e->timing) HIP_TRY(hipEventRecord(e->ev[1], st));
 
   hipLaunchKernelGGL(scan_seg_offsets, dim3(nframes), dim3(kThreads), 0, st, s);

@@ -124,6 +124,42 @@ int main(int argc, char** argv) {
     CHECK(!sjpeg::Encode(rgb.data(), W, H, 3 * W, param, &out));
   }
 
+  // ---- the other input layouts of the API (reference: src/sjpeg.h:300-349)
+  {
+    const int w = 37, h = 23, cw = (w + 1) / 2, ch = (h + 1) / 2;
+    const std::vector<uint8_t> px = Picture(w, h, 777);          // reused as raw byte material
+    std::vector<uint8_t> bgra(4 * w * h), yp(w * h), up(cw * ch), vp(cw * ch), uv(2 * cw * ch), u4(w * h), v4(w * h);
+    for (int i = 0; i < w * h; ++i) {
+      bgra[4 * i] = px[3 * i + 2]; bgra[4 * i + 1] = px[3 * i + 1]; bgra[4 * i + 2] = px[3 * i]; bgra[4 * i + 3] = 0x5a;
+      yp[i] = px[3 * i]; u4[i] = px[3 * i + 1]; v4[i] = px[3 * i + 2];
+    }
+    for (int i = 0; i < cw * ch; ++i) { up[i] = px[5 * i % px.size()]; vp[i] = px[7 * i % px.size()]; uv[2 * i] = up[i]; uv[2 * i + 1] = vp[i]; }
+    sjpeg::EncoderParam param(66.f);                              // default method 4
+    std::string out;
+    param.yuv_mode = SJPEG_YUV_444;
+    CHECK(sjpeg::EncodeBGRA(bgra.data(), w, h, 4 * w, param, &out));
+    Save(dir, "bgra_444_q66", out);
+    std::vector<uint8_t> vec;
+    std::shared_ptr<sjpeg::ByteSink> sink = sjpeg::MakeByteSink(&vec);
+    param.yuv_mode = SJPEG_YUV_420;
+    CHECK(sjpeg::EncodeGray(yp.data(), w, h, w, param, &out));
+    Save(dir, "gray_q66", out);
+    CHECK(sjpeg::EncodeNV12(yp.data(), w, uv.data(), 2 * cw, w, h, param, sink.get()));
+    Save(dir, "nv12_q66", std::string(vec.begin(), vec.end()));
+    sink = sjpeg::MakeByteSink(&vec);
+    CHECK(sjpeg::EncodeNV21(yp.data(), w, uv.data(), 2 * cw, w, h, param, sink.get()));
+    Save(dir, "nv21_q66", std::string(vec.begin(), vec.end()));
+    sink = sjpeg::MakeByteSink(&vec);
+    CHECK(sjpeg::EncodeYUV420(yp.data(), w, up.data(), cw, vp.data(), cw, w, h, param, sink.get()));
+    Save(dir, "yuv420_q66", std::string(vec.begin(), vec.end()));
+    sink = sjpeg::MakeByteSink(&vec);
+    CHECK(sjpeg::EncodeYUV444(yp.data(), w, u4.data(), w, v4.data(), w, w, h, param, sink.get()));
+    Save(dir, "yuv444_q66", std::string(vec.begin(), vec.end()));
+    CHECK(!sjpeg::EncodeBGRA(bgra.data(), w, h, 4 * w - 1, param, &out));       // stride too small
+    CHECK(!sjpeg::EncodeNV12(yp.data(), w, uv.data(), 2 * cw - 1, w, h, param, sink.get()));
+    CHECK(!sjpeg::EncodeYUV420(yp.data(), w, nullptr, cw, vp.data(), cw, w, h, param, sink.get()));
+  }
+
   // ---- quality ordering, method clamping
   {
     sjpeg::EncoderParam lo(30.f), hi(95.f);

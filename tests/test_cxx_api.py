@@ -52,6 +52,25 @@ def test_cxx_api_behaviour_and_parity(tmp_path, oracle):
     quant = np.clip((m * 100.0 / 80.0 + 0.5).astype(np.int64), 1, 255).astype(np.uint8)
     assert read("setquant_r80_limit_420") == oracle.encode_full(img, quant, min_quant=quant, yuv_mode=1, method=4)
     assert read("threads_q72_420") == oracle.encode_full(img, sj.make_tables(quality=72.0)[1], yuv_mode=1, method=4)
+    # other input layouts, rebuilt here exactly as api_test.cc builds them
+    w, h = 37, 23
+    cw, ch = (w + 1) // 2, (h + 1) // 2
+    px = synth.g_struct(w, h, 777).reshape(-1)
+    rgb = px.reshape(h * w, 3)
+    bgra = np.stack([rgb[:, 2], rgb[:, 1], rgb[:, 0], np.full(h * w, 0x5a, np.uint8)], 1).reshape(h, 4 * w)
+    yp, u4, v4 = (rgb[:, c].reshape(h, w).copy() for c in range(3))
+    idx = np.arange(cw * ch)
+    up = px[(5 * idx) % px.size].reshape(ch, cw).copy()
+    vp = px[(7 * idx) % px.size].reshape(ch, cw).copy()
+    uv = np.stack([up.reshape(-1), vp.reshape(-1)], 1).reshape(ch, 2 * cw).copy()
+    q66 = sj.make_tables(quality=66.0)[1]
+    from oracle import orc
+    assert read("bgra_444_q66") == oracle.encode_src(orc.SRC_BGRA, [bgra], w, h, q66, yuv_mode=3, method=4)
+    assert read("gray_q66") == oracle.encode_src(orc.SRC_GRAY, [yp], w, h, q66, method=4)
+    assert read("nv12_q66") == oracle.encode_src(orc.SRC_NV12, [yp, uv], w, h, q66, method=4)
+    assert read("nv21_q66") == oracle.encode_src(orc.SRC_NV21, [yp, uv], w, h, q66, method=4)
+    assert read("yuv420_q66") == oracle.encode_src(orc.SRC_YUV420, [yp, up, vp], w, h, q66, method=4)
+    assert read("yuv444_q66") == oracle.encode_src(orc.SRC_YUV444, [yp, u4, v4], w, h, q66, method=4)
     # metadata: same entropy data and tables as the plain stream, with the APPn segments spliced in
     meta = read("metadata_444")
     plain = oracle.encode_full(img, sj.make_tables(quality=80.0)[1], yuv_mode=3, method=0)

@@ -245,6 +245,48 @@ def test_c5_recompress_default_params(engine, digests):
     assert len(got) == d["size"] and hashlib.md5(got).hexdigest() == d["md5"]
 
 
+# ---- other input layouts: BGRA / RGBA / gray / planar YUV / NV12 / NV21 -------------------------
+
+def _random_planes(rng, fmt, w, h):
+    cw, ch = (w + 1) // 2, (h + 1) // 2
+    shapes = {1: [(h, 4 * w)], 2: [(h, 4 * w)], 3: [(h, w)], 4: [(h, w)] * 3, 5: [(h, w), (ch, cw), (ch, cw)],
+              6: [(h, w), (ch, 2 * cw)], 7: [(h, w), (ch, 2 * cw)]}[fmt]
+    return [rng.randint(0, 256, s).astype(np.uint8) for s in shapes]
+
+
+@pytest.mark.parametrize("fmt", [1, 2, 3, 4, 5, 6, 7])
+def test_source_layouts_vs_oracle(engine, oracle, fmt):
+    rng = np.random.RandomState(100 + fmt)
+    for (w, h) in ((1, 1), (16, 16), (17, 13), (40, 9), (97, 61), (250, 130), (1920, 1080)):
+        planes = _random_planes(rng, fmt, w, h)
+        if w >= 97:                                   # smoother content for the big ones
+            planes = [(p // 4 + np.arange(p.shape[1])[None, :] // 3).astype(np.uint8) for p in planes]
+        dev_planes = [torch.from_numpy(p).cuda().unsqueeze(0) for p in planes]
+        modes = (1, 3, 4) if fmt in (1, 2) else (1,)
+        for mode in modes:
+            for q, method in ((75.0, 0), (40.0, 4), (92.0, 3), (60.0, 1)):
+                got = sj.encode_source_method(fmt, dev_planes, w, h, q, mode, method, engine=engine)
+                want = oracle.encode_src(fmt, planes, w, h, oracle.quality_matrices(q), yuv_mode=mode,
+                                         method=method)
+                assert got == want, (fmt, w, h, mode, q, method)
+
+
+def test_source_argument_errors(engine):
+    y = torch.zeros((1, 16, 16), dtype=torch.uint8, device="cuda")
+    t, quant = sj.make_tables(quality=75)
+    src, _ = sj.make_source(sj.SRC_GRAY, [y])
+    with pytest.raises(sj.SjpegError):                 # gray implies 4:0:0
+        engine.encode_source(src, 1, 16, 16, t, b"", sj.YUV_420)
+    src, _ = sj.make_source(sj.SRC_NV12, [y])           # chroma plane missing
+    with pytest.raises(sj.SjpegError):
+        engine.encode_source(src, 1, 16, 16, t, b"", sj.YUV_420)
+    c = torch.zeros((1, 8, 4), dtype=torch.uint8, device="cuda")
+    src, _ = sj.make_source(sj.SRC_YUV420, [y, c, c])   # chroma rows shorter than (16 + 1) / 2
+    with pytest.raises(sj.SjpegError):
+        engine.encode_source(src, 1, 16, 16, t, b"", sj.YUV_420)
+    torch.cuda.synchronize()
+
+
 # ---- BASELINE.json full-size configurations --------------------------------------------------
 
 @pytest.mark.parametrize("name,mname", [("struct4k", "420"), ("noise4k", "420"), ("struct4k", "444"),
