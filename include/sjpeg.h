@@ -7,9 +7,10 @@
 // as HIP kernels on a gfx950 device (see sjpeg_hip.h); quantizer/table/header preparation
 // stays on the host and mirrors the reference bit for bit.
 //
-// What this build runs on the GPU: YUV 4:2:0 / 4:4:4 / 4:0:0 from packed RGB, with
-// standard or optimised Huffman tables (see docs in DESIGN.md for the current matrix).
-// Requests outside that matrix FAIL (return 0 / false) -- there is no CPU fallback.
+// What this build runs on the GPU: YUV 4:2:0 / 4:4:4 / 4:0:0 from every input layout of the
+// API, compression methods 0..6 (standard or optimised Huffman tables, fixed or adaptive
+// quantization).  SJPEG_YUV_AUTO / SJPEG_YUV_SHARP, trellis and the multi-pass size/PSNR search
+// are not available: such requests FAIL (0 / false), there is no CPU fallback.
 // The reason of the last failure on the calling thread: SjpegHipLastError().
 #ifndef SJPEG_AMD_SJPEG_H_
 #define SJPEG_AMD_SJPEG_H_
