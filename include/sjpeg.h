@@ -9,8 +9,9 @@
 //
 // What this build runs on the GPU: YUV 4:2:0 / 4:4:4 / 4:0:0 from every input layout of the
 // API, compression methods 0..6 (standard or optimised Huffman tables, fixed or adaptive
-// quantization).  SJPEG_YUV_AUTO / SJPEG_YUV_SHARP, trellis and the multi-pass size/PSNR search
-// are not available: such requests FAIL (0 / false), there is no CPU fallback.
+// quantization), and the multi-pass size / PSNR search (every pass is a GPU pass over the resident
+// picture).  SJPEG_YUV_AUTO / SJPEG_YUV_SHARP and trellis quantization are not available
+// (DESIGN.md section 1): such requests FAIL (0 / false), there is no CPU fallback.
 // The reason of the last failure on the calling thread: SjpegHipLastError().
 #ifndef SJPEG_AMD_SJPEG_H_
 #define SJPEG_AMD_SJPEG_H_

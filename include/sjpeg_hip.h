@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SJPEG_HIP_ABI_VERSION 1
+#define SJPEG_HIP_ABI_VERSION 2
 
 enum {
   SJPEG_HIP_OK = 0,
@@ -57,6 +57,8 @@ typedef struct sjpeg_hip_scan_tables {
   uint16_t bias[2][64];
   uint32_t dc_codes[2][12];
   uint32_t ac_codes[2][256];
+  uint8_t quant[2][64];        /* the (final, clamped) quantizer steps; only the quantization-
+                                  error pass reads them (src/quantize.cc:553-565) */
 } sjpeg_hip_scan_tables;
 
 /* Pixel sources.  Packed colour and gray use plane[0]; planar YUV uses Y, U, V; NV12/NV21 use
@@ -165,6 +167,21 @@ int sjpeg_hip_scan_symbol_stats(sjpeg_hip_engine* engine,
                                 int width, int height, int yuv_mode, int nframes,
                                 const sjpeg_hip_scan_tables* tables,
                                 uint32_t* d_freq, void* stream);
+
+/* Replaces Encoder::ComputePSNR's inner sum (src/dichotomy.cc:302-323 with QuantizeError,
+ * src/quantize.cc:553-565): d_err receives, per frame, the uint64 sum over all blocks and
+ * coefficients of ((|c| >> 4) - quant * level)^2 (each block's sum wrapped to 32 bits like the
+ * reference).  Needs tables->iquant / bias / quant. */
+int sjpeg_hip_scan_quant_error_src(sjpeg_hip_engine* engine, const struct sjpeg_hip_source* src,
+                                   int width, int height, int yuv_mode, int nframes,
+                                   const sjpeg_hip_scan_tables* tables, uint64_t* d_err,
+                                   void* stream);
+
+/* Number of entropy-coded bits (before byte stuffing and padding) of each frame of the most
+ * recent sjpeg_hip_encode_scan*() call on this engine, copied to HOST memory `bits[nframes]`.
+ * Synchronises the device.  With the coded size this gives what the reference's BitCounter
+ * reports (src/bit_writer.h:292-365). */
+int sjpeg_hip_engine_entropy_bits(sjpeg_hip_engine* engine, uint64_t* bits, int nframes);
 
 /* The same four operations for any pixel source (the functions above are these with
  * format = SJPEG_HIP_SRC_RGB).  yuv_mode must match the source where it is implied. */

@@ -80,6 +80,11 @@ class Oracle:
         lib.orc_encode_src.restype = C.c_size_t
         lib.orc_encode_src.argtypes = [C.POINTER(Source), C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                        C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_u8p)]
+        lib.orc_encode_search.restype = C.c_size_t
+        lib.orc_encode_search.argtypes = [C.POINTER(Source), C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                          C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                          C.c_float, C.c_int, C.c_float, C.c_float, C.c_float,
+                                          C.POINTER(_u8p)]
         lib.orc_histogram_src.argtypes = [C.POINTER(Source), C.c_int, C.c_int, C.c_int, C.c_void_p]
         lib.orc_symbol_stats_src.argtypes = [C.POINTER(Source), C.c_int, C.c_int, C.c_int, C.c_void_p,
                                              C.c_int, C.c_void_p]
@@ -158,6 +163,33 @@ class Oracle:
                                     mq.ctypes.data if mq is not None else None, q_bias, dmax_luma,
                                     dmax_chroma, yuv_mode, method, C.byref(out))
         return self._take(n, out)
+
+    def encode_search(self, fmt, planes, w, h, quant, yuv_mode=YUV_420, huffman=True, adaptive=True,
+                      target_mode=1, target_value=0.0, passes=10, tolerance=1.0, qmin=0.0, qmax=100.0,
+                      min_quant=None, q_bias=0x78, dmax_luma=12, dmax_chroma=1):
+        src, keep = make_source(fmt, planes)
+        q = np.ascontiguousarray(quant, np.uint8).reshape(2, 64)
+        mq = None if min_quant is None else np.ascontiguousarray(min_quant, np.uint8).reshape(2, 64)
+        out = _u8p()
+        n = self.lib.orc_encode_search(C.byref(src), w, h, q.ctypes.data,
+                                       mq.ctypes.data if mq is not None else None, q_bias, dmax_luma,
+                                       dmax_chroma, yuv_mode, int(huffman), int(adaptive), target_mode,
+                                       target_value, passes, tolerance, qmin, qmax, C.byref(out))
+        return self._take(n, out)
+
+    def quant_error(self, fmt, planes, w, h, quant, yuv_mode=YUV_420, q_bias=0x78):
+        src, keep = make_source(fmt, planes)
+        q = np.ascontiguousarray(quant, np.uint8).reshape(2, 64)
+        self.lib.orc_quant_error_src.restype = C.c_uint64
+        return int(self.lib.orc_quant_error_src(C.byref(src), C.c_int(w), C.c_int(h), C.c_int(yuv_mode),
+                                                C.c_void_p(q.ctypes.data), C.c_int(q_bias)))
+
+    def counted_bits(self, fmt, planes, w, h, quant, yuv_mode=YUV_420, q_bias=0x78):
+        src, keep = make_source(fmt, planes)
+        q = np.ascontiguousarray(quant, np.uint8).reshape(2, 64)
+        self.lib.orc_counted_bits_src.restype = C.c_uint64
+        return int(self.lib.orc_counted_bits_src(C.byref(src), C.c_int(w), C.c_int(h), C.c_int(yuv_mode),
+                                                 C.c_void_p(q.ctypes.data), C.c_int(q_bias)))
 
     def histogram(self, rgb, yuv_mode=YUV_420, stride=None):
         rgb, w, h, stride = self._img(rgb, stride)

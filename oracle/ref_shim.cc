@@ -42,6 +42,24 @@ size_t ref_encode_param(const uint8_t* rgb, int w, int h, int stride,
   return sjpeg::Encode(rgb, w, h, stride, param, out);
 }
 
+// sjpeg::Encode() with the size/PSNR search enabled (src/dichotomy.cc:113-205).
+// target_mode: 1 = size (bytes), 2 = PSNR (dB).  q_out / value_out: what the default hook found.
+size_t ref_encode_search(const uint8_t* rgb, int w, int h, int stride, float quality, int yuv_mode,
+                         int huffman, int adaptive, int target_mode, float target_value, int passes,
+                         float tolerance, float qmin, float qmax, uint8_t** out) {
+  sjpeg::EncoderParam param(quality);
+  param.yuv_mode = static_cast<SjpegYUVMode>(yuv_mode);
+  param.Huffman_compress = (huffman != 0);
+  param.adaptive_quantization = (adaptive != 0);
+  param.target_mode = static_cast<sjpeg::EncoderParam::TargetMode>(target_mode);
+  param.target_value = target_value;
+  param.passes = passes;
+  param.tolerance = tolerance;
+  param.qmin = qmin;
+  param.qmax = qmax;
+  return sjpeg::Encode(rgb, w, h, stride, param, out);
+}
+
 size_t ref_encode(const uint8_t* rgb, int w, int h, int stride, float quality,
                   int method, int yuv_mode, uint8_t** out) {
   return SjpegEncode(rgb, w, h, stride, out, quality, method,

@@ -971,4 +971,185 @@ size_t orc_encode_method(const uint8_t* rgb, int W, int H, int stride, float qua
   return orc_encode_full(rgb, W, H, stride, m, NULL, 0x78, 12, 1, yuv_mode, method, out);
 }
 
+/* ---------------------------------------------------------------- size / PSNR search */
+
+static float estimate_quality(const uint8_t m[64]) {      /* src/jpeg_tools.cc:143-167, luma */
+  int best_q = 0;
+  float best = 256.f * 256 * 64 + 1;
+  for (int q = 0; q <= 100; ++q) {
+    uint8_t t[64];
+    orc_set_quant_matrix(kAnnexK1[0], orc_qfactor((float)q), t);
+    float score = 0;
+    for (int i = 0; i < 64; ++i) {
+      const float d = (float)t[i] - (float)m[i];
+      score += d * d;
+      if (score > best) break;
+    }
+    if (score < best) { best = score; best_q = q; }
+  }
+  return (float)best_q;
+}
+
+/* src/dichotomy.cc:302-323 + src/quantize.cc:553-568 */
+static float psnr_and_error(const orc_source* S, const orc_scan* s, int yuv_mode, uint64_t* error_out) {
+  uint64_t error = 0;
+  int16_t in[6 * 64];
+  for (int my = 0; my < s->mb_h; ++my) {
+    for (int mx = 0; mx < s->mb_w; ++mx) {
+      orc_get_samples_src(S, yuv_mode, s->W, s->H, mx, my, in);
+      orc_fdct(in, s->L.mcu_blocks);
+      const int16_t* blk = in;
+      for (int c = 0; c < s->L.nb_comps; ++c) {
+        const orc_quantizer* Q = &s->q[s->L.quant_idx[c]];
+        for (int n = 0; n < s->L.nb_blocks[c]; ++n, blk += 64) {
+          uint32_t err = 0;
+          for (int j = 0; j < 64; ++j) {
+            int32_t v0 = blk[j] < 0 ? -blk[j] : blk[j];
+            const uint32_t v = Q->quant[j] * (uint32_t)quantize_abs((uint32_t)v0, Q->iquant[j], Q->bias[j]);
+            v0 >>= 4;
+            err += ((uint32_t)v0 - v) * ((uint32_t)v0 - v);
+          }
+          error += err;
+        }
+      }
+    }
+  }
+  if (error_out != NULL) *error_out = error;
+  const uint64_t size = 64ull * (uint64_t)s->mb_w * s->mb_h * s->L.mcu_blocks;
+  return (error > 0 && size > 0) ? 4.3429448f * log(size / (error / 255. / 255.)) : 99.f;
+}
+static float psnr_of(const orc_source* S, const orc_scan* s, int yuv_mode) {
+  return psnr_and_error(S, s, yuv_mode, NULL);
+}
+/* the two quantities one search pass measures, for direct kernel checks */
+uint64_t orc_quant_error_src(const orc_source* S, int W, int H, int yuv_mode, const uint8_t quant[2][64],
+                             int q_bias) {
+  orc_scan s;
+  uint64_t err = 0;
+  if (!scan_init(&s, W, H, yuv_mode, quant, NULL, q_bias)) return 0;
+  psnr_and_error(S, &s, yuv_mode, &err);
+  return err;
+}
+
+/* bits of the entropy segment incl. 0xFF escapes of completed bytes (BitCounter, bit_writer.h:292-365) */
+static size_t counted_bits(orc_scan* s, const orc_source* S, int yuv_mode, uint32_t dc[2][12], uint32_t ac[2][256]) {
+  orc_bw w;
+  memset(&w, 0, sizeof(w));
+  /* emit without the final padding: scan_emit pads, so redo its loop here */
+  int pred[3] = {0, 0, 0};
+  int16_t in[6 * 64], zz[64];
+  for (int my = 0; my < s->mb_h; ++my) {
+    for (int mx = 0; mx < s->mb_w; ++mx) {
+      orc_get_samples_src(S, yuv_mode, s->W, s->H, mx, my, in);
+      orc_fdct(in, s->L.mcu_blocks);
+      const int16_t* blk = in;
+      for (int c = 0; c < s->L.nb_comps; ++c) {
+        const int t = s->L.quant_idx[c];
+        for (int i = 0; i < s->L.nb_blocks[c]; ++i, blk += 64) {
+          orc_quantize_block(blk, &s->q[t], zz);
+          code_block(&w, zz, &pred[c], dc[t], ac[t]);
+        }
+      }
+    }
+  }
+  const size_t bits = 8 * w.size + (size_t)w.nbits;   /* escapes are already in w.size */
+  free(w.buf);
+  return bits;
+}
+uint64_t orc_counted_bits_src(const orc_source* S, int W, int H, int yuv_mode, const uint8_t quant[2][64],
+                              int q_bias) {
+  orc_scan s;
+  uint32_t dc[2][12], ac[2][256];
+  if (!scan_init(&s, W, H, yuv_mode, quant, NULL, q_bias)) return 0;
+  orc_default_codes(dc, ac);
+  return counted_bits(&s, S, yuv_mode, dc, ac);
+}
+
+size_t orc_encode_search(const orc_source* S, int W, int H, const uint8_t quant[2][64],
+                         const uint8_t* min_quant, int q_bias, int qdelta_max_luma,
+                         int qdelta_max_chroma, int yuv_mode, int huffman, int adaptive,
+                         int target_mode, float target_value, int passes, float tolerance,
+                         float qmin_in, float qmax_in, uint8_t** out) {
+  orc_scan s;
+  *out = NULL;
+  if (S->format == ORC_SRC_GRAY) yuv_mode = ORC_YUV_400;
+  else if (S->format == ORC_SRC_YUV444) yuv_mode = ORC_YUV_444;
+  else if (S->format >= ORC_SRC_YUV420) yuv_mode = ORC_YUV_420;
+  if (!scan_init(&s, W, H, yuv_mode, quant, min_quant, q_bias)) return 0;
+  passes = passes < 1 ? 1 : passes > 20 ? 20 : passes;            /* src/api.cc:169 */
+  /* SearchHook::Setup, src/dichotomy.cc:41-52 */
+  const int for_size = (target_mode == 1);
+  const float target = target_value;
+  const float tol = tolerance / 100.;
+  float qmin = (qmin_in < 0) ? 0 : qmin_in;
+  float qmax = (qmax_in > 100) ? 100 : (qmax_in < qmin_in) ? qmin_in : qmax_in;
+  float q = estimate_quality(quant[0]);
+  q = q < qmin ? qmin : q > qmax ? qmax : q;
+  uint32_t* hist = NULL;
+  if (adaptive) {
+    hist = (uint32_t*)malloc(2 * 64 * 128 * sizeof(uint32_t));
+    orc_histogram_src(S, W, H, yuv_mode, hist);
+  }
+  const int nt = s.L.nb_comps == 1 ? 1 : 2;
+  uint8_t opt_quants[2][64];
+  float best = 0.f;
+  for (int p = 0; p < passes; ++p) {
+    for (int c = 0; c < 2; ++c) {                  /* NextMatrix + FinalizeQuantMatrix */
+      orc_set_quant_matrix(kAnnexK1[c], orc_qfactor(q), s.q[c].quant);
+      orc_finalize_quant(&s.q[c], q_bias);
+    }
+    if (adaptive) orc_adapt_quant(hist, s.L.nb_comps, s.q, q_bias, qdelta_max_luma, qdelta_max_chroma);
+    float result;
+    if (for_size) {
+      orc_huff h[4];
+      default_huff(h);
+      uint32_t freq[2][272];
+      scan_stats(&s, S, yuv_mode, &freq[0][0]);
+      if (huffman) {
+        for (int t = 0; t < nt; ++t) {
+          memset(&h[t], 0, sizeof(h[t])); memset(&h[2 + t], 0, sizeof(h[2 + t]));
+          h[t].nsyms = orc_build_optimal(freq[t] + 256, 12, h[t].bits, h[t].syms);
+          h[2 + t].nsyms = orc_build_optimal(freq[t], 256, h[2 + t].bits, h[2 + t].syms);
+        }
+      }
+      uint32_t dc[2][12], ac[2][256];
+      memset(dc, 0, sizeof(dc)); memset(ac, 0, sizeof(ac));
+      for (int t = 0; t < 2; ++t) { orc_build_huffman(h[t].bits, h[t].syms, dc[t]); orc_build_huffman(h[2 + t].bits, h[2 + t].syms, ac[t]); }
+      /* HeaderSize(), src/dichotomy.cc:210-241 (no metadata here) */
+      size_t size = 20 + (size_t)nt * 65 + 2 + 2 + 8 + 3 * s.L.nb_comps + 2 + 6 + 2 * s.L.nb_comps + 2 + 2;
+      for (int t = 0; t < nt; ++t) size += (2 + 3 + 16 + h[t].nsyms) + (2 + 3 + 16 + h[2 + t].nsyms);
+      size *= 8;
+      if (huffman) {                               /* EntropySize(), src/entropy.cc:230-245 */
+        for (int t = 0; t < nt; ++t) {
+          for (int len = 0; len < 12; ++len) if (freq[t][256 + len]) size += (size_t)freq[t][256 + len] * ((dc[t][len] & 0xff) + len);
+          for (int sym = 0; sym < 256; ++sym) if (freq[t][sym]) size += (size_t)freq[t][sym] * ((ac[t][sym] & 0xff) + (sym & 0x0f));
+        }
+      } else {
+        size += counted_bits(&s, S, yuv_mode, dc, ac);
+      }
+      result = size / 8.f;
+    } else {
+      result = psnr_of(S, &s, yuv_mode);
+    }
+    const int last_is_best = (p == 0 || fabs(result - target) < best);
+    if (last_is_best) {
+      memcpy(opt_quants[0], s.q[0].quant, 64);
+      memcpy(opt_quants[1], s.q[1].quant, 64);
+      best = fabs(result - target);
+    }
+    /* SearchHook::Update, src/dichotomy.cc:54-71 */
+    int done = (fabs(result - target) < tol * target);
+    if (done) break;
+    if (result > target) qmax = q; else qmin = q;
+    const float last_q = q;
+    q = (qmin + qmax) / 2.;
+    done = (fabs(q - last_q) < 0.15);
+    if (done) break;
+  }
+  free(hist);
+  /* final encode with the best matrices (no further adaptation) */
+  return orc_encode_src(S, W, H, opt_quants, min_quant, q_bias, qdelta_max_luma, qdelta_max_chroma,
+                        yuv_mode, huffman ? 1 : 0, out);
+}
+
 void orc_free(void* p) { free(p); }

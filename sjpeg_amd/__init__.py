@@ -27,7 +27,8 @@ class ScanTables(C.Structure):
     _fields_ = [("iquant", (C.c_uint16 * 64) * 2),
                 ("bias", (C.c_uint16 * 64) * 2),
                 ("dc_codes", (C.c_uint32 * 12) * 2),
-                ("ac_codes", (C.c_uint32 * 256) * 2)]
+                ("ac_codes", (C.c_uint32 * 256) * 2),
+                ("quant", (C.c_uint8 * 64) * 2)]
 
 
 SRC_RGB, SRC_BGRA, SRC_RGBA, SRC_GRAY, SRC_YUV444, SRC_YUV420, SRC_NV12, SRC_NV21 = range(8)
@@ -135,6 +136,9 @@ def lib() -> C.CDLL:
                                                C.c_void_p, C.c_void_p]
     L.sjpeg_hip_scan_symbol_stats_src.argtypes = [C.c_void_p, srcp, C.c_int, C.c_int, C.c_int, C.c_int,
                                                   C.POINTER(ScanTables), C.c_void_p, C.c_void_p]
+    L.sjpeg_hip_scan_quant_error_src.argtypes = [C.c_void_p, srcp, C.c_int, C.c_int, C.c_int, C.c_int,
+                                                 C.POINTER(ScanTables), C.c_void_p, C.c_void_p]
+    L.sjpeg_hip_engine_entropy_bits.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
     L.sjpeg_hip_adapt_quant.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                         C.c_int, C.c_int, C.POINTER(ScanTables)]
     L.sjpeg_hip_optimize_huffman.argtypes = [C.c_void_p, C.c_int, C.POINTER(HuffmanSpec),
@@ -162,7 +166,7 @@ EXPORTED_C_SYMBOLS = [
     "sjpeg_hip_finalize_quant", "sjpeg_hip_default_huffman", "sjpeg_hip_make_header",
     "sjpeg_hip_scan_histogram", "sjpeg_hip_scan_symbol_stats", "sjpeg_hip_adapt_quant",
     "sjpeg_hip_encode_scan_src", "sjpeg_hip_scan_coeffs_src", "sjpeg_hip_scan_histogram_src",
-    "sjpeg_hip_scan_symbol_stats_src",
+    "sjpeg_hip_scan_symbol_stats_src", "sjpeg_hip_scan_quant_error_src", "sjpeg_hip_engine_entropy_bits",
     "sjpeg_hip_optimize_huffman", "sjpeg_hip_make_header_ex",
     "sjpeg_hip_engine_set_timing", "sjpeg_hip_engine_last_scan_ms",
     "sjpeg_hip_engine_last_total_ms",
@@ -356,6 +360,20 @@ class Engine:
                                                         C.byref(tables), out.data_ptr(), self._stream()),
                   "sjpeg_hip_scan_symbol_stats_src")
         return out
+
+    def scan_quant_error_source(self, src: Source, nframes, w, h, tables, yuv_mode, device="cuda"):
+        import torch
+        out = torch.zeros(nframes, dtype=torch.int64, device=device)
+        self._chk(lib().sjpeg_hip_scan_quant_error_src(self._h, C.byref(src), w, h, yuv_mode, nframes,
+                                                       C.byref(tables), out.data_ptr(), self._stream()),
+                  "sjpeg_hip_scan_quant_error_src")
+        return out
+
+    def entropy_bits(self, nframes):
+        bits = np.zeros(nframes, np.uint64)
+        self._chk(lib().sjpeg_hip_engine_entropy_bits(self._h, bits.ctypes.data, nframes),
+                  "sjpeg_hip_engine_entropy_bits")
+        return bits
 
     def scan_histogram(self, frames, yuv_mode: int):
         """[F, 2, 64, 128] uint32 (as int32 tensor) coefficient histograms (adaptive quantization)."""

@@ -10,6 +10,7 @@
 #include <string.h>
 
 #include <cmath>
+#include <math.h>
 #include <new>
 #include <string>
 #include <vector>
@@ -190,6 +191,10 @@ struct Encoder {
     meta_.iccp = p.iccp; meta_.exif = p.exif; meta_.app_markers = p.app_markers;
     meta_.xmp = p.xmp; meta_.xmp_split = p.xmp_split_point;
     passes_ = p.passes < 1 ? 1 : p.passes > 20 ? 20 : p.passes;
+    if (passes_ > 1) {                                              // src/api.cc:170-176
+      search_hook_ = (p.search_hook == nullptr) ? &default_hook_ : p.search_hook;
+      search_ok_ = search_hook_->Setup(p);
+    }
     yuv_mode_ = p.yuv_mode;
   }
 
@@ -206,6 +211,9 @@ struct Encoder {
   int passes_;
   int qdelta_luma_, qdelta_chroma_;
   sjpeg_host::Metadata meta_;
+  SearchHook default_hook_;
+  SearchHook* search_hook_ = nullptr;
+  bool search_ok_ = true;
 };
 
 bool Encoder::Run() {
@@ -233,7 +241,6 @@ bool Encoder::Run() {
     return Fail("trellis quantization (methods 7, 8 / use_trellis) is not available in this build: "
                 "it is a per-block dynamic program outside the GPU hot path; no CPU fallback exists");
   }
-  if (passes_ > 1) return Fail("multi-pass size/PSNR search is not available in this build");
   if (qdelta_luma_ < 0 || qdelta_luma_ > 12 || qdelta_chroma_ < 0 || qdelta_chroma_ > 12) {
     return Fail("qdelta_max_luma / qdelta_max_chroma must be in [0, 12]");
   }
@@ -299,39 +306,156 @@ bool Encoder::Run() {
   sjpeg_host::FinalizeQuantizer(quant_[1], min_quant_[1], q_bias_, 1, &tables);
   if (!ctx.Ensure(&ctx.d_stats, &ctx.stats_cap, 2 * 64 * 128 * sizeof(uint32_t))) return false;
 
+  if (passes_ > 1 && !search_ok_) return Fail("SearchHook::Setup() failed");
+  const int ntables = (nb_comps == 1) ? 1 : 2;
+  std::vector<uint32_t> hist;
   if (adaptive) {
-    // CollectHistograms on the GPU, AnalyseHisto on the host (src/enc.cc:425-429)
+    // CollectHistograms on the GPU (src/enc.cc:425-429, src/dichotomy.cc:117-121)
     if (sjpeg_hip_scan_histogram_src(ctx.engine, &dsrc, W_, H_, mode, 1,
                                  static_cast<uint32_t*>(ctx.d_stats), nullptr) != 0) {
       return FailHip("sjpeg_hip_scan_histogram");
     }
-    std::vector<uint32_t> hist(2 * 64 * 128);
+    hist.resize(2 * 64 * 128);
     if (hipMemcpy(hist.data(), ctx.d_stats, hist.size() * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess) {
       return Fail(std::string("histogram pass failed: ") + hipGetErrorString(hipGetLastError()));
     }
+  }
+  auto adapt = [&]() {                              // AnalyseHisto on the host
     sjpeg_host::AdaptQuantMatrices(reinterpret_cast<const uint32_t(*)[64][128]>(hist.data()), nb_comps,
                                    quant_, min_quant_, qdelta_luma_, qdelta_chroma_);
     for (int idx = (nb_comps > 1 ? 1 : 0); idx >= 0; --idx) {
       sjpeg_host::FinalizeQuantizer(quant_[idx], min_quant_[idx], q_bias_, idx, &tables);
     }
+  };
+  auto symbol_stats = [&](uint32_t freq[2][272]) -> bool {
+    if (sjpeg_hip_scan_symbol_stats_src(ctx.engine, &dsrc, W_, H_, mode, 1, &tables,
+                                        static_cast<uint32_t*>(ctx.d_stats), nullptr) != 0) {
+      return FailHip("sjpeg_hip_scan_symbol_stats");
+    }
+    if (hipMemcpy(freq, ctx.d_stats, 2 * 272 * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess) {
+      return Fail(std::string("statistics pass failed: ") + hipGetErrorString(hipGetLastError()));
+    }
+    return true;
+  };
+
+  if (passes_ > 1) {
+    // Encoder::LoopScan (src/dichotomy.cc:113-205): the search is a host control loop; each pass
+    // costs one statistics / error / size pass on the GPU over the resident picture.
+    SearchHook* const hook = search_hook_;
+    uint8_t opt_quants[2][64];
+    float best = 0.f, best_q = 0.f, best_result = 0.f;
+    for (int p = 0; p < passes_; ++p) {
+      hook->pass = p;
+      for (int c = 0; c < 2; ++c) {
+        hook->NextMatrix(c, quant_[c]);
+        sjpeg_host::FinalizeQuantizer(quant_[c], min_quant_[c], q_bias_, c, &tables);
+      }
+      if (adaptive) adapt();
+      float result;
+      if (hook->for_size) {
+        const HuffSpec* pdc[2] = {&sjpeg_host::DefaultHuff(0, 0), &sjpeg_host::DefaultHuff(0, 1)};
+        const HuffSpec* pac[2] = {&sjpeg_host::DefaultHuff(1, 0), &sjpeg_host::DefaultHuff(1, 1)};
+        HuffSpec popt[4];
+        uint32_t freq[2][272];
+        if (optimize) {
+          if (!symbol_stats(freq)) return false;
+          for (int t = 0; t < ntables; ++t) {
+            sjpeg_host::BuildOptimalSpec(freq[t] + 256, 12, &popt[t]);
+            sjpeg_host::BuildOptimalSpec(freq[t], 256, &popt[2 + t]);
+            pdc[t] = &popt[t]; pac[t] = &popt[2 + t];
+          }
+        }
+        sjpeg_host::InstallCodes(pdc, pac, ntables, &tables);
+        // HeaderSize() with the reference's own accounting (src/dichotomy.cc:210-241)
+        size_t size = 20 + meta_.app_markers.size();
+        if (!meta_.exif.empty()) size += 8 + meta_.exif.size();
+        if (!meta_.iccp.empty()) {
+          const size_t kMax = 0xffff - 12 - 4;
+          size += ((meta_.iccp.size() - 1) / kMax + 1) * (12 + 4 + 2) + meta_.iccp.size();
+        }
+        if (!meta_.xmp.empty()) size += 2 + 2 + 29 + meta_.xmp.size();
+        size += ntables * 65 + 2 + 2;
+        size += 8 + 3 * nb_comps + 2;
+        size += 6 + 2 * nb_comps + 2;
+        size += 2;
+        for (int t = 0; t < ntables; ++t) size += (2 + 3 + 16 + pdc[t]->nsyms) + (2 + 3 + 16 + pac[t]->nsyms);
+        size *= 8;
+        if (optimize) {                              // EntropySize(), src/entropy.cc:230-245
+          for (int t = 0; t < ntables; ++t) {
+            for (int len = 0; len < 12; ++len) {
+              if (freq[t][256 + len]) size += static_cast<size_t>(freq[t][256 + len]) * ((tables.dc_codes[t][len] & 0xff) + len);
+            }
+            for (int sym = 0; sym < 256; ++sym) {
+              if (freq[t][sym]) size += static_cast<size_t>(freq[t][sym]) * ((tables.ac_codes[t][sym] & 0xff) + (sym & 0x0f));
+            }
+          }
+        } else {
+          // BitCounter (src/bit_writer.h:292-365): coded bits + 8 per 0xFF among COMPLETED bytes.
+          // One real coding pass gives both: entropy bits, and the escapes through the size.
+          const size_t cap = sjpeg_hip_frame_bound(W_, H_, mode, 0);
+          if (cap == 0 || !ctx.Ensure(&ctx.d_out, &ctx.out_cap, cap)) return false;
+          if (sjpeg_hip_encode_scan_src(ctx.engine, &dsrc, W_, H_, mode, 1, &tables, nullptr, 0, 0,
+                                        ctx.d_out, cap, ctx.d_size, nullptr) != 0) {
+            return FailHip("sjpeg_hip_encode_scan");
+          }
+          uint64_t bits = 0, bytes = 0;
+          if (sjpeg_hip_engine_entropy_bits(ctx.engine, &bits, 1) != 0) return FailHip("entropy_bits");
+          if (hipMemcpy(&bytes, ctx.d_size, sizeof(bytes), hipMemcpyDeviceToHost) != hipSuccess || bytes == 0) {
+            return Fail("size pass failed");
+          }
+          uint64_t escapes = bytes - (bits + 7) / 8;
+          if ((bits & 7) != 0 && bytes >= 2) {       // a padded last byte that became 0xFF is not counted
+            uint8_t tail[2];
+            if (hipMemcpy(tail, static_cast<const uint8_t*>(ctx.d_out) + bytes - 2, 2, hipMemcpyDeviceToHost) != hipSuccess) {
+              return Fail("size pass failed");
+            }
+            if (tail[0] == 0xff && tail[1] == 0x00) --escapes;
+          }
+          size += bits + 8 * escapes;
+        }
+        result = size / 8.f;
+      } else {
+        // ComputePSNR (src/dichotomy.cc:295-323)
+        uint64_t err = 0;
+        if (sjpeg_hip_scan_quant_error_src(ctx.engine, &dsrc, W_, H_, mode, 1, &tables,
+                                           reinterpret_cast<uint64_t*>(ctx.d_stats), nullptr) != 0) {
+          return FailHip("sjpeg_hip_scan_quant_error");
+        }
+        if (hipMemcpy(&err, ctx.d_stats, sizeof(err), hipMemcpyDeviceToHost) != hipSuccess) return Fail("error pass failed");
+        sjpeg_host::FrameLayout L;
+        sjpeg_host::LayoutFor(mode, &L);
+        const uint64_t nb_mbs = static_cast<uint64_t>((W_ + L.block_w - 1) / L.block_w) * ((H_ + L.block_h - 1) / L.block_h);
+        const uint64_t n = 64ull * nb_mbs * L.mcu_blocks;
+        result = (err > 0 && n > 0) ? 4.3429448f * log(n / (err / 255. / 255.)) : 99.f;
+      }
+      const bool last_is_best = (p == 0 || fabs(result - hook->target) < best);
+      if (last_is_best) {
+        memcpy(opt_quants, quant_, sizeof(opt_quants));
+        best = fabs(result - hook->target);
+        best_q = hook->q;
+        best_result = result;
+      }
+      if (hook->Update(result)) break;
+    }
+    // transfer back the best matrices; they are final (no further adaptation)
+    sjpeg_host::ScaleMatrix(opt_quants[0], 100.f, quant_[0]);
+    sjpeg_host::ScaleMatrix(opt_quants[1], 100.f, quant_[1]);
+    for (int c = 0; c < 2; ++c) sjpeg_host::FinalizeQuantizer(quant_[c], min_quant_[c], q_bias_, c, &tables);
+    hook->q = best_q;
+    hook->value = best_result;
+  } else if (adaptive) {
+    adapt();
   }
 
   // Huffman tables: Annex K defaults (src/enc.cc:399) or optimised for this picture
   const HuffSpec* dc[2] = {&sjpeg_host::DefaultHuff(0, 0), &sjpeg_host::DefaultHuff(0, 1)};
   const HuffSpec* ac[2] = {&sjpeg_host::DefaultHuff(1, 0), &sjpeg_host::DefaultHuff(1, 1)};
   HuffSpec opt[4];
-  const int ntables = (nb_comps == 1) ? 1 : 2;
   if (optimize) {
     // statistics half of SinglePassScanOptimized on the GPU (src/enc.cc:323-372),
     // CompileEntropyStats on the host (src/entropy.cc:432-444)
-    if (sjpeg_hip_scan_symbol_stats_src(ctx.engine, &dsrc, W_, H_, mode, 1, &tables,
-                                    static_cast<uint32_t*>(ctx.d_stats), nullptr) != 0) {
-      return FailHip("sjpeg_hip_scan_symbol_stats");
-    }
     uint32_t freq[2][272];
-    if (hipMemcpy(freq, ctx.d_stats, sizeof(freq), hipMemcpyDeviceToHost) != hipSuccess) {
-      return Fail(std::string("statistics pass failed: ") + hipGetErrorString(hipGetLastError()));
-    }
+    if (!symbol_stats(freq)) return false;
     for (int t = 0; t < ntables; ++t) {
       sjpeg_host::BuildOptimalSpec(freq[t] + 256, 12, &opt[t]);
       sjpeg_host::BuildOptimalSpec(freq[t], 256, &opt[2 + t]);

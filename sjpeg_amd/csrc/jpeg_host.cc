@@ -121,6 +121,7 @@ void FinalizeQuantizer(uint8_t quant[64], const uint8_t min_quant[64], int q_bia
     // neutral bias 0x80 (quantize.cc:128-139).  DC always uses 0x80.
     const uint32_t recip = (v == 1) ? 0xffffu : ((1u << 16) + v / 2) / v;
     const uint32_t bias8 = (v == 1 || i == 0) ? 0x80u : static_cast<uint32_t>(q_bias);
+    t->quant[idx][i] = static_cast<uint8_t>(v);
     t->iquant[idx][i] = static_cast<uint16_t>(recip);
     t->bias[idx][i] = static_cast<uint16_t>((((bias8 * v) << 4) + 128) >> 8);
   }

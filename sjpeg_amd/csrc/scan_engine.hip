@@ -67,7 +67,7 @@ template <> struct Geo<SJPEG_HIP_YUV400> {
 
 // device copy of sjpeg_hip_scan_tables, pre-digested
 struct DevTables {
-  uint4 q[2][32];          // per natural-order PAIR (2j, 2j+1): {iq0 | iq1<<16, bias0*iq0, bias1*iq1, 0}
+  uint4 q[2][32];          // per natural-order PAIR (2j, 2j+1): {iq0 | iq1<<16, bias0*iq0, bias1*iq1, q0 | q1<<16}
   uint32_t dc[2][12];
   uint32_t ac[2][256];
 };
@@ -444,7 +444,7 @@ __device__ __forceinline__ uint32_t wg_exclusive_scan(uint32_t x, uint32_t* scra
 // ------------------------------------------------------------------------------------
 // K1: colour + fDCT + quantize + entropy-code one segment
 
-enum { kKindEncode = 0, kKindTap = 1, kKindHisto = 2, kKindStats = 3 };
+enum { kKindEncode = 0, kKindTap = 1, kKindHisto = 2, kKindStats = 3, kKindError = 4 };
 constexpr int kHistoWords = 2 * 64 * 32;          // per-workgroup partial: u8 counters [2][64][128]
 constexpr int kStatsWords = 2 * 272;              // per-workgroup partial: u32 [2][256 AC + 16 DC]
 
@@ -489,18 +489,20 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
     constexpr int kRowsPerStrip = (MODE == SJPEG_HIP_YUV420) ? 2 : 1;
     constexpr int kStripsX = PX / 8;                           // strips per MCU row
     const int per_row = kStripsX * n_proc;
-    const int nstrips = 8 * per_row;
-    const int rnd_y = 0;
-    (void)rnd_y;
-    for (int s = tid; s < nstrips; s += kScanThreads) {
-      const int yp = s / per_row;
-      const int rem = s - yp * per_row;
-      const int ml = ml_lo + rem / kStripsX;
-      const int xs = rem % kStripsX;
-      const int mcu = m_first - 1 + ml;
-      const int mb_y = mcu / a.mb_w;
-      const int mb_x = mcu - mb_y * a.mb_w;
-      const int x0 = mb_x * PX + xs * 8;
+    // A thread keeps ONE strip column (one MCU, one x-half) and walks down its row pairs
+    // yp0, yp0 + ngroups, ...: the index arithmetic (two integer divisions by run-time
+    // values) is done once per thread instead of once per strip, and consecutive lanes still
+    // read consecutive 24-byte pieces of a picture row.
+    const int ngroups = kScanThreads / per_row;                 // 3 for a full 4:2:0 segment
+    const int yp0 = tid / per_row;
+    const int rem = tid - yp0 * per_row;
+    const int ml = ml_lo + rem / kStripsX;
+    const int xs = rem % kStripsX;
+    const int mcu = m_first - 1 + ml;
+    const int mb_y = mcu / a.mb_w;
+    const int mb_x = mcu - mb_y * a.mb_w;
+    const int x0 = mb_x * PX + xs * 8;
+    for (int yp = yp0; yp < 8 && yp0 < ngroups; yp += ngroups) {
       const int y0 = mb_y * PX + yp * kRowsPerStrip;
       const bool inside = (x0 + 8 <= a.W) && (y0 + kRowsPerStrip <= a.H);
       if (SRC == kSrcPlanes) {
@@ -652,6 +654,46 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
     fdct_col8_pk(p[0][c], p[1][c], p[2][c], p[3][c], p[4][c], p[5][c], p[6][c], p[7][c]);
+  }
+  if (KIND == kKindError) {
+    // Quantization error of the picture (reference QuantizeError, src/quantize.cc:553-565):
+    // sum of ((|c| >> 4) - quant * level)^2, per block in 32-bit wrap-around, 64 bits overall.
+    const uint4* qt = lq + tbl * 32;
+    uint32_t err = 0;
+    int acc[8];
+    auto add_row = [&](int row, const int* ac8) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int c = ac8[i] >> 16;
+        const uint32_t mag = static_cast<uint32_t>(c < 0 ? -c : c);
+        const uint4 t = qt[row * 4 + (i >> 1)];
+        const uint32_t iq = (i & 1) ? (t.x >> 16) : (t.x & 0xffffu);
+        const uint32_t biq = (i & 1) ? t.z : t.y;
+        const uint32_t qv = (i & 1) ? (t.w >> 16) : (t.w & 0xffffu);
+        const uint32_t v = qv * ((mag * iq + biq) >> 20);
+        const uint32_t d = (mag >> 4) - v;
+        err += d * d;
+      }
+    };
+    fdct_row8_pk<22725, 21407, 19266, 16384, 12873, 8867, 4520>(p[0], acc); add_row(0, acc);
+    fdct_row8_pk<31521, 29692, 26722, 22725, 17855, 12299, 6270>(p[1], acc); add_row(1, acc);
+    fdct_row8_pk<29692, 27969, 25172, 21407, 16819, 11585, 5906>(p[2], acc); add_row(2, acc);
+    fdct_row8_pk<26722, 25172, 22654, 19266, 15137, 10426, 5315>(p[3], acc); add_row(3, acc);
+    fdct_row8_pk<22725, 21407, 19266, 16384, 12873, 8867, 4520>(p[4], acc); add_row(4, acc);
+    fdct_row8_pk<26722, 25172, 22654, 19266, 15137, 10426, 5315>(p[5], acc); add_row(5, acc);
+    fdct_row8_pk<29692, 27969, 25172, 21407, 16819, 11585, 5906>(p[6], acc); add_row(6, acc);
+    fdct_row8_pk<31521, 29692, 26722, 22725, 17855, 12299, 6270>(p[7], acc); add_row(7, acc);
+    unsigned long long e64 = emits ? err : 0u;
+    for (int d = 32; d > 0; d >>= 1) e64 += __shfl_xor(e64, d, 64);
+    unsigned long long* const we = reinterpret_cast<unsigned long long*>(misc);
+    if ((tid & 63) == 0) we[tid >> 6] = e64;
+    __syncthreads();
+    if (tid == 0) {
+      unsigned long long sum = 0;
+      for (int w = 0; w < kScanThreads / 64; ++w) sum += we[w];
+      reinterpret_cast<unsigned long long*>(a.partial)[static_cast<size_t>(frame) * a.nseg + seg] = sum;
+    }
+    return;
   }
   if (KIND == kKindHisto) {
     // Adaptive-quantization statistics (reference StoreHisto, src/histogram.cc:56-108): for every
@@ -994,6 +1036,18 @@ __global__ __launch_bounds__(kThreads) void reduce_partials(const uint32_t* part
   }
 }
 
+__global__ __launch_bounds__(kThreads) void reduce_error(const unsigned long long* part, int nseg,
+                                                        unsigned long long* out) {
+  __shared__ unsigned long long red[kThreads / 64];
+  const int frame = blockIdx.x;
+  unsigned long long sum = 0;
+  for (int s = threadIdx.x; s < nseg; s += kThreads) sum += part[static_cast<size_t>(frame) * nseg + s];
+  for (int d = 32; d > 0; d >>= 1) sum += __shfl_xor(sum, d, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sum;
+  __syncthreads();
+  if (threadIdx.x == 0) out[frame] = red[0] + red[1] + red[2] + red[3];
+}
+
 // ------------------------------------------------------------------------------------
 // K2: per frame, exclusive scan of segment bit lengths
 
@@ -1299,6 +1353,7 @@ struct sjpeg_hip_engine {
   DevBuf<uint32_t> seg_words, seg_nbits, ubuf, chunk_ff, partial;
   DevBuf<unsigned long long> seg_off, chunk_off, stamps;
   bool want_stamps = false;
+  int last_nseg = 0, last_nframes = 0;   // geometry of the last encode call (entropy_bits)
   size_t stamps_n = 0;
   bool timing = false;
   int ablate = 0;
@@ -1313,7 +1368,8 @@ void digest_tables(const sjpeg_hip_scan_tables* t, DevTables* d) {
     for (int j = 0; j < 64; ++j) {
       uint4& e = d->q[c][j >> 1];
       const uint32_t iq = t->iquant[c][j], biq = static_cast<uint32_t>(t->bias[c][j]) * iq;
-      if ((j & 1) == 0) { e.x = iq; e.y = biq; e.w = 0; } else { e.x |= iq << 16; e.z = biq; }
+      const uint32_t qv = t->quant[c][j];
+      if ((j & 1) == 0) { e.x = iq; e.y = biq; e.w = qv; } else { e.x |= iq << 16; e.z = biq; e.w |= qv << 16; }
     }
   }
   memcpy(d->dc, t->dc_codes, sizeof(d->dc));
@@ -1567,6 +1623,38 @@ static int scan_statistics(sjpeg_hip_engine* e, const sjpeg_hip_source* src, int
   return 0;
 }
 
+int sjpeg_hip_scan_quant_error_src(sjpeg_hip_engine* e, const sjpeg_hip_source* src, int width,
+                                   int height, int yuv_mode, int nframes,
+                                   const sjpeg_hip_scan_tables* tables, uint64_t* d_err, void* stream) {
+  if (d_err == nullptr || tables == nullptr) return fail(SJPEG_HIP_EINVAL, "null argument");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  FrameGeo g;
+  ScanArgs a;
+  int cls = 0;
+  int rc = prepare_scan(e, src, width, height, yuv_mode, nframes, tables, st, &g, &a, &cls);
+  if (rc) return rc;
+  if ((rc = e->partial.ensure(static_cast<size_t>(nframes) * g.nseg * 2))) return rc;
+  a.partial = e->partial.p;
+  if ((rc = launch_scan<kKindError>(yuv_mode, cls, dim3(g.nseg, nframes), st, a))) return rc;
+  hipLaunchKernelGGL(reduce_error, dim3(nframes), dim3(kThreads), 0, st,
+                     reinterpret_cast<const unsigned long long*>(e->partial.p), g.nseg,
+                     reinterpret_cast<unsigned long long*>(d_err));
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int sjpeg_hip_engine_entropy_bits(sjpeg_hip_engine* e, uint64_t* bits, int nframes) {
+  if (e == nullptr || bits == nullptr || nframes <= 0) return fail(SJPEG_HIP_EINVAL, "null argument");
+  if (e->last_nseg <= 0 || nframes > e->last_nframes) return fail(SJPEG_HIP_EINVAL, "no matching encode call");
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipDeviceSynchronize());
+  for (int f = 0; f < nframes; ++f) {
+    HIP_TRY(hipMemcpy(&bits[f], e->seg_off.p + static_cast<size_t>(f) * (e->last_nseg + 1) + e->last_nseg,
+                      sizeof(uint64_t), hipMemcpyDeviceToHost));
+  }
+  return 0;
+}
+
 int sjpeg_hip_scan_histogram_src(sjpeg_hip_engine* e, const sjpeg_hip_source* src, int width, int height,
                                  int yuv_mode, int nframes, uint32_t* d_hist, void* stream) {
   return scan_statistics(e, src, width, height, yuv_mode, nframes, nullptr, true, d_hist, stream);
@@ -1630,6 +1718,7 @@ int sjpeg_hip_encode_scan_src(sjpeg_hip_engine* e, const sjpeg_hip_source* src, 
     HIP_TRY(hipMemcpyAsync(e->header.p, header, header_size, hipMemcpyHostToDevice, st));
   }
 
+  e->last_nseg = g.nseg; e->last_nframes = nframes;
   StitchArgs s;
   s.nseg = g.nseg; s.nframes = nframes;
   s.seg_nbits = e->seg_nbits.p; s.seg_off = e->seg_off.p;

@@ -124,6 +124,55 @@ int main(int argc, char** argv) {
     CHECK(!sjpeg::Encode(rgb.data(), W, H, 3 * W, param, &out));
   }
 
+  // ---- multi-pass size / PSNR search (reference: src/dichotomy.cc; unit_test.cc TargetSize idea)
+  {
+    int idx = 0;
+    const float size_targets[3] = {1500.f, 4000.f, 9000.f}, psnr_targets[3] = {30.f, 38.f, 45.f};
+    for (int m = 0; m < 3; ++m) for (int huff = 0; huff < 2; ++huff) for (int adapt = 0; adapt < 2; ++adapt)
+      for (int tm = 1; tm <= 2; ++tm) for (int t = 0; t < 3; ++t) for (int passes = 2; passes <= 6; passes += 4) {
+        sjpeg::EncoderParam param(60.f);
+        param.yuv_mode = modes[m];
+        param.Huffman_compress = (huff != 0);
+        param.adaptive_quantization = (adapt != 0);
+        param.target_mode = static_cast<sjpeg::EncoderParam::TargetMode>(tm);
+        param.target_value = (tm == 1) ? size_targets[t] : psnr_targets[t];
+        param.passes = passes;
+        param.tolerance = (tm == 1) ? 1.f : 0.1f;
+        std::string out;
+        CHECK(sjpeg::Encode(rgb.data(), W, H, 3 * W, param, &out));
+        char name[32];
+        snprintf(name, sizeof(name), "search_%03d", idx++);
+        Save(dir, name, out);
+      }
+    // a 10-pass size search lands close to the request, and closer than a single pass at the seed
+    sjpeg::EncoderParam param(60.f);
+    param.yuv_mode = SJPEG_YUV_420;
+    param.target_mode = sjpeg::EncoderParam::TARGET_SIZE;
+    param.target_value = 5000.f;
+    param.passes = 10;
+    param.tolerance = 1.f;
+    std::string hit;
+    CHECK(sjpeg::Encode(rgb.data(), W, H, 3 * W, param, &hit));
+    CHECK(hit.size() > 4500 && hit.size() < 5500);
+    // user hook: called once per pass for both matrices, q/value reported back, Setup() veto is fatal
+    struct CountingHook : public sjpeg::SearchHook {
+      int setups = 0, matrices = 0, updates = 0;
+      bool veto = false;
+      bool Setup(const sjpeg::EncoderParam& p) override { ++setups; return !veto && sjpeg::SearchHook::Setup(p); }
+      void NextMatrix(int i, uint8_t dst[64]) override { ++matrices; sjpeg::SearchHook::NextMatrix(i, dst); }
+      bool Update(float r) override { ++updates; return sjpeg::SearchHook::Update(r); }
+    } hook;
+    param.search_hook = &hook;
+    param.passes = 4;
+    std::string hooked;
+    CHECK(sjpeg::Encode(rgb.data(), W, H, 3 * W, param, &hooked));
+    CHECK(hook.setups == 1 && hook.updates >= 1 && hook.updates <= 4 && hook.matrices == 2 * hook.updates);
+    CHECK(hook.value > 0.f && hook.q >= 0.f && hook.q <= 100.f && hook.for_size);
+    Save(dir, "search_hooked", hooked);
+    hook.veto = true;
+    CHECK(!sjpeg::Encode(rgb.data(), W, H, 3 * W, param, &hooked));
+  }
+
   // ---- the other input layouts of the API (reference: src/sjpeg.h:300-349)
   {
     const int w = 37, h = 23, cw = (w + 1) / 2, ch = (h + 1) / 2;

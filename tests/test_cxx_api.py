@@ -78,3 +78,21 @@ def test_cxx_api_behaviour_and_parity(tmp_path, oracle):
     extra = meta[20:len(meta) - (len(plain) - 20)]
     assert extra.startswith(b"\xff\xe5\x00\x04zz" + b"\xff\xe1") and b"\xff\xe1\x00\x1cExif\x00\x00II*\x00fake-exif-payloa\xff\xe2\xff\xffICC_PROFILE\x00\x01\x02" in extra
     assert extra.count(b"ICC_PROFILE\x00") == 2 and b"http://ns.adobe.com/xap/1.0/\x00<x:xmpmeta/>" in extra
+    # multi-pass searches: same nested loops as api_test.cc
+    q60 = sj.make_tables(quality=60.0)[1]
+    idx = 0
+    for name, mode in modes.items():
+        for huff in (False, True):
+            for adapt in (False, True):
+                for tm in (1, 2):
+                    for t in range(3):
+                        for passes in (2, 6):
+                            target = (1500.0, 4000.0, 9000.0)[t] if tm == 1 else (30.0, 38.0, 45.0)[t]
+                            want = oracle.encode_search(orc.SRC_RGB, [img], 141, 99, q60, yuv_mode=mode,
+                                                        huffman=huff, adaptive=adapt, target_mode=tm,
+                                                        target_value=target, passes=passes,
+                                                        tolerance=1.0 if tm == 1 else 0.1)
+                            assert read("search_%03d" % idx) == want, (idx, name, huff, adapt, tm, target, passes)
+                            idx += 1
+    assert read("search_hooked") == oracle.encode_search(orc.SRC_RGB, [img], 141, 99, q60, yuv_mode=1,
+                                                         target_mode=1, target_value=5000.0, passes=4)

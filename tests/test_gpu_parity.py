@@ -271,6 +271,37 @@ def test_source_layouts_vs_oracle(engine, oracle, fmt):
                 assert got == want, (fmt, w, h, mode, q, method)
 
 
+@pytest.mark.parametrize("fmt", [0, 1, 3, 4, 5, 6])
+def test_search_pass_measurements_vs_oracle(engine, oracle, fmt):
+    """What one pass of the size / PSNR search measures on the device: the squared quantization
+    error (reference src/dichotomy.cc:309-323) and the BitCounter's bit count with the standard
+    tables (src/bit_writer.h:292-365) rebuilt from the coded size + the entropy-bit total."""
+    rng = np.random.RandomState(300 + fmt)
+    for (w, h) in ((1, 1), (17, 13), (97, 61), (640, 360)):
+        if fmt == 0:
+            planes = [rng.randint(0, 256, (h, 3 * w)).astype(np.uint8)]
+        else:
+            planes = _random_planes(rng, fmt, w, h)
+        if w >= 97:
+            planes = [(p // 4 + np.arange(p.shape[1])[None, :] // 3).astype(np.uint8) for p in planes]
+        dev_planes = [torch.from_numpy(p).cuda().unsqueeze(0) for p in planes]
+        src, n = sj.make_source(fmt, dev_planes)
+        modes = (1, 3, 4) if fmt in (0, 1) else ({3: 4, 4: 3}.get(fmt, 1),)
+        for mode in modes:
+            for q in (8.0, 60.0, 97.0):
+                tables, quant = sj.make_tables(quality=q)
+                err = engine.scan_quant_error_source(src, n, w, h, tables, mode)
+                assert int(err[0].item()) == oracle.quant_error(fmt, planes, w, h, quant, yuv_mode=mode), (fmt, w, h, mode, q)
+                out, sizes = engine.encode_source(src, n, w, h, tables, b"", mode)
+                bits = int(engine.entropy_bits(1)[0])
+                coded = bytes(out[0, :int(sizes[0].item())].cpu().numpy())
+                body = coded[:-2]                                        # drop EOI
+                escapes = len(body) - (bits + 7) // 8
+                if bits % 8 != 0 and body[-2:] == b"\xff\x00":
+                    escapes -= 1
+                assert bits + 8 * escapes == oracle.counted_bits(fmt, planes, w, h, quant, yuv_mode=mode), (fmt, w, h, mode, q)
+
+
 def test_source_argument_errors(engine):
     y = torch.zeros((1, 16, 16), dtype=torch.uint8, device="cuda")
     t, quant = sj.make_tables(quality=75)
