@@ -266,6 +266,24 @@ __device__ __forceinline__ uint32_t mad_u16_hi(uint32_t a, uint32_t b, uint32_t 
   asm("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[1,1,0,0]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
   return d;
 }
+// D = a.u16[1] * b.u16[0] + c
+__device__ __forceinline__ uint32_t mad_u16_hl(uint32_t a, uint32_t b, uint32_t c) {
+  uint32_t d;
+  asm("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+// a.u16[0] * b.u16[0] + a.u16[1] * b.u16[1] + c, modulo 2^32
+__device__ __forceinline__ uint32_t udot2(uint32_t a, uint32_t b, uint32_t c) {
+  return __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b), c, false);
+}
+__device__ __forceinline__ uint32_t sdot2u(uint32_t a, int klo, int khi, uint32_t c) {
+  return static_cast<uint32_t>(__builtin_amdgcn_sdot2(as_pk(a), pk_const(klo, khi), static_cast<int>(c), false));
+}
+// (x1 >> 16) << 16 | (x0 >> 16) & 0xffff: the upper halves of two 32-bit sums as an int16 pair
+__device__ __forceinline__ uint32_t pk_top(uint32_t x0, uint32_t x1) {
+  return __builtin_amdgcn_perm(x1, x0, 0x07060302u);
+}
 
 // natural index -> zig-zag position
 __device__ constexpr int kInvZig(int j) {
@@ -323,17 +341,6 @@ __device__ __forceinline__ uint32_t pack16(int lo, int hi) {
   return (static_cast<uint32_t>(lo) & 0xffffu) | (static_cast<uint32_t>(hi) << 16);
 }
 
-// BT.601 full-range 16.16 fixed point (src/colors_rgb.cc:17-19,31-32)
-__device__ __forceinline__ int luma16(int r, int g, int b) {
-  return (mul24(19595, r) + mul24(38469, g) + mul24(7471, b) + (32768 - (128 << 16))) >> 16;
-}
-__device__ __forceinline__ int cb16(int r, int g, int b, int rnd, int sh) {
-  return (mul24(-11059, r) - mul24(21709, g) + mul24(32768, b) + rnd) >> sh;
-}
-__device__ __forceinline__ int cr16(int r, int g, int b, int rnd, int sh) {
-  return (mul24(32768, r) - mul24(27439, g) - mul24(5329, b) + rnd) >> sh;
-}
-
 __device__ __forceinline__ int byte_of(const uint32_t* w, int i) {
   return static_cast<int>((w[i >> 2] >> (8 * (i & 3))) & 0xffu);
 }
@@ -362,18 +369,15 @@ __device__ __forceinline__ void load_row8(const uint8_t* frame, long long row_st
   }
 }
 
-// R, G, B of 8 consecutive pixels of row y (coordinates clamp to the picture)
+// Raw dwords of 8 consecutive pixels of row y (coordinates clamp to the picture): 6 dwords for
+// packed RGB, 8 for the 4-byte layouts.
 template <int SRC>
-__device__ __forceinline__ void fetch_rgb8(const ScanArgs& a, const uint8_t* frame_px, int x0, int y,
-                                           bool inside, int* r, int* g, int* b) {
+__device__ __forceinline__ void load_px8(const ScanArgs& a, const uint8_t* frame_px, int x0, int y,
+                                         bool inside, uint32_t* w) {
   if (SRC == kSrcRgb24) {
-    uint32_t w[6];
     load_row8(frame_px, a.row_stride[0], a.W, a.H, x0, y, inside, w);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) { r[i] = byte_of(w, 3 * i); g[i] = byte_of(w, 3 * i + 1); b[i] = byte_of(w, 3 * i + 2); }
   } else {
     // 4 bytes per pixel (BGRA / RGBA, alpha ignored: src/colors_rgb.cc:882-1025)
-    uint32_t w[8];
     if (inside) {
       __builtin_memcpy(w, frame_px + y * a.row_stride[0] + 4ll * x0, 32);
     } else {
@@ -385,13 +389,55 @@ __device__ __forceinline__ void fetch_rgb8(const ScanArgs& a, const uint8_t* fra
         __builtin_memcpy(&w[i], row + 4ll * xx, 4);
       }
     }
+  }
+}
+
+// The same 8 pixels as packed 16-bit operands: rg[i] = r_i | g_i << 16 (i = 0..7),
+// bb[j] = b_2j | b_(2j+1) << 16 (j = 0..3).  One byte-permute per register.
+template <int SRC>
+__device__ __forceinline__ void unpack_px8(const ScanArgs& a, const uint32_t* w, uint32_t* rg, uint32_t* bb) {
+  if (SRC == kSrcRgb24) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      r[i] = static_cast<int>((w[i] >> a.rsh) & 0xffu);
-      g[i] = static_cast<int>((w[i] >> 8) & 0xffu);
-      b[i] = static_cast<int>((w[i] >> a.bsh) & 0xffu);
+      const int o = 3 * i, d = o >> 2, sl = o & 3;                  // r at byte o, g at o + 1
+      const uint32_t sel = sl | 0x0c00u | (static_cast<uint32_t>(sl + 1) << 16) | 0x0c000000u;
+      rg[i] = __builtin_amdgcn_perm(w[d + 1 < 6 ? d + 1 : 5], w[d], sel);
     }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int o = 6 * j + 2, d = o >> 2, sl = o & 3;              // b at bytes o and o + 3
+      const uint32_t sel = sl | 0x0c00u | (static_cast<uint32_t>(sl + 3) << 16) | 0x0c000000u;
+      bb[j] = __builtin_amdgcn_perm(w[d + 1 < 6 ? d + 1 : 5], w[d], sel);
+    }
+  } else {
+    const uint32_t rs = static_cast<uint32_t>(a.rsh) >> 3, bs = static_cast<uint32_t>(a.bsh) >> 3;
+    const uint32_t sel_rg = rs | 0x0c00u | 0x00010000u | 0x0c000000u;
+    const uint32_t sel_bb = bs | 0x0c00u | ((4u + bs) << 16) | 0x0c000000u;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) rg[i] = __builtin_amdgcn_perm(0u, w[i], sel_rg);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bb[j] = __builtin_amdgcn_perm(w[2 * j + 1], w[2 * j], sel_bb);
   }
+}
+
+// BT.601 full-range 16.16 fixed point (src/colors_rgb.cc:17-19,31-32,785-828) on packed operands.
+// All sums are the reference's, modulo 2^32; the int16 results are read off the upper halves.
+constexpr uint32_t kLumaRG = 19595u | (38469u << 16);
+constexpr uint32_t kLumaRound = static_cast<uint32_t>(32768 - (128 << 16));
+// luma of pixels 2j and 2j + 1 as an int16 pair
+__device__ __forceinline__ uint32_t luma_pair(uint32_t rg0, uint32_t rg1, uint32_t bbj, uint32_t k7471,
+                                              uint32_t rnd) {
+  const uint32_t y0 = udot2(rg0, kLumaRG, mad_u16_lo(bbj, k7471, rnd));
+  const uint32_t y1 = udot2(rg1, kLumaRG, mad_u16_hl(bbj, k7471, rnd));
+  return pk_top(y0, y1);
+}
+// 32-bit Cb / Cr sums (before the final shift) of one (R | G << 16, B) triple; rnd = rounding term
+__device__ __forceinline__ uint32_t cb_sum(uint32_t RG, uint32_t B, uint32_t rnd) {
+  return sdot2u(RG, -11059, -21709, (B << 15) + rnd);
+}
+__device__ __forceinline__ uint32_t cr_sum(uint32_t RG, uint32_t B, uint32_t k32768, uint32_t rnd) {
+  const uint32_t GB = __builtin_amdgcn_perm(B, RG, 0x05040302u);     // G | B << 16
+  return sdot2u(GB, -27439, -5329, mad_u16_lo(RG, k32768, rnd));
 }
 
 // 8 level-shifted samples of an 8-bit plane (sample pitch `step` bytes), clamped coordinates:
@@ -502,9 +548,29 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
     const int mb_y = mcu / a.mb_w;
     const int mb_x = mcu - mb_y * a.mb_w;
     const int x0 = mb_x * PX + xs * 8;
-    for (int yp = yp0; yp < 8 && yp0 < ngroups; yp += ngroups) {
+    const uint32_t k7471 = 7471u, k32768 = 32768u;             // multiplier operands (low halves)
+    constexpr int kNW = (SRC == kSrcRgb24) ? 6 : 8;             // dwords per 8 pixels
+    constexpr int kBatch = 3;                                   // row pairs in flight per thread
+    for (int ypb = yp0; ypb < 8 && yp0 < ngroups; ypb += kBatch * ngroups) {
+    // all global loads of the batch are issued before the first one is consumed
+    uint32_t raw[kBatch][kRowsPerStrip][kNW];
+    if (SRC != kSrcPlanes) {
+#pragma unroll
+      for (int it = 0; it < kBatch; ++it) {
+        const int yp = ypb + it * ngroups;
+        if (yp < 8) {
+          const int y0 = mb_y * PX + yp * kRowsPerStrip;
+          const bool inside = (x0 + 8 <= a.W) && (y0 + kRowsPerStrip <= a.H);
+#pragma unroll
+          for (int r = 0; r < kRowsPerStrip; ++r) load_px8<SRC>(a, frame_px, x0, y0 + r, inside, raw[it][r]);
+        }
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < kBatch; ++it) {
+      const int yp = ypb + it * ngroups;
+      if (yp >= 8) break;
       const int y0 = mb_y * PX + yp * kRowsPerStrip;
-      const bool inside = (x0 + 8 <= a.W) && (y0 + kRowsPerStrip <= a.H);
       if (SRC == kSrcPlanes) {
         // 8-bit planes are used as they are, minus 128 (src/encoders.cc:256-490)
         int ya[8];
@@ -543,56 +609,56 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
         }
         continue;
       }
-      int r0[8], g0[8], b0[8];
-      fetch_rgb8<SRC>(a, frame_px, x0, y0, inside, r0, g0, b0);
+      uint32_t rg0[8], bb0[4];
+      unpack_px8<SRC>(a, raw[it][0], rg0, bb0);
       if (MODE == SJPEG_HIP_YUV420) {
-        int r1[8], g1[8], b1[8];
-        fetch_rgb8<SRC>(a, frame_px, x0, y0 + 1, inside, r1, g1, b1);
-        int ya[8], yb[8];
-        int U[4], V[4];
+        uint32_t rg1[8], bb1[4];
+        unpack_px8<SRC>(a, raw[it][kRowsPerStrip - 1], rg1, bb1);
+        uint32_t ya[4], yb[4], us32[4], vs32[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-          int R = 0, Gs = 0, B = 0;
-#pragma unroll
-          for (int e = 0; e < 2; ++e) {
-            const int i = 2 * c + e;
-            ya[i] = luma16(r0[i], g0[i], b0[i]);
-            yb[i] = luma16(r1[i], g1[i], b1[i]);
-            R += r0[i] + r1[i]; Gs += g0[i] + g1[i]; B += b0[i] + b1[i];
-          }
-          U[c] = cb16(R, Gs, B, 32768 << 2, 18);
-          V[c] = cr16(R, Gs, B, 32768 << 2, 18);
+          ya[c] = luma_pair(rg0[2 * c], rg0[2 * c + 1], bb0[c], k7471, kLumaRound);
+          yb[c] = luma_pair(rg1[2 * c], rg1[2 * c + 1], bb1[c], k7471, kLumaRound);
+          // 2x2 sums: halves stay below 1021, plain 32-bit adds never carry across
+          const uint32_t RG = (rg0[2 * c] + rg0[2 * c + 1]) + (rg1[2 * c] + rg1[2 * c + 1]);
+          const uint32_t BB = bb0[c] + bb1[c];
+          const uint32_t B = (BB & 0xffffu) + (BB >> 16);
+          us32[c] = cb_sum(RG, B, 32768u << 2);
+          vs32[c] = cr_sum(RG, B, k32768, 32768u << 2);
         }
+        // (sum >> 16) >> 2 == sum >> 18 (floor of floor)
+        const s16x2 two = pk_const(2, 2);
+        const uint32_t u01 = as_u32(as_pk(pk_top(us32[0], us32[1])) >> two);
+        const uint32_t u23 = as_u32(as_pk(pk_top(us32[2], us32[3])) >> two);
+        const uint32_t v01 = as_u32(as_pk(pk_top(vs32[0], vs32[1])) >> two);
+        const uint32_t v23 = as_u32(as_pk(pk_top(vs32[2], vs32[3])) >> two);
         const int k = (yp >> 2) * 2 + xs;
         const int row = (yp & 3) * 2;
         unsigned char* ys = smem + (ml * BPM + k) * kSlotBytes + row * 16;
-        *reinterpret_cast<uint4*>(ys) =
-            make_uint4(pack16(ya[0], ya[1]), pack16(ya[2], ya[3]), pack16(ya[4], ya[5]), pack16(ya[6], ya[7]));
-        *reinterpret_cast<uint4*>(ys + 16) =
-            make_uint4(pack16(yb[0], yb[1]), pack16(yb[2], yb[3]), pack16(yb[4], yb[5]), pack16(yb[6], yb[7]));
+        *reinterpret_cast<uint4*>(ys) = make_uint4(ya[0], ya[1], ya[2], ya[3]);
+        *reinterpret_cast<uint4*>(ys + 16) = make_uint4(yb[0], yb[1], yb[2], yb[3]);
         unsigned char* us = smem + (ml * BPM + 4) * kSlotBytes + yp * 16 + xs * 8;
-        *reinterpret_cast<uint2*>(us) = make_uint2(pack16(U[0], U[1]), pack16(U[2], U[3]));
-        *reinterpret_cast<uint2*>(us + kSlotBytes) = make_uint2(pack16(V[0], V[1]), pack16(V[2], V[3]));
+        *reinterpret_cast<uint2*>(us) = make_uint2(u01, u23);
+        *reinterpret_cast<uint2*>(us + kSlotBytes) = make_uint2(v01, v23);
       } else {
-        int yv[8], uv[8], vv[8];
+        uint32_t yv[4], uv[4], vv[4];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          yv[i] = luma16(r0[i], g0[i], b0[i]);
+        for (int c = 0; c < 4; ++c) {
+          yv[c] = luma_pair(rg0[2 * c], rg0[2 * c + 1], bb0[c], k7471, kLumaRound);
           if (MODE == SJPEG_HIP_YUV444) {
-            uv[i] = cb16(r0[i], g0[i], b0[i], 32768, 16);
-            vv[i] = cr16(r0[i], g0[i], b0[i], 32768, 16);
+            const uint32_t b0 = bb0[c] & 0xffffu, b1 = bb0[c] >> 16;
+            uv[c] = pk_top(cb_sum(rg0[2 * c], b0, 32768u), cb_sum(rg0[2 * c + 1], b1, 32768u));
+            vv[c] = pk_top(cr_sum(rg0[2 * c], b0, k32768, 32768u), cr_sum(rg0[2 * c + 1], b1, k32768, 32768u));
           }
         }
         unsigned char* ys = smem + (ml * BPM) * kSlotBytes + yp * 16;
-        *reinterpret_cast<uint4*>(ys) =
-            make_uint4(pack16(yv[0], yv[1]), pack16(yv[2], yv[3]), pack16(yv[4], yv[5]), pack16(yv[6], yv[7]));
+        *reinterpret_cast<uint4*>(ys) = make_uint4(yv[0], yv[1], yv[2], yv[3]);
         if (MODE == SJPEG_HIP_YUV444) {
-          *reinterpret_cast<uint4*>(ys + kSlotBytes) =
-              make_uint4(pack16(uv[0], uv[1]), pack16(uv[2], uv[3]), pack16(uv[4], uv[5]), pack16(uv[6], uv[7]));
-          *reinterpret_cast<uint4*>(ys + 2 * kSlotBytes) =
-              make_uint4(pack16(vv[0], vv[1]), pack16(vv[2], vv[3]), pack16(vv[4], vv[5]), pack16(vv[6], vv[7]));
+          *reinterpret_cast<uint4*>(ys + kSlotBytes) = make_uint4(uv[0], uv[1], uv[2], uv[3]);
+          *reinterpret_cast<uint4*>(ys + 2 * kSlotBytes) = make_uint4(vv[0], vv[1], vv[2], vv[3]);
         }
       }
+    }
     }
   }
   __syncthreads();
