@@ -50,6 +50,7 @@ constexpr int kThreads = 256;        // stitch kernels (K2..K5): 4 waves
 constexpr int kScanThreads = 256;    // K1: 4 waves = 41 coded MCUs + 1 halo MCU in 4:2:0
 constexpr int kSlotBytes = 144;      // 64 int16 + 16 B pad: conflict-free ds_read_b128 per lane
 constexpr int kWinWords = 2048;       // LDS bit window, 32-bit MSB-first words (8 KiB)
+constexpr int kSpillWords = 54;      // kMaxBlockBits / 32
 constexpr int kMaxBlockBits = 1728;  // 22 (DC) + 63*27 (AC) rounded up; reference bound enc.cc:206-209
 constexpr int kChunkWords = 1024;    // K3/K5 chunk: 4 KiB of un-stuffed stream
 constexpr int kChunkBytes = kChunkWords * 4;
@@ -85,6 +86,7 @@ struct ScanArgs {
   uint32_t* seg_words;     // [nframes*nseg][slot_words]
   uint32_t slot_words;
   uint32_t* seg_nbits;     // [nframes*nseg]
+  uint32_t* spill;         // [nframes*nseg][kScanThreads][kSpillWords]: words that cannot stay in place
   int16_t* coeffs;         // kKindTap: quantized coefficients
   uint32_t* partial;       // kKindHisto / kKindStats: per-workgroup partial statistics
   unsigned long long* stamps;  // profiling (env SJPEG_HIP_STAMPS): 8 cycle stamps per workgroup
@@ -939,46 +941,86 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
   const int b_tbl = (MODE == SJPEG_HIP_YUV420) ? (b_k >= 4) : (MODE == SJPEG_HIP_YUV444 ? (b_k >= 1) : 0);
   const uint32_t* const ac = lac + b_tbl * 256;
   const uint32_t dc_bits = b_dc & 0xffffffu, dc_len = b_dc >> 24;
-  const uint16_t* const zz = reinterpret_cast<const uint16_t*>(bslot);   // bit 15 = negative, 14..0 = level
+  // the walk reads 16-bit entries and writes 32-bit words in the same slot: no type-based reordering
+  typedef uint16_t __attribute__((may_alias)) u16_alias;
+  typedef uint32_t __attribute__((may_alias)) u32_alias;
+  const u16_alias* const zz = reinterpret_cast<const u16_alias*>(bslot);   // bit 15 = negative, 14..0 = level
   const uint32_t zrl = ac[0xf0], eob = ac[0x00];
   const uint32_t zl = zrl & 0xffu;
   const unsigned long long nzm = b_emits ? ((static_cast<unsigned long long>(btail[1]) << 32) | btail[0]) : 0ull;
 
-  // Both passes are software-pipelined by hand: the entry of the NEXT non-zero position and
-  // the Huffman word of the CURRENT one are in flight while the previous symbol is consumed,
-  // so no LDS round trip sits on the loop-carried dependency chain.
-  // pass 1: bit length of the block
+  // ONE walk codes the block (src/entropy.cc:161-198).  The bits go, MSB-first, into the block's
+  // OWN slot, over coefficients that were already consumed: word w replaces entries 2w and
+  // 2w + 1, and is only written once every entry up to 2w + 1 has been loaded (a block produces
+  // far fewer than 16 bits per zig-zag position).  The rare word that would overtake the reader
+  // goes to a global spill row instead, and so does everything after it.  The walk is
+  // software-pipelined by hand: the entry of the NEXT non-zero position and the Huffman word of
+  // the CURRENT one are in flight while the previous symbol is appended; unrolled by two with
+  // swapped roles so that an in-flight LDS value is never copied (a copy forces a wait).
+  constexpr int kEnd = 69;                         // "no more non-zeros": reads as a loaded frontier
+  u32_alias* const bw = reinterpret_cast<u32_alias*>(bslot);
+  uint32_t* const spill = a.spill + ((static_cast<size_t>(frame) * a.nseg + seg) * kScanThreads + tid) * kSpillWords;
+  unsigned long long acc = 0;                      // pending bits, right-aligned (upper bits stale)
+  uint32_t nacc = 0, wr = 0;                       // pending bit count (< 32), words produced
+  uint32_t wr_spill = 0xffffu;                     // first word that went to the spill row
   uint32_t len = 0;
-  {
+  if (b_emits) {
     unsigned long long m = nzm;
-    auto next_pos = [&]() -> int { if (!m) return 0; const int i = __builtin_ctzll(m); m &= m - 1; return i; };
+    auto next_pos = [&]() -> int { if (!m) return kEnd; const int i = __builtin_ctzll(m); m &= m - 1; return i; };
+    auto append = [&](uint32_t bits, uint32_t nb, int frontier) {   // 1 <= nb <= 27
+      acc = (acc << nb) | bits;
+      nacc += nb;
+      if (nacc >= 32u) {
+        nacc -= 32u;
+        const uint32_t word = static_cast<uint32_t>(acc >> nacc);
+        if (wr_spill == 0xffffu && 2u * wr + 1u <= static_cast<uint32_t>(frontier)) {
+          bw[wr] = word;
+        } else {
+          if (wr_spill == 0xffffu) wr_spill = wr;
+          spill[wr] = word;
+        }
+        ++wr;
+      }
+    };
     int prev = 1;
-    // one step: consume entry (iC, eC) -> issue its table read into codeOut; fetch the next
-    // entry into (iN, eN); account the table word of the step before (codeIn).  The loop is
-    // unrolled by two with swapped roles, so an in-flight LDS result is never copied (a copy
-    // would force a wait and serialise the round trips again).
-    auto step = [&](int iC, uint32_t eC, int& iN, uint32_t& eN, uint32_t codeIn, uint32_t& codeOut) {
+    // stage A of entry (iC, eC): indices + issue the table read (codeOut); fetch next entry;
+    // stage B of the symbol before it (sIn = n | zr << 8 | suffix << 16, codeIn in flight).
+    auto step = [&](int iC, uint32_t eC, int& iN, uint32_t& eN,
+                    uint32_t codeIn, uint32_t sIn, bool vIn, uint32_t& codeOut, uint32_t& sOut) {
       iN = next_pos();
       eN = zz[iN];
       const uint32_t mag = eC & 0x7fffu;
       const int run = iC - prev;
       prev = iC + 1;
-      const int n = 32 - __clz(mag);
+      const uint32_t n = 32u - __clz(mag);
+      const uint32_t ones = (1u << n) - 1u;
+      const uint32_t suffix = (eC & 0x8000u) ? (mag ^ ones) : mag;      // negative: ~mag on n bits
       codeOut = ac[((run & 15) << 4) | n];
-      len += (codeIn & 0xffu) + static_cast<uint32_t>(run >> 4) * zl + n;
+      sOut = n | ((static_cast<uint32_t>(run) >> 4) << 8) | (suffix << 16);
+      if (vIn) {
+        const uint32_t pn = sIn & 0xffu;
+        for (uint32_t z = (sIn >> 8) & 0xffu; z > 0; --z) append(zrl >> 16, zl, iN);
+        append(((codeIn >> 16) << pn) | (sIn >> 16), (codeIn & 0xffu) + pn, iN);
+      }
     };
-    int iA = next_pos(), iB = 0;                   // 0 = exhausted (position 0 is the DC)
-    uint32_t eA = zz[iA], eB = 0, cA = 0, cB = 0;
-    while (iA) {
-      step(iA, eA, iB, eB, cA, cB);
-      if (!iB) { cA = cB; break; }
-      step(iB, eB, iA, eA, cB, cA);
+    int iA = next_pos(), iB = kEnd;
+    uint32_t eA = zz[iA], eB = 0, cA = 0, cB = 0, sA = 0, sB = 0;
+    append(dc_bits, dc_len, iA);
+    bool pend = false;                             // a symbol waits for stage B (in cA/sA)
+    while (iA != kEnd) {
+      step(iA, eA, iB, eB, cA, sA, pend, cB, sB);
+      if (iB == kEnd) { cA = cB; sA = sB; pend = true; break; }
+      step(iB, eB, iA, eA, cB, sB, true, cA, sA);
+      pend = true;
     }
-    len += cA & 0xffu;
-    if (b_emits) {
-      len += dc_len;
-      if (prev <= 63) len += eob & 0xffu;          // last non-zero index < 63
+    if (pend) {
+      const uint32_t pn = sA & 0xffu;
+      for (uint32_t z = (sA >> 8) & 0xffu; z > 0; --z) append(zrl >> 16, zl, kEnd);
+      append(((cA >> 16) << pn) | (sA >> 16), (cA & 0xffu) + pn, kEnd);
     }
+    if (prev <= 63) append(eob >> 16, eob & 0xffu, kEnd);          // last non-zero index < 63
+    len = 32u * wr + nacc;
+    if (nacc != 0u) append(0u, 32u - nacc, kEnd);                    // left-align the last word
   }
   btail[3] = len;
   __syncthreads();
@@ -991,10 +1033,12 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
   __syncthreads();
   const uint32_t start = btail[3];
   const uint32_t end = start + len;
+  const uint32_t nw = (len + 31u) >> 5;
 
   stamp(5);
-  // pass 2: emit into the LDS window, round by round (one round unless the segment
-  // overflows the window); words are MSB-first, flushed coalesced to the segment's slot.
+  // Stitch: every block's words are shifted to its bit offset and ORed into the LDS window,
+  // round by round (one round unless the segment overflows the window); the window is flushed
+  // coalesced to the segment's slot.
   uint32_t* const out_words = a.seg_words + (static_cast<size_t>(frame) * a.nseg + seg) * a.slot_words;
   uint32_t base = 0;                               // bit position of window word 0, multiple of 32
   uint32_t carry = 0;
@@ -1007,59 +1051,35 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
     const bool fits = !done && (end <= base + kWinWords * 32u);
     if (!done && !fits) atomicMin(&misc[8], start);
     __syncthreads();
-    // everything that starts before the first non-fitting block (stream order) is emitted now
+    // everything that starts before the first non-fitting block (stream order) is placed now
     const uint32_t limit = misc[8];
     if (fits && start < limit) {
       const uint32_t pos = start - base;
-      uint32_t bp = pos;                           // running bit position inside the window
-      // branch-free append: OR the (<= 27) bits into the one or two window words they touch
-      auto put = [&](uint32_t bits, uint32_t nb) { // 1 <= nb <= 27
-        const uint32_t v = bits << (32 - nb);      // left-aligned
-        const uint32_t o = bp & 31u;
-        uint32_t* w = win + (bp >> 5);
-        atomicOr(w, v >> o);
-        atomicOr(w + 1, (v << 1) << (31u - o));    // zero when the symbol ends inside the word
-        bp += nb;
-      };
-      put(dc_bits, dc_len);
-      unsigned long long m = nzm;
-      auto next_pos = [&]() -> int { if (!m) return 0; const int i = __builtin_ctzll(m); m &= m - 1; return i; };
-      int prev = 1;
-      // stage A of entry (iC, eC): indices + issue the table read (codeOut); fetch next entry;
-      // stage B of the symbol before it (sIn = n | zr << 8 | suffix << 16, codeIn in flight).
-      auto step = [&](int iC, uint32_t eC, int& iN, uint32_t& eN,
-                      uint32_t codeIn, uint32_t sIn, bool vIn, uint32_t& codeOut, uint32_t& sOut) {
-        iN = next_pos();
-        eN = zz[iN];
-        const uint32_t mag = eC & 0x7fffu;
-        const int run = iC - prev;
-        prev = iC + 1;
-        const uint32_t n = 32u - __clz(mag);
-        const uint32_t ones = (1u << n) - 1u;
-        const uint32_t suffix = (eC & 0x8000u) ? (mag ^ ones) : mag;      // negative: ~mag on n bits
-        codeOut = ac[((run & 15) << 4) | n];
-        sOut = n | ((static_cast<uint32_t>(run) >> 4) << 8) | (suffix << 16);
-        if (vIn) {
-          const uint32_t pn = sIn & 0xffu;
-          for (uint32_t z = (sIn >> 8) & 0xffu; z > 0; --z) put(zrl >> 16, zl);
-          put(((codeIn >> 16) << pn) | (sIn >> 16), (codeIn & 0xffu) + pn);
+      const uint32_t o = pos & 31u;
+      uint32_t* const dst = win + (pos >> 5);
+      uint32_t before = 0;                         // source word j - 1
+      if (wr_spill == 0xffffu) {
+        for (uint32_t j0 = 0; j0 < nw; j0 += 4) {
+          uint32_t v[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) v[u] = bw[j0 + u];               // inside the 144-byte slot
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const uint32_t j = j0 + u;
+            if (j >= nw) v[u] = 0;
+            if (j <= nw) atomicOr(dst + j, __builtin_amdgcn_alignbit(before, v[u], o));   // (before:v) >> o
+            before = v[u];
+          }
         }
-      };
-      int iA = next_pos(), iB = 0;
-      uint32_t eA = zz[iA], eB = 0, cA = 0, cB = 0, sA = 0, sB = 0;
-      bool pend = false;                           // a symbol waits for stage B (in cA/sA)
-      while (iA) {
-        step(iA, eA, iB, eB, cA, sA, pend, cB, sB);
-        if (!iB) { cA = cB; sA = sB; pend = true; break; }
-        step(iB, eB, iA, eA, cB, sB, true, cA, sA);
-        pend = true;
+      } else {
+        for (uint32_t j = 0; j < ((nw + 3u) & ~3u); ++j) {              // same schedule, word by word
+          uint32_t v = 0;
+          if (j < nw) v = (j < wr_spill) ? bw[j] : spill[j];
+          if (j <= nw) atomicOr(dst + j, __builtin_amdgcn_alignbit(before, v, o));
+          before = v;
+        }
       }
-      if (pend) {
-        const uint32_t pn = sA & 0xffu;
-        for (uint32_t z = (sA >> 8) & 0xffu; z > 0; --z) put(zrl >> 16, zl);
-        put(((cA >> 16) << pn) | (sA >> 16), (cA & 0xffu) + pn);
-      }
-      if (prev <= 63) put(eob >> 16, eob & 0xffu);
+      if ((nw & 3u) == 0u && o != 0u) atomicOr(dst + nw, before << (32u - o));
       done = true;
     }
     __syncthreads();
@@ -1416,7 +1436,7 @@ struct sjpeg_hip_engine {
   int device = 0;
   DevBuf<DevTables> tables;
   DevBuf<uint8_t> header;
-  DevBuf<uint32_t> seg_words, seg_nbits, ubuf, chunk_ff, partial;
+  DevBuf<uint32_t> seg_words, seg_nbits, spill, ubuf, chunk_ff, partial;
   DevBuf<unsigned long long> seg_off, chunk_off, stamps;
   bool want_stamps = false;
   int last_nseg = 0, last_nframes = 0;   // geometry of the last encode call (entropy_bits)
@@ -1532,6 +1552,7 @@ int prepare_scan(sjpeg_hip_engine* e, const sjpeg_hip_source* src,
   const size_t total_segs = static_cast<size_t>(nframes) * g->nseg;
   if ((rc = e->seg_words.ensure(total_segs * g->slot_words))) return rc;
   if ((rc = e->seg_nbits.ensure(total_segs))) return rc;
+  if ((rc = e->spill.ensure(total_segs * kScanThreads * kSpillWords))) return rc;
   DevTables host_tables;
   digest_tables(tables, &host_tables);
   HIP_TRY(hipMemcpyAsync(e->tables.p, &host_tables, sizeof(DevTables), hipMemcpyHostToDevice, st));
@@ -1539,6 +1560,7 @@ int prepare_scan(sjpeg_hip_engine* e, const sjpeg_hip_source* src,
   a->has_clip = (W % g->px != 0) || (H % g->px != 0);
   a->tables = e->tables.p;
   a->seg_words = e->seg_words.p;
+  a->spill = e->spill.p;
   a->slot_words = g->slot_words;
   a->seg_nbits = e->seg_nbits.p;
   a->coeffs = nullptr;
@@ -1594,7 +1616,7 @@ int sjpeg_hip_engine_create(int device, sjpeg_hip_engine** engine) {
 void sjpeg_hip_engine_destroy(sjpeg_hip_engine* e) {
   if (e == nullptr) return;
   (void)hipSetDevice(e->device);
-  e->tables.release(); e->header.release(); e->seg_words.release(); e->seg_nbits.release();
+  e->tables.release(); e->header.release(); e->seg_words.release(); e->seg_nbits.release(); e->spill.release();
   e->ubuf.release(); e->chunk_ff.release(); e->partial.release(); e->seg_off.release(); e->chunk_off.release();
   for (auto& ev : e->ev) if (ev) (void)hipEventDestroy(ev);
   delete e;

@@ -26,7 +26,7 @@ buf = np.zeros(1 << 22, np.uint64)
 n = L.sjpeg_hip_debug_stamps(eng._h, buf.ctypes.data, buf.size)
 st = buf[:n].reshape(-1, 8).astype(np.int64)
 d = np.diff(st, axis=1)
-names = ["P1 colour", "P2 dct+quant", "dc+sort", "pass1 len", "scan", "pass2 emit", "flush"]
+names = ["P1 colour", "P2 dct+quant", "dc+sort", "walk (code)", "scan", "stitch", "flush"]
 print("workgroups", len(st), "lifetime mean cycles", (st[:, 7] - st[:, 0]).mean())
 for i, nm in enumerate(names):
     print(f"  {nm:14s} mean {d[:, i].mean():9.0f}  p50 {np.median(d[:, i]):9.0f}  p95 {np.percentile(d[:, i], 95):9.0f}")
