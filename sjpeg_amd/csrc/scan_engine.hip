@@ -932,7 +932,9 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
   perm[bin_start[cnt] + rank] = tid;
   __syncthreads();
   stamp(3);
-  const int blk = (a.ablate == 20) ? tid : static_cast<int>(perm[tid]);   // the block this thread entropy-codes
+  // the block this thread entropy-codes; ablate 21: the heavy wave lands on a different SIMD per workgroup
+  const int blk = (a.ablate == 20) ? tid
+                : static_cast<int>(perm[(a.ablate == 21) ? ((tid + 64 * ((seg + frame) & 3)) & 255) : tid]);
   unsigned char* const bslot = smem + blk * kSlotBytes;
   uint32_t* const btail = reinterpret_cast<uint32_t*>(bslot + 128);
   const uint32_t b_dc = btail[2];
