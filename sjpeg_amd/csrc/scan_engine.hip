@@ -50,7 +50,7 @@ constexpr int kThreads = 256;        // stitch kernels (K2..K5): 4 waves
 constexpr int kScanThreads = 256;    // K1: 4 waves = 41 coded MCUs + 1 halo MCU in 4:2:0
 constexpr int kSlotBytes = 144;      // 64 int16 + 16 B pad: conflict-free ds_read_b128 per lane
 constexpr int kWinWords = 2048;       // LDS bit window, 32-bit MSB-first words (8 KiB)
-constexpr int kSpillWords = 54;      // kMaxBlockBits / 32
+constexpr int kSpillWords = 64;      // per block: 16 words for each of the four parts (<= 496 bits)
 constexpr int kMaxBlockBits = 1728;  // 22 (DC) + 63*27 (AC) rounded up; reference bound enc.cc:206-209
 constexpr int kChunkWords = 1024;    // K3/K5 chunk: 4 KiB of un-stuffed stream
 constexpr int kChunkBytes = kChunkWords * 4;
@@ -86,7 +86,7 @@ struct ScanArgs {
   uint32_t* seg_words;     // [nframes*nseg][slot_words]
   uint32_t slot_words;
   uint32_t* seg_nbits;     // [nframes*nseg]
-  uint32_t* spill;         // [nframes*nseg][kScanThreads][kSpillWords]: words that cannot stay in place
+  uint32_t* spill;         // [nframes*nseg][kScanThreads][kSpillWords]: words that cannot stay in the slot
   int16_t* coeffs;         // kKindTap: quantized coefficients
   uint32_t* partial;       // kKindHisto / kKindStats: per-workgroup partial statistics
   unsigned long long* stamps;  // profiling (env SJPEG_HIP_STAMPS): 8 cycle stamps per workgroup
@@ -906,85 +906,112 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
   }
 
   // The run/size coding of a block (src/entropy.cc:161-198) is a serial walk over its non-zero
-  // coefficients.  Blocks are handed to threads sorted by their number of non-zeros (counting
-  // sort, descending), so that the 64 blocks a wave walks together have similar trip counts:
-  // a structured 4K picture averages 13 non-zeros per block but 42 for the worst of 64
-  // consecutive blocks.  hist/perm live in the bit window, idle until pass 2.
-  uint32_t* const hist = win;                      // [64]
-  uint32_t* const bin_start = win + 64;            // [64]
-  uint32_t* const perm = win + 128;                // [kScanThreads]
-  const uint32_t cnt = emits ? static_cast<uint32_t>(__popc(nz_lo) + __popc(nz_hi)) : 0u;
-  if (tid < 64) hist[tid] = 0;
-  __syncthreads();
-  const uint32_t rank = atomicAdd(&hist[cnt], 1u);
-  __syncthreads();
-  if (tid < 64) {                                  // wave 0: exclusive scan over bins 63, 62, ... 0
-    const uint32_t h = hist[63 - tid];
-    uint32_t incl = h;
+  // coefficients, and a structured 4K picture averages 13 non-zeros per block but 45 for the
+  // worst block of a segment: one thread per block leaves the whole workgroup waiting for that
+  // one walk.  So a block is coded as up to four independent PARTS, one per quarter of the
+  // zig-zag scan (positions 1-15 with the DC, 16-31, 32-47, 48-63; empty quarters make no part).
+  // A part needs only the block's non-zero mask to know the run in front of its first symbol and
+  // whether it carries the EOB, and its bits are stitched at bit granularity like the blocks
+  // themselves.  Parts are handed to threads sorted by their number of non-zeros (counting sort,
+  // descending), 256 per round: walks of at most 16 symbols with similar trip counts per wave.
+  // The unit list and the part lengths live in the bit window, idle until the stitch.
+  constexpr int kMaxRounds = 4;
+  uint32_t* const hist = win;                      // [32], bins 0..16
+  uint32_t* const bin_start = win + 32;            // [32]
+  uint16_t* const ulist = reinterpret_cast<uint16_t*>(win + 64);          // [1024] block | quarter << 8
+  uint16_t* const ulen = reinterpret_cast<uint16_t*>(win + 64 + 512);     // [256][4] bits per part
+  {
+    uint32_t c[4] = {static_cast<uint32_t>(__popc(nz_lo & 0xffffu)), static_cast<uint32_t>(__popc(nz_lo >> 16)),
+                     static_cast<uint32_t>(__popc(nz_hi & 0xffffu)), static_cast<uint32_t>(__popc(nz_hi >> 16))};
+    if (tid < 32) hist[tid] = 0;
+    *reinterpret_cast<uint2*>(ulen + 4 * tid) = make_uint2(0u, 0u);
+    __syncthreads();
+    uint32_t rank[4] = {0, 0, 0, 0};
+    if (emits) {
+      rank[0] = atomicAdd(&hist[c[0]], 1u);        // quarter 0 always makes a part (DC, EOB)
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const uint32_t y = __shfl_up(incl, d, 64);
-      if (tid >= d) incl += y;
+      for (int q = 1; q < 4; ++q) if (c[q] != 0u) rank[q] = atomicAdd(&hist[c[q]], 1u);
     }
-    bin_start[63 - tid] = incl - h;
+    __syncthreads();
+    if (tid < 64) {                                // wave 0: exclusive scan over bins 16, 15, ... 0
+      const uint32_t h = tid <= 16 ? hist[16 - tid] : 0u;
+      uint32_t incl = h;
+#pragma unroll
+      for (int d = 1; d < 32; d <<= 1) {
+        const uint32_t y = __shfl_up(incl, d, 64);
+        if (tid >= d) incl += y;
+      }
+      if (tid <= 16) bin_start[16 - tid] = incl - h;
+      if (tid == 16) misc[9] = incl;               // number of parts
+    }
+    __syncthreads();
+    if (emits) {
+      ulist[bin_start[c[0]] + rank[0]] = static_cast<uint16_t>(tid);
+#pragma unroll
+      for (int q = 1; q < 4; ++q) {
+        if (c[q] != 0u) ulist[bin_start[c[q]] + rank[q]] = static_cast<uint16_t>(tid | (q << 8));
+      }
+    }
+    __syncthreads();
   }
-  __syncthreads();
-  perm[bin_start[cnt] + rank] = tid;
-  __syncthreads();
   stamp(3);
-  // the block this thread entropy-codes; ablate 21: the heavy wave lands on a different SIMD per workgroup
-  const int blk = (a.ablate == 20) ? tid
-                : static_cast<int>(perm[(a.ablate == 21) ? ((tid + 64 * ((seg + frame) & 3)) & 255) : tid]);
-  unsigned char* const bslot = smem + blk * kSlotBytes;
-  uint32_t* const btail = reinterpret_cast<uint32_t*>(bslot + 128);
-  const uint32_t b_dc = btail[2];
-  const bool b_emits = b_dc != 0;
-  const int b_k = blk % BPM;
-  const int b_tbl = (MODE == SJPEG_HIP_YUV420) ? (b_k >= 4) : (MODE == SJPEG_HIP_YUV444 ? (b_k >= 1) : 0);
-  const uint32_t* const ac = lac + b_tbl * 256;
-  const uint32_t dc_bits = b_dc & 0xffffffu, dc_len = b_dc >> 24;
+  const uint32_t n_units = misc[9];
+  const int n_rounds = static_cast<int>((n_units + kScanThreads - 1) / kScanThreads);   // <= 4
+
   // the walk reads 16-bit entries and writes 32-bit words in the same slot: no type-based reordering
   typedef uint16_t __attribute__((may_alias)) u16_alias;
   typedef uint32_t __attribute__((may_alias)) u32_alias;
-  const u16_alias* const zz = reinterpret_cast<const u16_alias*>(bslot);   // bit 15 = negative, 14..0 = level
-  const uint32_t zrl = ac[0xf0], eob = ac[0x00];
-  const uint32_t zl = zrl & 0xffu;
-  const unsigned long long nzm = b_emits ? ((static_cast<unsigned long long>(btail[1]) << 32) | btail[0]) : 0ull;
-
-  // ONE walk codes the block (src/entropy.cc:161-198).  The bits go, MSB-first, into the block's
-  // OWN slot, over coefficients that were already consumed: word w replaces entries 2w and
-  // 2w + 1, and is only written once every entry up to 2w + 1 has been loaded (a block produces
-  // far fewer than 16 bits per zig-zag position).  The rare word that would overtake the reader
-  // goes to a global spill row instead, and so does everything after it.  The walk is
-  // software-pipelined by hand: the entry of the NEXT non-zero position and the Huffman word of
-  // the CURRENT one are in flight while the previous symbol is appended; unrolled by two with
-  // swapped roles so that an in-flight LDS value is never copied (a copy forces a wait).
   constexpr int kEnd = 69;                         // "no more non-zeros": reads as a loaded frontier
-  u32_alias* const bw = reinterpret_cast<u32_alias*>(bslot);
-  uint32_t* const spill = a.spill + ((static_cast<size_t>(frame) * a.nseg + seg) * kScanThreads + tid) * kSpillWords;
-  unsigned long long acc = 0;                      // pending bits, right-aligned (upper bits stale)
-  uint32_t nacc = 0, wr = 0;                       // pending bit count (< 32), words produced
-  uint32_t wr_spill = 0xffffu;                     // first word that went to the spill row
-  uint32_t len = 0;
-  if (b_emits) {
-    unsigned long long m = nzm;
+  constexpr uint32_t kNoSpill = 0xffffu;
+  uint32_t* const spill_wg = a.spill + (static_cast<size_t>(frame) * a.nseg + seg) * kScanThreads * kSpillWords;
+
+  // ONE walk codes a part.  The bits go, MSB-first, into the part's OWN quarter of the slot (8
+  // words over its 16 entries), over coefficients that were already consumed: word w replaces
+  // entries 2w and 2w + 1 and is only written once every entry up to 2w + 1 has been loaded.
+  // The rare word that would overtake the reader, or leave the quarter, goes to a global spill
+  // row instead, and so does everything after it.  The walk is software-pipelined by hand: the
+  // entry of the NEXT non-zero position and the Huffman word of the CURRENT one are in flight
+  // while the previous symbol is appended; unrolled by two with swapped roles so that an
+  // in-flight LDS value is never copied (a copy forces a wait).
+  auto walk = [&](uint32_t unit, uint32_t& len_out, uint32_t& spill_out) {
+    const int blk = static_cast<int>(unit & 255u), q = static_cast<int>(unit >> 8);
+    unsigned char* const bslot = smem + blk * kSlotBytes;
+    const uint32_t* const btail = reinterpret_cast<const uint32_t*>(bslot + 128);
+    const unsigned long long m_all = (static_cast<unsigned long long>(btail[1]) << 32) | btail[0];
+    const uint32_t b_dc = btail[2];
+    const int b_k = blk % BPM;
+    const int b_tbl = (MODE == SJPEG_HIP_YUV420) ? (b_k >= 4) : (MODE == SJPEG_HIP_YUV444 ? (b_k >= 1) : 0);
+    const uint32_t* const ac = lac + b_tbl * 256;
+    const u16_alias* const zz = reinterpret_cast<const u16_alias*>(bslot);   // bit 15 = negative, 14..0 = level
+    u32_alias* const bw = reinterpret_cast<u32_alias*>(bslot) + 8 * q;
+    uint32_t* const spill = spill_wg + blk * kSpillWords + 16 * q;
+    const uint32_t zrl = ac[0xf0], eob = ac[0x00];
+    const uint32_t zl = zrl & 0xffu;
+    const int sh = 16 * q;
+    unsigned long long m = m_all & (0xffffull << sh);
+    const unsigned long long below = m_all & ((1ull << sh) - 1ull);
+    const bool is_last = (q == 3) || ((m_all >> (sh + 16)) == 0ull);
+    int prev = below ? 64 - __builtin_clzll(below) : 1;       // position after the previous non-zero
+    unsigned long long acc = 0;                    // pending bits, right-aligned (upper bits stale)
+    uint32_t nacc = 0, wr = 0;                     // pending bit count (< 32), words produced
+    uint32_t wr_spill = kNoSpill;                  // first word that went to the spill row
+    const uint32_t wabs = 16u * static_cast<uint32_t>(q) + 1u;   // entry 2 * (8q + wr) + 1
     auto next_pos = [&]() -> int { if (!m) return kEnd; const int i = __builtin_ctzll(m); m &= m - 1; return i; };
-    auto append = [&](uint32_t bits, uint32_t nb, int frontier) {   // 1 <= nb <= 27
+    auto append = [&](uint32_t bits, uint32_t nb, int frontier) {   // 1 <= nb <= 31
       acc = (acc << nb) | bits;
       nacc += nb;
       if (nacc >= 32u) {
         nacc -= 32u;
         const uint32_t word = static_cast<uint32_t>(acc >> nacc);
-        if (wr_spill == 0xffffu && 2u * wr + 1u <= static_cast<uint32_t>(frontier)) {
+        if (wr_spill == kNoSpill && wr < 8u && 2u * wr + wabs <= static_cast<uint32_t>(frontier)) {
           bw[wr] = word;
         } else {
-          if (wr_spill == 0xffffu) wr_spill = wr;
+          if (wr_spill == kNoSpill) wr_spill = wr;
           spill[wr] = word;
         }
         ++wr;
       }
     };
-    int prev = 1;
     // stage A of entry (iC, eC): indices + issue the table read (codeOut); fetch next entry;
     // stage B of the symbol before it (sIn = n | zr << 8 | suffix << 16, codeIn in flight).
     auto step = [&](int iC, uint32_t eC, int& iN, uint32_t& eN,
@@ -1007,7 +1034,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
     };
     int iA = next_pos(), iB = kEnd;
     uint32_t eA = zz[iA], eB = 0, cA = 0, cB = 0, sA = 0, sB = 0;
-    append(dc_bits, dc_len, iA);
+    if (q == 0) append(b_dc & 0xffffffu, b_dc >> 24, iA);
     bool pend = false;                             // a symbol waits for stage B (in cA/sA)
     while (iA != kEnd) {
       step(iA, eA, iB, eB, cA, sA, pend, cB, sB);
@@ -1020,69 +1047,115 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
       for (uint32_t z = (sA >> 8) & 0xffu; z > 0; --z) append(zrl >> 16, zl, kEnd);
       append(((cA >> 16) << pn) | (sA >> 16), (cA & 0xffu) + pn, kEnd);
     }
-    if (prev <= 63) append(eob >> 16, eob & 0xffu, kEnd);          // last non-zero index < 63
-    len = 32u * wr + nacc;
-    if (nacc != 0u) append(0u, 32u - nacc, kEnd);                    // left-align the last word
+    if (is_last && prev <= 63) append(eob >> 16, eob & 0xffu, kEnd);   // last non-zero index < 63
+    const uint32_t len = 32u * wr + nacc;
+    if (nacc != 0u) append(0u, 32u - nacc, kEnd);                        // left-align the last word
+    ulen[4 * blk + q] = static_cast<uint16_t>(len);
+    len_out = len;
+    spill_out = wr_spill;
+  };
+
+  uint32_t u_id[kMaxRounds], u_len[kMaxRounds], u_spill[kMaxRounds];
+#pragma unroll
+  for (int r = 0; r < kMaxRounds; ++r) {
+    u_id[r] = 0xffffu; u_len[r] = 0u; u_spill[r] = kNoSpill;
+    if (r < n_rounds) {
+      const uint32_t idx = static_cast<uint32_t>(r) * kScanThreads + tid;
+      if (idx < n_units) {
+        u_id[r] = ulist[idx];
+        walk(u_id[r], u_len[r], u_spill[r]);
+      }
+    }
   }
-  btail[3] = len;
   __syncthreads();
   stamp(4);
-  // offsets are a prefix sum in STREAM order (thread tid owns block tid here)
+  // offsets are a prefix sum in STREAM order (thread tid owns block tid here); the lengths of
+  // the first three parts stay with the block so that every part can find its own offset
   uint32_t total;
-  const uint32_t my_start = wg_exclusive_scan<kScanThreads>(tail[3], misc, &total);
+  {
+    const uint2 L = *reinterpret_cast<const uint2*>(ulen + 4 * tid);
+    const uint32_t l0 = L.x & 0xffffu, l1 = L.x >> 16, l2 = L.y & 0xffffu, l3 = L.y >> 16;
+    tail[2] = l0 | (l1 << 10) | (l2 << 20);
+    const uint32_t my_start = wg_exclusive_scan<kScanThreads>(l0 + l1 + l2 + l3, misc, &total);
+    tail[3] = my_start;
+  }
   if (a.ablate == 3) { if (tid == 0) a.seg_nbits[static_cast<size_t>(frame) * a.nseg + seg] = total; return; }
-  tail[3] = my_start;
   __syncthreads();
-  const uint32_t start = btail[3];
-  const uint32_t end = start + len;
-  const uint32_t nw = (len + 31u) >> 5;
+  uint32_t u_start[kMaxRounds];
+#pragma unroll
+  for (int r = 0; r < kMaxRounds; ++r) {
+    u_start[r] = 0;
+    if (u_id[r] != 0xffffu) {
+      const uint32_t* const btail = reinterpret_cast<const uint32_t*>(smem + (u_id[r] & 255u) * kSlotBytes + 128);
+      const uint32_t pk = btail[2], q = u_id[r] >> 8;
+      const uint32_t l0 = pk & 1023u, l1 = (pk >> 10) & 1023u, l2 = (pk >> 20) & 1023u;
+      u_start[r] = btail[3] + (q >= 1u ? l0 : 0u) + (q >= 2u ? l1 : 0u) + (q >= 3u ? l2 : 0u);
+    }
+  }
 
   stamp(5);
-  // Stitch: every block's words are shifted to its bit offset and ORed into the LDS window,
+  // Stitch: every part's words are shifted to its bit offset and ORed into the LDS window,
   // round by round (one round unless the segment overflows the window); the window is flushed
   // coalesced to the segment's slot.
   uint32_t* const out_words = a.seg_words + (static_cast<size_t>(frame) * a.nseg + seg) * a.slot_words;
   uint32_t base = 0;                               // bit position of window word 0, multiple of 32
   uint32_t carry = 0;
-  bool done = !b_emits;
+  auto place = [&](uint32_t unit, uint32_t start, uint32_t len, uint32_t wr_spill) {
+    const uint32_t blk = unit & 255u, q = unit >> 8;
+    const u32_alias* const bw = reinterpret_cast<const u32_alias*>(smem + blk * kSlotBytes) + 8 * q;
+    const uint32_t* const spill = spill_wg + blk * kSpillWords + 16 * q;
+    const uint32_t nw = (len + 31u) >> 5;
+    const uint32_t pos = start - base;
+    const uint32_t o = pos & 31u;
+    uint32_t* const dst = win + (pos >> 5);
+    uint32_t before = 0;                           // source word j - 1
+    if (wr_spill == kNoSpill) {                    // nw <= 8, all inside the quarter
+      for (uint32_t j0 = 0; j0 < nw; j0 += 4) {
+        const uint4 v4 = *reinterpret_cast<const uint4*>(bw + j0);
+        uint32_t v[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const uint32_t j = j0 + u;
+          if (j >= nw) v[u] = 0;
+          if (j <= nw) atomicOr(dst + j, __builtin_amdgcn_alignbit(before, v[u], o));   // (before:v) >> o
+          before = v[u];
+        }
+      }
+    } else {
+      for (uint32_t j = 0; j < ((nw + 3u) & ~3u); ++j) {                // same schedule, word by word
+        uint32_t v = 0;
+        if (j < nw) v = (j < wr_spill) ? bw[j] : spill[j];
+        if (j <= nw) atomicOr(dst + j, __builtin_amdgcn_alignbit(before, v, o));
+        before = v;
+      }
+    }
+    if ((nw & 3u) == 0u && o != 0u) atomicOr(dst + nw, before << (32u - o));
+  };
+  uint32_t pending = 0;                            // bit r: part of round r still has to be placed
+#pragma unroll
+  for (int r = 0; r < kMaxRounds; ++r) if (u_id[r] != 0xffffu) pending |= 1u << r;
   for (;;) {
     for (int i = tid; i < kWinWords + 1; i += kScanThreads) win[i] = 0;
     if (tid == 0) misc[8] = total;
     __syncthreads();
     if (tid == 0 && carry != 0) atomicOr(&win[0], carry);
-    const bool fits = !done && (end <= base + kWinWords * 32u);
-    if (!done && !fits) atomicMin(&misc[8], start);
-    __syncthreads();
-    // everything that starts before the first non-fitting block (stream order) is placed now
-    const uint32_t limit = misc[8];
-    if (fits && start < limit) {
-      const uint32_t pos = start - base;
-      const uint32_t o = pos & 31u;
-      uint32_t* const dst = win + (pos >> 5);
-      uint32_t before = 0;                         // source word j - 1
-      if (wr_spill == 0xffffu) {
-        for (uint32_t j0 = 0; j0 < nw; j0 += 4) {
-          uint32_t v[4];
+    uint32_t fits = 0;
 #pragma unroll
-          for (int u = 0; u < 4; ++u) v[u] = bw[j0 + u];               // inside the 144-byte slot
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const uint32_t j = j0 + u;
-            if (j >= nw) v[u] = 0;
-            if (j <= nw) atomicOr(dst + j, __builtin_amdgcn_alignbit(before, v[u], o));   // (before:v) >> o
-            before = v[u];
-          }
-        }
-      } else {
-        for (uint32_t j = 0; j < ((nw + 3u) & ~3u); ++j) {              // same schedule, word by word
-          uint32_t v = 0;
-          if (j < nw) v = (j < wr_spill) ? bw[j] : spill[j];
-          if (j <= nw) atomicOr(dst + j, __builtin_amdgcn_alignbit(before, v, o));
-          before = v;
-        }
+    for (int r = 0; r < kMaxRounds; ++r) {
+      if (pending & (1u << r)) {
+        if (u_start[r] + u_len[r] <= base + kWinWords * 32u) fits |= 1u << r;
+        else atomicMin(&misc[8], u_start[r]);
       }
-      if ((nw & 3u) == 0u && o != 0u) atomicOr(dst + nw, before << (32u - o));
-      done = true;
+    }
+    __syncthreads();
+    // everything that starts before the first non-fitting part (stream order) is placed now
+    const uint32_t limit = misc[8];
+#pragma unroll
+    for (int r = 0; r < kMaxRounds; ++r) {
+      if ((fits & (1u << r)) && u_start[r] < limit) {
+        place(u_id[r], u_start[r], u_len[r], u_spill[r]);
+        pending &= ~(1u << r);
+      }
     }
     __syncthreads();
     stamp(6);
