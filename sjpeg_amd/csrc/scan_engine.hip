@@ -915,7 +915,6 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
   // themselves.  Parts are handed to threads sorted by their number of non-zeros (counting sort,
   // descending), 256 per round: walks of at most 16 symbols with similar trip counts per wave.
   // The unit list and the part lengths live in the bit window, idle until the stitch.
-  constexpr int kMaxRounds = 4;
   uint32_t* const hist = win;                      // [32], bins 0..16
   uint32_t* const bin_start = win + 32;            // [32]
   uint16_t* const ulist = reinterpret_cast<uint16_t*>(win + 64);          // [1024] block | quarter << 8
@@ -988,7 +987,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
     const uint32_t zrl = ac[0xf0], eob = ac[0x00];
     const uint32_t zl = zrl & 0xffu;
     const int sh = 16 * q;
-    unsigned long long m = m_all & (0xffffull << sh);
+    uint32_t m = static_cast<uint32_t>(m_all >> sh) & 0xffffu;   // the part's own 16 positions
     const unsigned long long below = m_all & ((1ull << sh) - 1ull);
     const bool is_last = (q == 3) || ((m_all >> (sh + 16)) == 0ull);
     int prev = below ? 64 - __builtin_clzll(below) : 1;       // position after the previous non-zero
@@ -996,7 +995,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
     uint32_t nacc = 0, wr = 0;                     // pending bit count (< 32), words produced
     uint32_t wr_spill = kNoSpill;                  // first word that went to the spill row
     const uint32_t wabs = 16u * static_cast<uint32_t>(q) + 1u;   // entry 2 * (8q + wr) + 1
-    auto next_pos = [&]() -> int { if (!m) return kEnd; const int i = __builtin_ctzll(m); m &= m - 1; return i; };
+    auto next_pos = [&]() -> int { if (!m) return kEnd; const int i = __builtin_ctz(m); m &= m - 1; return sh + i; };
     auto append = [&](uint32_t bits, uint32_t nb, int frontier) {   // 1 <= nb <= 31
       acc = (acc << nb) | bits;
       nacc += nb;
@@ -1055,16 +1054,18 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
     spill_out = wr_spill;
   };
 
-  uint32_t u_id[kMaxRounds], u_len[kMaxRounds], u_spill[kMaxRounds];
-#pragma unroll
-  for (int r = 0; r < kMaxRounds; ++r) {
-    u_id[r] = 0xffffu; u_len[r] = 0u; u_spill[r] = kNoSpill;
-    if (r < n_rounds) {
-      const uint32_t idx = static_cast<uint32_t>(r) * kScanThreads + tid;
-      if (idx < n_units) {
-        u_id[r] = ulist[idx];
-        walk(u_id[r], u_len[r], u_spill[r]);
-      }
+  // what this thread coded in each round: unit | spill << 10 | len << 16, 0xffffffff = nothing.
+  // (four registers picked by the round counter: one copy of the walk for all rounds)
+  uint32_t ur0 = 0xffffffffu, ur1 = 0xffffffffu, ur2 = 0xffffffffu, ur3 = 0xffffffffu;
+  auto ur_get = [&](int r) { return r == 0 ? ur0 : r == 1 ? ur1 : r == 2 ? ur2 : ur3; };
+  for (int r = 0; r < n_rounds; ++r) {
+    const uint32_t idx = static_cast<uint32_t>(r) * kScanThreads + tid;
+    if (idx < n_units) {
+      const uint32_t unit = ulist[idx];
+      uint32_t len, wsp;
+      walk(unit, len, wsp);
+      const uint32_t rec = unit | ((wsp & 31u) << 10) | (len << 16);   // spill index 0..15, 31 = none
+      if (r == 0) ur0 = rec; else if (r == 1) ur1 = rec; else if (r == 2) ur2 = rec; else ur3 = rec;
     }
   }
   __syncthreads();
@@ -1081,17 +1082,19 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
   }
   if (a.ablate == 3) { if (tid == 0) a.seg_nbits[static_cast<size_t>(frame) * a.nseg + seg] = total; return; }
   __syncthreads();
-  uint32_t u_start[kMaxRounds];
+  uint32_t us0 = 0, us1 = 0, us2 = 0, us3 = 0;     // bit offset of each of them in the segment
 #pragma unroll
-  for (int r = 0; r < kMaxRounds; ++r) {
-    u_start[r] = 0;
-    if (u_id[r] != 0xffffu) {
-      const uint32_t* const btail = reinterpret_cast<const uint32_t*>(smem + (u_id[r] & 255u) * kSlotBytes + 128);
-      const uint32_t pk = btail[2], q = u_id[r] >> 8;
+  for (int r = 0; r < 4; ++r) {
+    const uint32_t rec = ur_get(r);
+    if (rec != 0xffffffffu) {
+      const uint32_t* const btail = reinterpret_cast<const uint32_t*>(smem + (rec & 255u) * kSlotBytes + 128);
+      const uint32_t pk = btail[2], q = (rec >> 8) & 3u;
       const uint32_t l0 = pk & 1023u, l1 = (pk >> 10) & 1023u, l2 = (pk >> 20) & 1023u;
-      u_start[r] = btail[3] + (q >= 1u ? l0 : 0u) + (q >= 2u ? l1 : 0u) + (q >= 3u ? l2 : 0u);
+      const uint32_t st = btail[3] + (q >= 1u ? l0 : 0u) + (q >= 2u ? l1 : 0u) + (q >= 3u ? l2 : 0u);
+      if (r == 0) us0 = st; else if (r == 1) us1 = st; else if (r == 2) us2 = st; else us3 = st;
     }
   }
+  auto us_get = [&](int r) { return r == 0 ? us0 : r == 1 ? us1 : r == 2 ? us2 : us3; };
 
   stamp(5);
   // Stitch: every part's words are shifted to its bit offset and ORed into the LDS window,
@@ -1100,8 +1103,9 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
   uint32_t* const out_words = a.seg_words + (static_cast<size_t>(frame) * a.nseg + seg) * a.slot_words;
   uint32_t base = 0;                               // bit position of window word 0, multiple of 32
   uint32_t carry = 0;
-  auto place = [&](uint32_t unit, uint32_t start, uint32_t len, uint32_t wr_spill) {
-    const uint32_t blk = unit & 255u, q = unit >> 8;
+  auto place = [&](uint32_t rec, uint32_t start) {
+    const uint32_t blk = rec & 255u, q = (rec >> 8) & 3u, len = rec >> 16;
+    const uint32_t wr_spill = ((rec >> 10) & 31u) == 31u ? kNoSpill : ((rec >> 10) & 31u);
     const u32_alias* const bw = reinterpret_cast<const u32_alias*>(smem + blk * kSlotBytes) + 8 * q;
     const uint32_t* const spill = spill_wg + blk * kSpillWords + 16 * q;
     const uint32_t nw = (len + 31u) >> 5;
@@ -1133,7 +1137,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
   };
   uint32_t pending = 0;                            // bit r: part of round r still has to be placed
 #pragma unroll
-  for (int r = 0; r < kMaxRounds; ++r) if (u_id[r] != 0xffffu) pending |= 1u << r;
+  for (int r = 0; r < 4; ++r) if (ur_get(r) != 0xffffffffu) pending |= 1u << r;
   for (;;) {
     for (int i = tid; i < kWinWords + 1; i += kScanThreads) win[i] = 0;
     if (tid == 0) misc[8] = total;
@@ -1141,19 +1145,19 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
     if (tid == 0 && carry != 0) atomicOr(&win[0], carry);
     uint32_t fits = 0;
 #pragma unroll
-    for (int r = 0; r < kMaxRounds; ++r) {
+    for (int r = 0; r < 4; ++r) {
       if (pending & (1u << r)) {
-        if (u_start[r] + u_len[r] <= base + kWinWords * 32u) fits |= 1u << r;
-        else atomicMin(&misc[8], u_start[r]);
+        if (us_get(r) + (ur_get(r) >> 16) <= base + kWinWords * 32u) fits |= 1u << r;
+        else atomicMin(&misc[8], us_get(r));
       }
     }
     __syncthreads();
     // everything that starts before the first non-fitting part (stream order) is placed now
     const uint32_t limit = misc[8];
 #pragma unroll
-    for (int r = 0; r < kMaxRounds; ++r) {
-      if ((fits & (1u << r)) && u_start[r] < limit) {
-        place(u_id[r], u_start[r], u_len[r], u_spill[r]);
+    for (int r = 0; r < 4; ++r) {
+      if (r < n_rounds && (fits & (1u << r)) && us_get(r) < limit) {
+        place(ur_get(r), us_get(r));
         pending &= ~(1u << r);
       }
     }
