@@ -993,23 +993,23 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
     int prev = below ? 64 - __builtin_clzll(below) : 1;       // position after the previous non-zero
     unsigned long long acc = 0;                    // pending bits, right-aligned (upper bits stale)
     uint32_t nacc = 0, wr = 0;                     // pending bit count (< 32), words produced
-    uint32_t wr_spill = kNoSpill;                  // first word that went to the spill row
+    uint32_t wr_lim = 8;                           // words [0, wr_lim) may stay in the slot
     const uint32_t wabs = 16u * static_cast<uint32_t>(q) + 1u;   // entry 2 * (8q + wr) + 1
     auto next_pos = [&]() -> int { if (!m) return kEnd; const int i = __builtin_ctz(m); m &= m - 1; return sh + i; };
+    // branch-free but for the two predicated stores: most appends of a wave complete a word in
+    // some lane anyway
     auto append = [&](uint32_t bits, uint32_t nb, int frontier) {   // 1 <= nb <= 31
       acc = (acc << nb) | bits;
       nacc += nb;
-      if (nacc >= 32u) {
-        nacc -= 32u;
-        const uint32_t word = static_cast<uint32_t>(acc >> nacc);
-        if (wr_spill == kNoSpill && wr < 8u && 2u * wr + wabs <= static_cast<uint32_t>(frontier)) {
-          bw[wr] = word;
-        } else {
-          if (wr_spill == kNoSpill) wr_spill = wr;
-          spill[wr] = word;
-        }
-        ++wr;
+      const bool full = nacc >= 32u;
+      nacc &= 31u;
+      const uint32_t word = static_cast<uint32_t>(acc >> nacc);
+      const bool in_place = (wr < wr_lim) & (2u * wr + wabs <= static_cast<uint32_t>(frontier));
+      if (full) {
+        if (in_place) bw[wr] = word; else spill[wr] = word;
       }
+      wr_lim = (full & !in_place) ? (wr < wr_lim ? wr : wr_lim) : wr_lim;
+      wr += full ? 1u : 0u;
     };
     // stage A of entry (iC, eC): indices + issue the table read (codeOut); fetch next entry;
     // stage B of the symbol before it (sIn = n | zr << 8 | suffix << 16, codeIn in flight).
@@ -1051,7 +1051,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
     if (nacc != 0u) append(0u, 32u - nacc, kEnd);                        // left-align the last word
     ulen[4 * blk + q] = static_cast<uint16_t>(len);
     len_out = len;
-    spill_out = wr_spill;
+    spill_out = wr > wr_lim ? wr_lim : kNoSpill;
   };
 
   // what this thread coded in each round: unit | spill << 10 | len << 16, 0xffffffff = nothing.
