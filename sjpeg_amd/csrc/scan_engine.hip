@@ -186,6 +186,7 @@ __device__ __forceinline__ void fdct_block(int* v) {
 // ---- packed int16 arithmetic (two columns per register), the 16-bit-lane formulation the
 // reference's own SIMD paths use and prove bit-identical to the plain-C one (src/fdct.cc:147).
 typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t as_u32(s16x2 v) { return __builtin_bit_cast(uint32_t, v); }
 __device__ __forceinline__ s16x2 as_pk(uint32_t v) { return __builtin_bit_cast(s16x2, v); }
 
@@ -238,6 +239,13 @@ __device__ __forceinline__ void fdct_col8_pk(uint32_t& r0, uint32_t& r1, uint32_
 __device__ __forceinline__ int dot2(s16x2 a, int klo, int khi, int acc) {
   return __builtin_amdgcn_sdot2(a, pk_const(klo, khi), acc, false);
 }
+// the same with a zero accumulator: the three-operand encoding takes the 0 inline (the
+// accumulate-in-place form the compiler picks would need a v_mov first)
+__device__ __forceinline__ int dot2z(s16x2 a, int klo, int khi) {
+  int d;
+  asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(d) : "v"(as_u32(a)), "s"(as_u32(pk_const(klo, khi))));
+  return d;
+}
 
 // Row transform of one row held as 4 packed pairs; 32-bit wrap-around accumulation like
 // src/fdct.cc:174-209 (and pmaddwd in its SSE2 twin).  acc[i] >> 16 is coefficient i of the row.
@@ -247,14 +255,14 @@ __device__ __forceinline__ void fdct_row8_pk(const uint32_t* row, int* acc) {
   const s16x2 r3 = pk_swap(as_pk(row[3])), r2 = pk_swap(as_pk(row[2]));
   const s16x2 A01 = p0 + r3, B01 = p0 - r3;       // (a0,a1), (b0,b1)
   const s16x2 A23 = p1 + r2, B23 = p1 - r2;       // (a2,a3), (b2,b3)
-  acc[0] = dot2(A23, C4, C4, dot2(A01, C4, C4, 0));
-  acc[4] = dot2(A23, -C4, C4, dot2(A01, C4, -C4, 0));
-  acc[2] = dot2(A23, -C6, -C2, dot2(A01, C2, C6, 0));
-  acc[6] = dot2(A23, C2, -C6, dot2(A01, C6, -C2, 0));
-  acc[1] = dot2(B23, C5, C7, dot2(B01, C1, C3, 0));
-  acc[3] = dot2(B23, -C1, -C5, dot2(B01, C3, -C7, 0));
-  acc[5] = dot2(B23, C7, C3, dot2(B01, C5, -C1, 0));
-  acc[7] = dot2(B23, C3, -C1, dot2(B01, C7, -C5, 0));
+  acc[0] = dot2(A23, C4, C4, dot2z(A01, C4, C4));
+  acc[4] = dot2(A23, -C4, C4, dot2z(A01, C4, -C4));
+  acc[2] = dot2(A23, -C6, -C2, dot2z(A01, C2, C6));
+  acc[6] = dot2(A23, C2, -C6, dot2z(A01, C6, -C2));
+  acc[1] = dot2(B23, C5, C7, dot2z(B01, C1, C3));
+  acc[3] = dot2(B23, -C1, -C5, dot2z(B01, C3, -C7));
+  acc[5] = dot2(B23, C7, C3, dot2z(B01, C5, -C1));
+  acc[7] = dot2(B23, C3, -C1, dot2z(B01, C7, -C5));
 }
 
 // D = a.u16[half] * b.u16[half] + c   (one VOP3 op on packed operands)
@@ -268,13 +276,23 @@ __device__ __forceinline__ uint32_t mad_u16_hi(uint32_t a, uint32_t b, uint32_t 
   asm("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[1,1,0,0]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
   return d;
 }
+// D = a.u16[0 or 1] * k + c with a uniform 16-bit multiplier k (scalar operand)
+__device__ __forceinline__ uint32_t mad_u16_lo_k(uint32_t a, uint32_t k, uint32_t c) {
+  uint32_t d;
+  asm("v_mad_u32_u16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(k), "v"(c));
+  return d;
+}
+__device__ __forceinline__ uint32_t mad_u16_hi_k(uint32_t a, uint32_t k, uint32_t c) {
+  uint32_t d;
+  asm("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(d) : "v"(a), "s"(k), "v"(c));
+  return d;
+}
 // D = a.u16[1] * b.u16[0] + c
 __device__ __forceinline__ uint32_t mad_u16_hl(uint32_t a, uint32_t b, uint32_t c) {
   uint32_t d;
   asm("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
   return d;
 }
-typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 // a.u16[0] * b.u16[0] + a.u16[1] * b.u16[1] + c, modulo 2^32
 __device__ __forceinline__ uint32_t udot2(uint32_t a, uint32_t b, uint32_t c) {
   return __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b), c, false);
@@ -302,8 +320,7 @@ __device__ constexpr int kInvZig(int j) {
 //   level = ((|c| + bias) * iquant) >> 20 == (|c|*iquant + bias*iquant) >> 20
 // The reference's qthresh test is implied: |c| >= qthresh <=> level > 0 (quantize.cc:144-145).
 template <int ROW, int C1, int C2, int C3, int C4, int C5, int C6, int C7>
-__device__ __forceinline__ void row_quant(const uint32_t* row, const uint4* qt, uint32_t* ent,
-                                          uint32_t& nz_lo, uint32_t& nz_hi) {
+__device__ __forceinline__ void row_quant(const uint32_t* row, const uint4* qt, uint32_t* ent, uint32_t* nzq) {
   int acc[8];
   fdct_row8_pk<C1, C2, C3, C4, C5, C6, C7>(row, acc);
 #pragma unroll
@@ -315,11 +332,15 @@ __device__ __forceinline__ void row_quant(const uint32_t* row, const uint4* qt, 
     const uint4 t = qt[4 * ROW + k];
     const uint32_t l0 = mad_u16_lo(ap, t.x, t.y) >> 20;
     const uint32_t l1 = mad_u16_hi(ap, t.x, t.z) >> 20;
-    ent[k] = (cp & 0x80008000u) | l0 | (l1 << 16);
+    const uint32_t lv = l0 | (l1 << 16);
+    ent[k] = (cp & 0x80008000u) | lv;
+    // non-zero flags: both at once (packed min), each dropped at its zig-zag position of the
+    // 16-bit mask of its quarter by one multiply-add (every position is written exactly once)
+    uint32_t f;                                   // (min(l0, 1), min(l1, 1))
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(f) : "v"(lv), "v"(0x00010001u));
     const int z0 = kInvZig(8 * ROW + 2 * k), z1 = kInvZig(8 * ROW + 2 * k + 1);   // folds after unroll
-    const uint32_t f0 = l0 < 1u ? l0 : 1u, f1 = l1 < 1u ? l1 : 1u;
-    if (z0 < 32) nz_lo |= f0 << z0; else nz_hi |= f0 << (z0 - 32);
-    if (z1 < 32) nz_lo |= f1 << z1; else nz_hi |= f1 << (z1 - 32);
+    nzq[z0 >> 4] = mad_u16_lo_k(f, 1u << (z0 & 15), nzq[z0 >> 4]);
+    nzq[z1 >> 4] = mad_u16_hi_k(f, 1u << (z1 & 15), nzq[z1 >> 4]);
   }
 }
 
@@ -802,21 +823,22 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
     for (int i = tid; i < kHistoWords; i += kScanThreads) dst[i] = lh[i];
     return;
   }
-  uint32_t nz_lo = 0, nz_hi = 0;
+  uint32_t nzq[4] = {0, 0, 0, 0};                   // non-zero masks of the four zig-zag quarters
   uint32_t ent[32];                             // natural order, 2 entries per dword
   {
     const uint4* qt = lq + tbl * 32;
     // cos(k*pi/16)/sqrt(2) tables, rows 1/7, 2/6, 3/5 pre-scaled (src/fdct.cc:28-35,599-606)
-    row_quant<0, 22725, 21407, 19266, 16384, 12873, 8867, 4520>(p[0], qt, ent + 0, nz_lo, nz_hi);
-    row_quant<1, 31521, 29692, 26722, 22725, 17855, 12299, 6270>(p[1], qt, ent + 4, nz_lo, nz_hi);
-    row_quant<2, 29692, 27969, 25172, 21407, 16819, 11585, 5906>(p[2], qt, ent + 8, nz_lo, nz_hi);
-    row_quant<3, 26722, 25172, 22654, 19266, 15137, 10426, 5315>(p[3], qt, ent + 12, nz_lo, nz_hi);
-    row_quant<4, 22725, 21407, 19266, 16384, 12873, 8867, 4520>(p[4], qt, ent + 16, nz_lo, nz_hi);
-    row_quant<5, 26722, 25172, 22654, 19266, 15137, 10426, 5315>(p[5], qt, ent + 20, nz_lo, nz_hi);
-    row_quant<6, 29692, 27969, 25172, 21407, 16819, 11585, 5906>(p[6], qt, ent + 24, nz_lo, nz_hi);
-    row_quant<7, 31521, 29692, 26722, 22725, 17855, 12299, 6270>(p[7], qt, ent + 28, nz_lo, nz_hi);
+    row_quant<0, 22725, 21407, 19266, 16384, 12873, 8867, 4520>(p[0], qt, ent + 0, nzq);
+    row_quant<1, 31521, 29692, 26722, 22725, 17855, 12299, 6270>(p[1], qt, ent + 4, nzq);
+    row_quant<2, 29692, 27969, 25172, 21407, 16819, 11585, 5906>(p[2], qt, ent + 8, nzq);
+    row_quant<3, 26722, 25172, 22654, 19266, 15137, 10426, 5315>(p[3], qt, ent + 12, nzq);
+    row_quant<4, 22725, 21407, 19266, 16384, 12873, 8867, 4520>(p[4], qt, ent + 16, nzq);
+    row_quant<5, 26722, 25172, 22654, 19266, 15137, 10426, 5315>(p[5], qt, ent + 20, nzq);
+    row_quant<6, 29692, 27969, 25172, 21407, 16819, 11585, 5906>(p[6], qt, ent + 24, nzq);
+    row_quant<7, 31521, 29692, 26722, 22725, 17855, 12299, 6270>(p[7], qt, ent + 28, nzq);
   }
-  nz_lo &= ~1u;                                 // DC is coded separately
+  nzq[0] &= ~1u;                                // DC is coded separately
+  const uint32_t nz_lo = nzq[0] | (nzq[1] << 16), nz_hi = nzq[2] | (nzq[3] << 16);
   const int dc_mag = static_cast<int>(ent[0] & 0x7fffu);
   const int dc_val = (ent[0] & 0x8000u) ? -dc_mag : dc_mag;
   // zig-zag reorder with byte permutes, 4 entries per ds_write_b64
@@ -920,8 +942,8 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
   uint16_t* const ulist = reinterpret_cast<uint16_t*>(win + 64);          // [1024] block | quarter << 8
   uint16_t* const ulen = reinterpret_cast<uint16_t*>(win + 64 + 512);     // [256][4] bits per part
   {
-    uint32_t c[4] = {static_cast<uint32_t>(__popc(nz_lo & 0xffffu)), static_cast<uint32_t>(__popc(nz_lo >> 16)),
-                     static_cast<uint32_t>(__popc(nz_hi & 0xffffu)), static_cast<uint32_t>(__popc(nz_hi >> 16))};
+    uint32_t c[4] = {static_cast<uint32_t>(__popc(nzq[0])), static_cast<uint32_t>(__popc(nzq[1])),
+                     static_cast<uint32_t>(__popc(nzq[2])), static_cast<uint32_t>(__popc(nzq[3]))};
     if (tid < 32) hist[tid] = 0;
     *reinterpret_cast<uint2*>(ulen + 4 * tid) = make_uint2(0u, 0u);
     __syncthreads();
