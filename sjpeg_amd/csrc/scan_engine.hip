@@ -1288,6 +1288,8 @@ __device__ __forceinline__ uint32_t count_ff(uint32_t w, int nbytes /*valid lead
 
 __global__ __launch_bounds__(kThreads) void concat_chunks(const StitchArgs a) {
   __shared__ uint32_t red[8];
+  __shared__ unsigned long long loff[kThreads + 1];
+  __shared__ int seg0;
   const int frame = blockIdx.y;
   const unsigned long long* off = a.seg_off + static_cast<size_t>(frame) * (a.nseg + 1);
   const unsigned long long T = off[a.nseg];                 // total bits
@@ -1299,21 +1301,52 @@ __global__ __launch_bounds__(kThreads) void concat_chunks(const StitchArgs a) {
     const unsigned long long w0 = static_cast<unsigned long long>(chunk) * kChunkWords + threadIdx.x * 4;
     unsigned long long pos = w0 * 32;
     uint32_t ffs = 0;
-    if (pos < U * 8) {
-      // segment containing bit `pos`: largest s with off[s] <= pos.  Segments have similar
-      // lengths, so interpolate and walk a few steps; bisect only if the guess is far off.
-      int s = static_cast<int>(static_cast<float>(pos) / static_cast<float>(T) * static_cast<float>(a.nseg));
+    // The segment holding the chunk's first bit is found ONCE per workgroup; the offsets that
+    // follow it are staged in LDS (a chunk spans a couple of segments, seldom more than a few
+    // dozen), so that the per-thread search never chains global loads.
+    if (threadIdx.x == 0) {
+      const unsigned long long p0 = static_cast<unsigned long long>(chunk) * kChunkWords * 32;
+      int lo = 0, hi = a.nseg - 1;
+      int s = static_cast<int>(static_cast<float>(p0) / static_cast<float>(T) * static_cast<float>(a.nseg));
       s = min(max(s, 0), a.nseg - 1);
       int steps = 0;
-      while (steps < 6 && off[s] > pos) { --s; ++steps; }
-      while (steps < 6 && off[s + 1] <= pos) { ++s; ++steps; }
-      if (off[s] > pos || off[s + 1] <= pos) {
-        int lo = 0, hi = a.nseg - 1;
+      while (steps < 6 && off[s] > p0) { --s; ++steps; }
+      while (steps < 6 && s < a.nseg - 1 && off[s + 1] <= p0) { ++s; ++steps; }
+      if (off[s] > p0 || (s < a.nseg - 1 && off[s + 1] <= p0)) {
         while (lo < hi) {
           const int mid = (lo + hi + 1) >> 1;
-          if (off[mid] <= pos) lo = mid; else hi = mid - 1;
+          if (off[mid] <= p0) lo = mid; else hi = mid - 1;
         }
         s = lo;
+      }
+      seg0 = s;
+    }
+    __syncthreads();
+    const int sbase = seg0;
+    const int nstaged = min(kThreads + 1, a.nseg + 1 - sbase);            // offsets sbase .. sbase + nstaged - 1
+    for (int i = threadIdx.x; i < nstaged; i += kThreads) loff[i] = off[sbase + i];
+    __syncthreads();
+    if (pos < U * 8) {
+      // segment containing bit `pos`: largest s with off[s] <= pos
+      int s;
+      {
+        int lo = 0, hi = nstaged - 1;                                       // loff[lo] <= pos always
+        if (loff[hi] <= pos) {
+          // beyond the staged window (thousands of near-empty segments): global bisection
+          int glo = sbase + hi, ghi = a.nseg - 1;
+          while (glo < ghi) {
+            const int mid = (glo + ghi + 1) >> 1;
+            if (off[mid] <= pos) glo = mid; else ghi = mid - 1;
+          }
+          s = glo;
+        } else {
+          while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (loff[mid] <= pos) lo = mid; else hi = mid;
+          }
+          s = sbase + lo;
+        }
+        s = min(s, a.nseg - 1);                                           // pos in the final padding
       }
       unsigned long long s_beg = off[s], s_end = off[s + 1];
       uint32_t words[4];
