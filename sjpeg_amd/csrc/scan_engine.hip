@@ -1272,10 +1272,15 @@ __global__ __launch_bounds__(kThreads) void scan_seg_offsets(const StitchArgs a)
     running += total;
   }
   if (threadIdx.x == 0) off[a.nseg] = running;
+  // K3 accumulates the 0xFF counts of the chunks with atomics: clear the ones this frame uses
+  const unsigned long long U = (running + 7) >> 3;
+  const uint32_t nchunks = static_cast<uint32_t>((U + kChunkBytes - 1) / kChunkBytes);
+  uint32_t* ff = a.chunk_ff + static_cast<size_t>(frame) * a.max_chunks;
+  for (uint32_t i = threadIdx.x; i < nchunks; i += kThreads) ff[i] = 0;
 }
 
 // ------------------------------------------------------------------------------------
-// K3: gather the continuous bit stream, 4 KiB chunks, and count 0xFF bytes
+// K3: place every segment in the continuous bit stream, and count 0xFF bytes per 4 KiB chunk
 
 __device__ __forceinline__ uint32_t count_ff(uint32_t w, int nbytes /*valid leading bytes, MSB first*/) {
   uint32_t n = 0;
@@ -1286,122 +1291,103 @@ __device__ __forceinline__ uint32_t count_ff(uint32_t w, int nbytes /*valid lead
   return n;
 }
 
-__global__ __launch_bounds__(kThreads) void concat_chunks(const StitchArgs a) {
-  __shared__ uint32_t red[8];
-  __shared__ unsigned long long loff[kThreads + 1];
-  __shared__ int seg0;
-  const int frame = blockIdx.y;
+// One WAVE per SEGMENT (scatter form): a segment knows where its bits go (seg_off); its
+// words are read coalesced, funnel-shifted to the destination alignment, and every word of the
+// continuous stream whose FIRST bit lies inside the segment is written.  Only the last of those
+// words needs bits of the following segment(s), or the final 1-bit padding
+// (src/bit_writer.cc:107-116).  0xFF bytes are counted per 4 KiB chunk of the stream (atomics;
+// cleared by K2).
+// The kernel is latency-bound by construction (a few KB per workgroup), so the dependent chain
+// is cut to ONE round trip: destination word i always needs source words i and i + 1 whatever
+// the offset (only the shift depends on it), so the first kSpec batches of source words are
+// requested before the offsets have arrived.  Earlier forms (a workgroup per 4 KiB chunk with a
+// search; per group of segments) spent 35-50 us in chains of 3-5 dependent loads.
+constexpr int kSpec = 12;                                   // speculative batches of 64 words: segments up to 3 KiB
+constexpr int kPlaceLanes = 64;                             // one WAVE per segment, four segments per workgroup
+__global__ __launch_bounds__(kThreads) void place_segments(const StitchArgs a) {
+  const int frame = blockIdx.y, sc0 = blockIdx.x * (kThreads / kPlaceLanes) + (threadIdx.x >> 6);
+  if (sc0 >= a.nseg) return;
   const unsigned long long* off = a.seg_off + static_cast<size_t>(frame) * (a.nseg + 1);
+  const uint32_t* segw = a.seg_words + static_cast<size_t>(frame) * a.nseg * a.slot_words;
+  const uint32_t* src = segw + static_cast<size_t>(sc0) * a.slot_words;
+  uint32_t spec[kSpec][2];
+#pragma unroll
+  for (int k = 0; k < kSpec; ++k) {                          // inside the slot whatever the length
+    const uint32_t i = k * kPlaceLanes + (threadIdx.x & 63);
+    spec[k][0] = src[i];
+    spec[k][1] = src[i + 1];
+  }
+  const unsigned long long b0 = off[sc0], b1 = off[sc0 + 1];
   const unsigned long long T = off[a.nseg];                 // total bits
   const unsigned long long U = (T + 7) >> 3;                // bytes incl. 1-bit padding
-  const uint32_t nchunks = static_cast<uint32_t>((U + kChunkBytes - 1) / kChunkBytes);
-  const uint32_t* segw = a.seg_words + static_cast<size_t>(frame) * a.nseg * a.slot_words;
   uint32_t* ub = a.ubuf + static_cast<size_t>(frame) * a.ubuf_words;
-  for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
-    const unsigned long long w0 = static_cast<unsigned long long>(chunk) * kChunkWords + threadIdx.x * 4;
-    unsigned long long pos = w0 * 32;
+  uint32_t* cff = a.chunk_ff + static_cast<size_t>(frame) * a.max_chunks;
+  const int lane = threadIdx.x & 63;
+  const unsigned long long wbeg = (b0 + 31) >> 5;
+  const unsigned long long wend = (sc0 == a.nseg - 1) ? ((U + 3) >> 2) : ((b1 + 31) >> 5);
+  const uint32_t nwords = static_cast<uint32_t>(wend - wbeg);
+  const uint32_t lead = static_cast<uint32_t>(wbeg * 32 - b0);           // bits of the segment in front of word wbeg (< 32)
+  const uint32_t len = static_cast<uint32_t>(b1 - b0);
+  uint32_t* dst = ub + wbeg;
+  const uint32_t wbase = static_cast<uint32_t>(wbeg);                     // < 2^32 words per frame
+  uint32_t ff_acc = 0;                                      // 0xFF bytes seen by this lane in chunk ff_chunk
+  uint32_t ff_chunk = 0xffffffffu;                          // wave-uniform
+  auto ff_flush = [&]() {
+    uint32_t sum = ff_acc;
+    for (int d = 32; d > 0; d >>= 1) sum += __shfl_down(sum, d, 64);
+    if (lane == 0 && sum != 0u) atomicAdd(&cff[ff_chunk], sum);
+    ff_acc = 0;
+  };
+  auto one = [&](uint32_t i, uint32_t v0, uint32_t v1) {
     uint32_t ffs = 0;
-    // The segment holding the chunk's first bit is found ONCE per workgroup; the offsets that
-    // follow it are staged in LDS (a chunk spans a couple of segments, seldom more than a few
-    // dozen), so that the per-thread search never chains global loads.
-    if (threadIdx.x == 0) {
-      const unsigned long long p0 = static_cast<unsigned long long>(chunk) * kChunkWords * 32;
-      int lo = 0, hi = a.nseg - 1;
-      int s = static_cast<int>(static_cast<float>(p0) / static_cast<float>(T) * static_cast<float>(a.nseg));
-      s = min(max(s, 0), a.nseg - 1);
-      int steps = 0;
-      while (steps < 6 && off[s] > p0) { --s; ++steps; }
-      while (steps < 6 && s < a.nseg - 1 && off[s + 1] <= p0) { ++s; ++steps; }
-      if (off[s] > p0 || (s < a.nseg - 1 && off[s + 1] <= p0)) {
-        while (lo < hi) {
-          const int mid = (lo + hi + 1) >> 1;
-          if (off[mid] <= p0) lo = mid; else hi = mid - 1;
-        }
-        s = lo;
-      }
-      seg0 = s;
-    }
-    __syncthreads();
-    const int sbase = seg0;
-    const int nstaged = min(kThreads + 1, a.nseg + 1 - sbase);            // offsets sbase .. sbase + nstaged - 1
-    for (int i = threadIdx.x; i < nstaged; i += kThreads) loff[i] = off[sbase + i];
-    __syncthreads();
-    if (pos < U * 8) {
-      // segment containing bit `pos`: largest s with off[s] <= pos
-      int s;
-      {
-        int lo = 0, hi = nstaged - 1;                                       // loff[lo] <= pos always
-        if (loff[hi] <= pos) {
-          // beyond the staged window (thousands of near-empty segments): global bisection
-          int glo = sbase + hi, ghi = a.nseg - 1;
-          while (glo < ghi) {
-            const int mid = (glo + ghi + 1) >> 1;
-            if (off[mid] <= pos) glo = mid; else ghi = mid - 1;
-          }
-          s = glo;
-        } else {
-          while (hi - lo > 1) {
-            const int mid = (lo + hi) >> 1;
-            if (loff[mid] <= pos) lo = mid; else hi = mid;
-          }
-          s = sbase + lo;
-        }
-        s = min(s, a.nseg - 1);                                           // pos in the final padding
-      }
-      unsigned long long s_beg = off[s], s_end = off[s + 1];
-      uint32_t words[4];
-      if (pos + 128 <= s_end) {
-        // common case: the 128 bits come from ONE segment -> five source words, funnel shifts
-        const uint32_t r = static_cast<uint32_t>(pos - s_beg);
-        const uint32_t* src = segw + static_cast<size_t>(s) * a.slot_words + (r >> 5);
-        const uint32_t sh = r & 31u;
-        uint32_t v[5];
-#pragma unroll
-        for (int j = 0; j < 5; ++j) v[j] = src[j];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          words[j] = __builtin_amdgcn_alignbit(v[j], v[j + 1], 32u - sh);   // (v[j]:v[j+1]) >> (32 - sh)
-          if (sh == 0) words[j] = v[j];
-          ffs += count_ff(words[j], 4);
-        }
-        pos += 128;
-      } else
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        uint32_t outw = 0;
-        int need = 32;
-        while (need > 0 && pos < T) {
-          while (pos >= s_end) { ++s; s_beg = s_end; s_end = off[s + 1]; }
-          const unsigned long long avail = s_end - pos;
+    if (i < nwords) {
+      const uint32_t r = lead + 32u * i;                                  // first source bit of this word
+      uint32_t outw;
+      if (r + 32u <= len) {
+        outw = lead ? __builtin_amdgcn_alignbit(v0, v1, 32u - lead) : v0;   // (v0:v1) >> (32 - lead)
+      } else {
+        // the word that runs over the end of the segment: finish it from the next ones
+        outw = 0;
+        int need = 32, sc = sc0;
+        unsigned long long p = (wbeg + i) * 32, c_beg = b0, c_end = b1;
+        while (need > 0 && p < T) {
+          while (p >= c_end) { ++sc; c_beg = c_end; c_end = off[sc + 1]; }
+          const unsigned long long avail = c_end - p;
           const int take = avail < static_cast<unsigned long long>(need) ? static_cast<int>(avail) : need;
-          const uint32_t r = static_cast<uint32_t>(pos - s_beg);
-          const uint32_t* p = segw + static_cast<size_t>(s) * a.slot_words + (r >> 5);
-          const unsigned long long two = (static_cast<unsigned long long>(p[0]) << 32) | p[1];
-          const uint32_t bits = static_cast<uint32_t>((two << (r & 31)) >> (64 - take));
+          const uint32_t rr = static_cast<uint32_t>(p - c_beg);
+          const uint32_t* q = segw + static_cast<size_t>(sc) * a.slot_words + (rr >> 5);
+          const unsigned long long two = (static_cast<unsigned long long>(q[0]) << 32) | q[1];
+          const uint32_t bits = static_cast<uint32_t>((two << (rr & 31)) >> (64 - take));
           outw |= bits << (need - take);
           need -= take;
-          pos += take;
+          p += take;
         }
-        if (need > 0) {                                    // past the end: pad with 1-bits
-          outw |= (need == 32) ? 0xffffffffu : ((1u << need) - 1u);
-          pos += need;
-        }
-        words[j] = outw;
-        const unsigned long long byte0 = (w0 + j) * 4;
-        const int valid = byte0 >= U ? 0 : (U - byte0 >= 4 ? 4 : static_cast<int>(U - byte0));
-        ffs += count_ff(outw, valid);
+        if (need > 0) outw |= (need == 32) ? 0xffffffffu : ((1u << need) - 1u);   // past the end: 1-bits
       }
-      *reinterpret_cast<uint4*>(ub + w0) = make_uint4(words[0], words[1], words[2], words[3]);
+      dst[i] = outw;
+      const unsigned long long byte0 = (wbeg + i) * 4;
+      const int valid = byte0 >= U ? 0 : (U - byte0 >= 4 ? 4 : static_cast<int>(U - byte0));
+      ffs = count_ff(outw, valid);
     }
-    // workgroup sum of 0xFF counts
-    for (int d = 32; d > 0; d >>= 1) ffs += __shfl_down(ffs, d, 64);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ffs;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      a.chunk_ff[static_cast<size_t>(frame) * a.max_chunks + chunk] = red[0] + red[1] + red[2] + red[3];
+    // the 64 words of a wave sit in one chunk unless they straddle a boundary
+    const uint32_t chunk = (wbase + i) >> 10;
+    const uint32_t chunk0 = __builtin_amdgcn_readfirstlane(chunk);
+    if (chunk0 != ff_chunk) {                                // uniform
+      if (ff_chunk != 0xffffffffu) ff_flush();
+      ff_chunk = chunk0;
     }
-    __syncthreads();
+    if (chunk == chunk0) ff_acc += ffs;
+    else if (ffs != 0u) atomicAdd(&cff[chunk], ffs);
+  };
+#pragma unroll
+  for (int k = 0; k < kSpec; ++k) {
+    if (static_cast<uint32_t>(k) * kPlaceLanes < nwords) one(k * kPlaceLanes + lane, spec[k][0], spec[k][1]);
   }
+  for (uint32_t i0 = kSpec * kPlaceLanes; i0 < nwords; i0 += kPlaceLanes) {
+    const uint32_t i = i0 + lane;
+    one(i, src[i], src[i + 1]);
+  }
+  if (ff_chunk != 0xffffffffu) ff_flush();
 }
 
 // ------------------------------------------------------------------------------------
@@ -1962,7 +1948,7 @@ int sjpeg_hip_encode_scan_src(sjpeg_hip_engine* e, const sjpeg_hip_source* src, 
   uint32_t gx = 4096u / static_cast<uint32_t>(nframes);
   if (gx < 64) gx = 64;
   if (gx > max_chunks) gx = max_chunks;
-  hipLaunchKernelGGL(concat_chunks, dim3(gx, nframes), dim3(kThreads), 0, st, s);
+  hipLaunchKernelGGL(place_segments, dim3((g.nseg + 3) / 4, nframes), dim3(kThreads), 0, st, s);
   HIP_TRY(hipGetLastError());
   hipLaunchKernelGGL(scan_chunk_offsets, dim3(nframes), dim3(kThreads), 0, st, s);
   HIP_TRY(hipGetLastError());
