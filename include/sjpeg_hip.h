@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SJPEG_HIP_ABI_VERSION 2
+#define SJPEG_HIP_ABI_VERSION 3
 
 enum {
   SJPEG_HIP_OK = 0,
@@ -182,6 +182,31 @@ int sjpeg_hip_scan_quant_error_src(sjpeg_hip_engine* engine, const struct sjpeg_
  * Synchronises the device.  With the coded size this gives what the reference's BitCounter
  * reports (src/bit_writer.h:292-365). */
 int sjpeg_hip_engine_entropy_bits(sjpeg_hip_engine* engine, uint64_t* bits, int nframes);
+
+/* ---- one frame over several GPUs ------------------------------------------
+ * The reference codes a frame as ONE entropy segment (src/enc.cc:276-307; no restart markers,
+ * src/sjpegi.h:68-74), so a frame can only be shared between devices at BIT granularity.  The
+ * engine's unit of independent work is the segment (a fixed number of consecutive MCUs in scan
+ * order); sjpeg_hip_segment_count() says how many a frame has.  Rank r of P codes the band of
+ * segments [r*n/P, (r+1)*n/P): it needs the pixel rows of those MCUs plus the one MCU in front of
+ * the band (DC predictors; `src` is addressed as the whole frame, rows outside are not read).
+ * It gets the band's un-stuffed bit string (MSB-first 32-bit words) and its length in bits.  The
+ * root gathers strings and lengths (RCCL gather / send-recv), and sjpeg_hip_stitch_bands() shifts
+ * every band to its bit offset, pads with 1-bits, stuffs 0xFF bytes, adds header and EOI: the
+ * bytes of sjpeg_hip_encode_scan_src() on one device, i.e. of the reference. */
+int sjpeg_hip_segment_count(int width, int height, int yuv_mode);
+/* capacity in 32-bit words a band buffer must have (0 on bad arguments) */
+size_t sjpeg_hip_band_bound(int width, int height, int yuv_mode, int seg_begin, int seg_end);
+int sjpeg_hip_encode_band_src(sjpeg_hip_engine* engine, const sjpeg_hip_source* src,
+                              int width, int height, int yuv_mode,
+                              const sjpeg_hip_scan_tables* tables, int seg_begin, int seg_end,
+                              uint32_t* d_words, size_t cap_words, uint64_t* d_nbits, void* stream);
+/* d_words: nbands buffers of band_stride_words words each, in band order (device memory of
+ * `engine`'s device); d_nbits[nbands]; the rest as sjpeg_hip_encode_scan() for one frame. */
+int sjpeg_hip_stitch_bands(sjpeg_hip_engine* engine, int nbands, const uint32_t* d_words,
+                           size_t band_stride_words, const uint64_t* d_nbits,
+                           const void* header, size_t header_size, int append_eoi,
+                           void* d_out, size_t out_cap, uint64_t* d_size, void* stream);
 
 /* The same four operations for any pixel source (the functions above are these with
  * format = SJPEG_HIP_SRC_RGB).  yuv_mode must match the source where it is implied. */

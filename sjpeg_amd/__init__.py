@@ -42,6 +42,20 @@ class Source(C.Structure):
                 ("row_stride", C.c_int64 * 3), ("frame_stride", C.c_int64 * 3)]
 
 
+def segment_count(w, h, yuv_mode):
+    n = lib().sjpeg_hip_segment_count(w, h, yuv_mode)
+    if n <= 0:
+        raise SjpegError("sjpeg_hip_segment_count: " + lib().sjpeg_hip_last_error().decode())
+    return n
+
+
+def band_bound(w, h, yuv_mode, seg_begin, seg_end):
+    n = lib().sjpeg_hip_band_bound(w, h, yuv_mode, seg_begin, seg_end)
+    if n == 0:
+        raise SjpegError("sjpeg_hip_band_bound: bad arguments")
+    return n
+
+
 def make_source(fmt, planes):
     """planes: CUDA uint8 tensors [F, rows, row_bytes] (one per plane of the layout).
     Returns (Source, nframes); the tensors must outlive the calls that use it."""
@@ -139,6 +153,13 @@ def lib() -> C.CDLL:
     L.sjpeg_hip_scan_quant_error_src.argtypes = [C.c_void_p, srcp, C.c_int, C.c_int, C.c_int, C.c_int,
                                                  C.POINTER(ScanTables), C.c_void_p, C.c_void_p]
     L.sjpeg_hip_engine_entropy_bits.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    L.sjpeg_hip_segment_count.argtypes = [C.c_int, C.c_int, C.c_int]
+    L.sjpeg_hip_band_bound.restype = C.c_size_t
+    L.sjpeg_hip_band_bound.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.sjpeg_hip_encode_band_src.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                            C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    L.sjpeg_hip_stitch_bands.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_char_p,
+                                         C.c_size_t, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
     L.sjpeg_hip_adapt_quant.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                         C.c_int, C.c_int, C.POINTER(ScanTables)]
     L.sjpeg_hip_optimize_huffman.argtypes = [C.c_void_p, C.c_int, C.POINTER(HuffmanSpec),
@@ -168,6 +189,7 @@ EXPORTED_C_SYMBOLS = [
     "sjpeg_hip_encode_scan_src", "sjpeg_hip_scan_coeffs_src", "sjpeg_hip_scan_histogram_src",
     "sjpeg_hip_scan_symbol_stats_src", "sjpeg_hip_scan_quant_error_src", "sjpeg_hip_engine_entropy_bits",
     "sjpeg_hip_optimize_huffman", "sjpeg_hip_make_header_ex",
+    "sjpeg_hip_segment_count", "sjpeg_hip_band_bound", "sjpeg_hip_encode_band_src", "sjpeg_hip_stitch_bands",
     "sjpeg_hip_engine_set_timing", "sjpeg_hip_engine_last_scan_ms",
     "sjpeg_hip_engine_last_total_ms",
 ]
@@ -368,6 +390,39 @@ class Engine:
                                                        C.byref(tables), out.data_ptr(), self._stream()),
                   "sjpeg_hip_scan_quant_error_src")
         return out
+
+    def encode_band(self, src: Source, w, h, tables: ScanTables, yuv_mode, seg_begin, seg_end,
+                    cap_words=None, device="cuda"):
+        """One band of a frame shared between GPUs (include/sjpeg_hip.h): un-stuffed bit string
+        (int32 tensor of MSB-first words) + its length in bits (int64 tensor [1])."""
+        import torch
+        need = band_bound(w, h, yuv_mode, seg_begin, seg_end)
+        cap_words = need if cap_words is None else cap_words
+        words = torch.zeros(cap_words, dtype=torch.int32, device=device)
+        nbits = torch.zeros(1, dtype=torch.int64, device=device)
+        self._chk(lib().sjpeg_hip_encode_band_src(self._h, C.byref(src), w, h, yuv_mode, C.byref(tables),
+                                                  seg_begin, seg_end, words.data_ptr(), cap_words,
+                                                  nbits.data_ptr(), self._stream()),
+                  "sjpeg_hip_encode_band_src")
+        return words, nbits
+
+    def stitch_bands(self, words, nbits, header: bytes, append_eoi=True, out_cap=None):
+        """words [nbands, stride] int32, nbits [nbands] int64 (this engine's device) -> JPEG bytes."""
+        import torch
+        assert words.dim() == 2 and words.is_contiguous() and nbits.numel() == words.shape[0]
+        nb, stride = words.shape
+        if out_cap is None:
+            out_cap = len(header) + 2 * 4 * nb * stride + 4096
+        out = torch.empty(out_cap, dtype=torch.uint8, device=words.device)
+        size = torch.zeros(1, dtype=torch.int64, device=words.device)
+        self._chk(lib().sjpeg_hip_stitch_bands(self._h, nb, words.data_ptr(), stride, nbits.data_ptr(),
+                                               header, len(header), int(append_eoi), out.data_ptr(),
+                                               out_cap, size.data_ptr(), self._stream()),
+                  "sjpeg_hip_stitch_bands")
+        n = int(size.item())
+        if n == 0:
+            raise SjpegError("sjpeg_hip_stitch_bands: output buffer too small")
+        return bytes(out[:n].cpu().numpy())
 
     def entropy_bits(self, nframes):
         bits = np.zeros(nframes, np.uint64)

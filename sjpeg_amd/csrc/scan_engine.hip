@@ -82,6 +82,7 @@ struct ScanArgs {
   int rsh, bsh;                 // kSrcRgbx32: bit position of R and B inside a pixel dword (0 / 16)
   int cstep, uoff, voff;        // kSrcPlanes: bytes per chroma sample (2 = interleaved) and U/V offsets
   int W, H, mb_w, n_mcus, nseg, has_clip;
+  int seg_first;                // band mode: frame-level index of this launch's segment 0
   const DevTables* tables;
   uint32_t* seg_words;     // [nframes*nseg][slot_words]
   uint32_t slot_words;
@@ -537,7 +538,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
     }
   };
   stamp(0);
-  const int m_first = seg * G::kSegMcus;                       // first coded MCU of the segment
+  const int m_first = (seg + a.seg_first) * G::kSegMcus;       // first coded MCU of the segment
   const int n_coded = min(G::kSegMcus, a.n_mcus - m_first);
   const int halo = m_first > 0 ? 1 : 0;                        // previous MCU: DC predictors only
   const uint8_t* const frame_px = a.plane[0] + frame * a.frame_stride[0];
@@ -1255,6 +1256,9 @@ struct StitchArgs {
   uint8_t* out;
   size_t out_stride;
   unsigned long long* sizes;
+  const unsigned long long* seg_nbits64;   // band stitch: lengths as uint64 (else NULL)
+  unsigned long long* total_bits_out;      // band encode: where the bit count of the band goes (else NULL)
+  uint32_t subs;                           // K3: waves per segment (1 unless segments are whole bands)
 };
 
 __global__ __launch_bounds__(kThreads) void scan_seg_offsets(const StitchArgs a) {
@@ -1265,13 +1269,19 @@ __global__ __launch_bounds__(kThreads) void scan_seg_offsets(const StitchArgs a)
   unsigned long long running = 0;
   for (int base = 0; base < a.nseg; base += kThreads) {
     const int i = base + threadIdx.x;
-    const uint32_t x = i < a.nseg ? nb[i] : 0u;
+    // (a band is shorter than 2^32 bits: sjpeg_hip_stitch_bands checks its capacity)
+    const uint32_t x = i >= a.nseg ? 0u
+                     : a.seg_nbits64 != nullptr ? static_cast<uint32_t>(a.seg_nbits64[static_cast<size_t>(frame) * a.nseg + i])
+                                                : nb[i];
     uint32_t total;
     const uint32_t ex = wg_exclusive_scan<kThreads>(x, scratch, &total);
     if (i < a.nseg) off[i] = running + ex;
     running += total;
   }
-  if (threadIdx.x == 0) off[a.nseg] = running;
+  if (threadIdx.x == 0) {
+    off[a.nseg] = running;
+    if (a.total_bits_out != nullptr) a.total_bits_out[frame] = running;
+  }
   // K3 accumulates the 0xFF counts of the chunks with atomics: clear the ones this frame uses
   const unsigned long long U = (running + 7) >> 3;
   const uint32_t nchunks = static_cast<uint32_t>((U + kChunkBytes - 1) / kChunkBytes);
@@ -1305,7 +1315,12 @@ __device__ __forceinline__ uint32_t count_ff(uint32_t w, int nbytes /*valid lead
 constexpr int kSpec = 12;                                   // speculative batches of 64 words: segments up to 3 KiB
 constexpr int kPlaceLanes = 64;                             // one WAVE per segment, four segments per workgroup
 __global__ __launch_bounds__(kThreads) void place_segments(const StitchArgs a) {
-  const int frame = blockIdx.y, sc0 = blockIdx.x * (kThreads / kPlaceLanes) + (threadIdx.x >> 6);
+  const int frame = blockIdx.y;
+  // a wave takes words [sub * kSpec * 64, ...) of one segment; normal segments have one wave
+  // (subs == 1, the loop below takes the rare longer rest), whole bands are cut into many
+  const uint32_t unit = blockIdx.x * (kThreads / kPlaceLanes) + (threadIdx.x >> 6);
+  const int sc0 = static_cast<int>(unit / a.subs);
+  const uint32_t ibase = (unit % a.subs) * (kSpec * kPlaceLanes);
   if (sc0 >= a.nseg) return;
   const unsigned long long* off = a.seg_off + static_cast<size_t>(frame) * (a.nseg + 1);
   const uint32_t* segw = a.seg_words + static_cast<size_t>(frame) * a.nseg * a.slot_words;
@@ -1313,7 +1328,7 @@ __global__ __launch_bounds__(kThreads) void place_segments(const StitchArgs a) {
   uint32_t spec[kSpec][2];
 #pragma unroll
   for (int k = 0; k < kSpec; ++k) {                          // inside the slot whatever the length
-    const uint32_t i = k * kPlaceLanes + (threadIdx.x & 63);
+    const uint32_t i = min(ibase + k * kPlaceLanes + (threadIdx.x & 63), a.slot_words - 2u);
     spec[k][0] = src[i];
     spec[k][1] = src[i + 1];
   }
@@ -1381,11 +1396,13 @@ __global__ __launch_bounds__(kThreads) void place_segments(const StitchArgs a) {
   };
 #pragma unroll
   for (int k = 0; k < kSpec; ++k) {
-    if (static_cast<uint32_t>(k) * kPlaceLanes < nwords) one(k * kPlaceLanes + lane, spec[k][0], spec[k][1]);
+    if (ibase + static_cast<uint32_t>(k) * kPlaceLanes < nwords) one(ibase + k * kPlaceLanes + lane, spec[k][0], spec[k][1]);
   }
-  for (uint32_t i0 = kSpec * kPlaceLanes; i0 < nwords; i0 += kPlaceLanes) {
-    const uint32_t i = i0 + lane;
-    one(i, src[i], src[i + 1]);
+  if (a.subs == 1u) {
+    for (uint32_t i0 = kSpec * kPlaceLanes; i0 < nwords; i0 += kPlaceLanes) {
+      const uint32_t i = i0 + lane;
+      one(i, src[i], src[i + 1]);
+    }
   }
   if (ff_chunk != 0xffffffffu) ff_flush();
 }
@@ -1677,6 +1694,7 @@ int prepare_scan(sjpeg_hip_engine* e, const sjpeg_hip_source* src,
   digest_tables(tables, &host_tables);
   HIP_TRY(hipMemcpyAsync(e->tables.p, &host_tables, sizeof(DevTables), hipMemcpyHostToDevice, st));
   a->W = W; a->H = H; a->mb_w = g->mb_w; a->n_mcus = g->n_mcus; a->nseg = g->nseg;
+  a->seg_first = 0;
   a->has_clip = (W % g->px != 0) || (H % g->px != 0);
   a->tables = e->tables.p;
   a->seg_words = e->seg_words.p;
@@ -1937,6 +1955,7 @@ int sjpeg_hip_encode_scan_src(sjpeg_hip_engine* e, const sjpeg_hip_source* src, 
   s.append_eoi = append_eoi;
   s.out = static_cast<uint8_t*>(d_out); s.out_stride = out_stride;
   s.sizes = reinterpret_cast<unsigned long long*>(d_sizes);
+  s.seg_nbits64 = nullptr; s.total_bits_out = nullptr; s.subs = 1;
 
   if (e->timing) HIP_TRY(hipEventRecord(e->ev[0], st));
   if ((rc = launch_scan<kKindEncode>(yuv_mode, cls, dim3(g.nseg, nframes), st, a))) return rc;
@@ -1958,6 +1977,113 @@ int sjpeg_hip_encode_scan_src(sjpeg_hip_engine* e, const sjpeg_hip_source* src, 
     HIP_TRY(hipEventRecord(e->ev[2], st));
     e->ev_valid = true;
   }
+  return 0;
+}
+
+// ---- one frame over several GPUs: bands of consecutive segments ----------
+
+int sjpeg_hip_segment_count(int width, int height, int yuv_mode) {
+  FrameGeo g;
+  if (!frame_geo(width, height, yuv_mode, &g)) return fail(SJPEG_HIP_EINVAL, "bad geometry / yuv_mode");
+  return g.nseg;
+}
+
+size_t sjpeg_hip_band_bound(int width, int height, int yuv_mode, int seg_begin, int seg_end) {
+  FrameGeo g;
+  if (!frame_geo(width, height, yuv_mode, &g)) return 0;
+  if (seg_begin < 0 || seg_end > g.nseg || seg_begin >= seg_end) return 0;
+  return (static_cast<size_t>(seg_end - seg_begin) * g.slot_words + kChunkWords + 3) & ~size_t(3);
+}
+
+int sjpeg_hip_encode_band_src(sjpeg_hip_engine* e, const sjpeg_hip_source* src, int width, int height,
+                              int yuv_mode, const sjpeg_hip_scan_tables* tables, int seg_begin,
+                              int seg_end, uint32_t* d_words, size_t cap_words, uint64_t* d_nbits,
+                              void* stream) {
+  if (d_words == nullptr || d_nbits == nullptr) return fail(SJPEG_HIP_EINVAL, "d_words/d_nbits == NULL");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  FrameGeo g;
+  ScanArgs a;
+  int cls = 0;
+  int rc = prepare_scan(e, src, width, height, yuv_mode, 1, tables, st, &g, &a, &cls);
+  if (rc) return rc;
+  if (seg_begin < 0 || seg_end > g.nseg || seg_begin >= seg_end) return fail(SJPEG_HIP_EINVAL, "bad segment range");
+  const int nloc = seg_end - seg_begin;
+  const size_t need = sjpeg_hip_band_bound(width, height, yuv_mode, seg_begin, seg_end);
+  if (cap_words < need) {
+    return fail(SJPEG_HIP_ECAPACITY, "band buffer of " + std::to_string(cap_words) + " words, need " + std::to_string(need));
+  }
+  a.nseg = nloc;
+  a.seg_first = seg_begin;
+  const uint32_t max_chunks = static_cast<uint32_t>((cap_words + kChunkWords - 1) / kChunkWords);
+  if ((rc = e->seg_off.ensure(static_cast<size_t>(nloc) + 1))) return rc;
+  if ((rc = e->chunk_ff.ensure(max_chunks))) return rc;
+  StitchArgs s;
+  memset(&s, 0, sizeof(s));
+  s.nseg = nloc; s.nframes = 1;
+  s.seg_nbits = e->seg_nbits.p; s.seg_off = e->seg_off.p;
+  s.seg_words = e->seg_words.p; s.slot_words = g.slot_words;
+  s.ubuf = d_words; s.ubuf_words = cap_words;
+  s.chunk_ff = e->chunk_ff.p; s.max_chunks = max_chunks;
+  s.total_bits_out = reinterpret_cast<unsigned long long*>(d_nbits);
+  s.subs = 1;
+  if ((rc = launch_scan<kKindEncode>(yuv_mode, cls, dim3(nloc, 1), st, a))) return rc;
+  hipLaunchKernelGGL(scan_seg_offsets, dim3(1), dim3(kThreads), 0, st, s);
+  HIP_TRY(hipGetLastError());
+  hipLaunchKernelGGL(place_segments, dim3((nloc + 3) / 4, 1), dim3(kThreads), 0, st, s);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int sjpeg_hip_stitch_bands(sjpeg_hip_engine* e, int nbands, const uint32_t* d_words,
+                           size_t band_stride_words, const uint64_t* d_nbits, const void* header,
+                           size_t header_size, int append_eoi, void* d_out, size_t out_cap,
+                           uint64_t* d_size, void* stream) {
+  if (e == nullptr || d_words == nullptr || d_nbits == nullptr || d_out == nullptr || d_size == nullptr) {
+    return fail(SJPEG_HIP_EINVAL, "null argument");
+  }
+  if (nbands <= 0 || nbands > 65535) return fail(SJPEG_HIP_EINVAL, "nbands out of range");
+  if (band_stride_words < 4 || band_stride_words >= (size_t(1) << 27)) {
+    return fail(SJPEG_HIP_EINVAL, "band_stride_words out of range (a band is shorter than 2^32 bits)");
+  }
+  if (header == nullptr) header_size = 0;
+  if (out_cap < header_size + 2 + 64) return fail(SJPEG_HIP_ECAPACITY, "out_cap too small");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  HIP_TRY(hipSetDevice(e->device));
+  int rc;
+  const size_t ubuf_words = (static_cast<size_t>(nbands) * band_stride_words + kChunkWords + 3) & ~size_t(3);
+  const uint32_t max_chunks = static_cast<uint32_t>((ubuf_words + kChunkWords - 1) / kChunkWords);
+  if ((rc = e->seg_off.ensure(static_cast<size_t>(nbands) + 1))) return rc;
+  if ((rc = e->ubuf.ensure(ubuf_words))) return rc;
+  if ((rc = e->chunk_ff.ensure(max_chunks))) return rc;
+  if ((rc = e->chunk_off.ensure(max_chunks))) return rc;
+  if ((rc = e->header.ensure(header_size > 0 ? header_size : 1))) return rc;
+  if (header_size > 0) HIP_TRY(hipMemcpyAsync(e->header.p, header, header_size, hipMemcpyHostToDevice, st));
+  StitchArgs s;
+  memset(&s, 0, sizeof(s));
+  s.nseg = nbands; s.nframes = 1;
+  s.seg_nbits64 = reinterpret_cast<const unsigned long long*>(d_nbits);
+  s.seg_off = e->seg_off.p;
+  s.seg_words = d_words; s.slot_words = static_cast<uint32_t>(band_stride_words);
+  s.ubuf = e->ubuf.p; s.ubuf_words = ubuf_words;
+  s.chunk_ff = e->chunk_ff.p; s.chunk_off = e->chunk_off.p; s.max_chunks = max_chunks;
+  s.header = e->header.p; s.header_size = static_cast<uint32_t>(header_size);
+  s.append_eoi = append_eoi;
+  s.out = static_cast<uint8_t*>(d_out); s.out_stride = out_cap;
+  s.sizes = reinterpret_cast<unsigned long long*>(d_size);
+  const uint32_t per_wave = kSpec * kPlaceLanes;
+  s.subs = static_cast<uint32_t>((band_stride_words + per_wave - 1) / per_wave);
+  e->last_nseg = nbands; e->last_nframes = 1;
+  hipLaunchKernelGGL(scan_seg_offsets, dim3(1), dim3(kThreads), 0, st, s);
+  HIP_TRY(hipGetLastError());
+  const uint32_t units = static_cast<uint32_t>(nbands) * s.subs;
+  hipLaunchKernelGGL(place_segments, dim3((units + 3) / 4, 1), dim3(kThreads), 0, st, s);
+  HIP_TRY(hipGetLastError());
+  hipLaunchKernelGGL(scan_chunk_offsets, dim3(1), dim3(kThreads), 0, st, s);
+  HIP_TRY(hipGetLastError());
+  uint32_t gx = 4096u;
+  if (gx > max_chunks) gx = max_chunks;
+  hipLaunchKernelGGL(stuff_chunks, dim3(gx, 1), dim3(kThreads), 0, st, s);
+  HIP_TRY(hipGetLastError());
   return 0;
 }
 

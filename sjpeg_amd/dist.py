@@ -1,4 +1,6 @@
-"""Multi-GPU plumbing for the batch path (BASELINE.json config #4): frames are independent
+"""Multi-GPU plumbing.
+
+Batch path (BASELINE.json config #4): frames are independent
 objects, so the hot path shards by frame with NO data-path collective; the only exchange is
 the gather of the finished per-frame byte streams to rank 0 (RCCL over xGMI on the GPU box,
 gloo in CPU tests), followed by a host-side concatenate.
@@ -59,3 +61,54 @@ def gather_streams(out: torch.Tensor, sizes: torch.Tensor, frame_ids: Sequence[i
             frames[k] = buf[pos:pos + n].tobytes()
             pos += n
     return frames  # type: ignore[return-value]
+
+
+# ---- one frame over several GPUs: bands of consecutive segments -------------
+
+def band_ranges(nseg: int, world: int) -> List[tuple]:
+    """Segments [r*nseg/world, (r+1)*nseg/world) for every rank r (empty if nseg < world)."""
+    return [(r * nseg // world, (r + 1) * nseg // world) for r in range(world)]
+
+
+def gather_bands(words: torch.Tensor, nbits: torch.Tensor, stride: int, dst: int = 0, group=None):
+    """The one exchange step of the banded path: every rank contributes its band's bit string
+    (int32 words, at most `stride`) and bit count; `dst` gets ([world, stride] int32, [world] int64),
+    the others (None, None).  Two collectives: all_gather of the lengths (8 B each), gather of the
+    strings padded to `stride` (RCCL has no gatherv)."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    dev = words.device
+    mine = torch.zeros(stride, dtype=torch.int32, device=dev)
+    n = min(int(words.numel()), stride)
+    mine[:n] = words.reshape(-1)[:n]
+    lens = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(lens, nbits.reshape(1).to(torch.int64), group=group)
+    recv = [torch.zeros(stride, dtype=torch.int32, device=dev) for _ in range(world)] if rank == dst else None
+    dist.gather(mine, recv, dst=dst, group=group)
+    if rank != dst:
+        return None, None
+    return torch.stack(recv).contiguous(), torch.cat(lens).contiguous()
+
+
+def encode_frame_banded(engine, src, w: int, h: int, tables, header: bytes, yuv_mode: int,
+                        dst: int = 0, group=None) -> Optional[bytes]:
+    """One frame coded by all ranks of the group, bit-identical to the single-device encode.
+    `src` is this rank's sjpeg_amd.Source addressed as the whole frame (only the rows of the rank's
+    band and of the MCU in front of it are read).  Returns the JPEG on `dst`, None elsewhere."""
+    import sjpeg_amd as sj
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    nseg = sj.segment_count(w, h, yuv_mode)
+    ranges = band_ranges(nseg, world)
+    stride = max(sj.band_bound(w, h, yuv_mode, b, e) for (b, e) in ranges if e > b)
+    b, e = ranges[rank]
+    dev = torch.device("cuda", torch.cuda.current_device())
+    if e > b:
+        words, nbits = engine.encode_band(src, w, h, tables, yuv_mode, b, e)
+    else:                                     # fewer segments than ranks: this rank has nothing
+        words = torch.zeros(4, dtype=torch.int32, device=dev)
+        nbits = torch.zeros(1, dtype=torch.int64, device=dev)
+    allw, alln = gather_bands(words, nbits, stride, dst=dst, group=group)
+    if rank != dst:
+        return None
+    return engine.stitch_bands(allw, alln, header)

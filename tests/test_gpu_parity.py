@@ -375,3 +375,72 @@ def test_c5_recompress_method0(engine, digests):
     torch.cuda.synchronize()
     got = bytes(out[0, :int(sizes[0])].cpu().numpy())
     assert len(got) == d["size"] and hashlib.md5(got).hexdigest() == d["md5"]
+
+
+# ---- one frame over several devices: bands of segments, simulated on one GPU ----
+
+def test_stitch_bands_arbitrary_cuts(engine, oracle):
+    """The root's half of the banded path: bit strings cut at arbitrary bit positions (empty and
+    few-bit bands included) come back as the reference's entropy segment, byte for byte."""
+    from test_dist_cpu import _pack_words, _unstuffed_bits
+    rng = np.random.RandomState(5)
+    for (w, h, q, mode) in ((200, 120, 80.0, 1), (64, 64, 98.0, 3), (333, 211, 40.0, 4), (1920, 1080, 75.0, 1)):
+        img = synth.g_noise(w, h, 9) if q > 90 else synth.g_struct(w, h, 9)
+        bits, seg = _unstuffed_bits(oracle, img, q, mode)
+        for nb in (1, 2, 3, 7, 16):
+            cuts = np.sort(rng.randint(0, len(bits) + 1, nb - 1)).tolist()
+            if nb >= 7:
+                cuts[1] = cuts[0]                                  # an empty band
+                cuts[3] = min(cuts[2] + 3, len(bits))              # a 3-bit band
+                cuts = sorted(cuts)
+            edges = [0] + cuts + [len(bits)]
+            lens = [edges[i + 1] - edges[i] for i in range(nb)]
+            stride = (max(lens) + 31) // 32 + 5
+            words = np.zeros((nb, stride), np.int32)
+            for i in range(nb):
+                pw = _pack_words(bits[edges[i]:edges[i + 1]])
+                words[i, :len(pw)] = pw
+            got = engine.stitch_bands(torch.from_numpy(words).cuda(), torch.tensor(lens, dtype=torch.int64).cuda(),
+                                      b"HDR", append_eoi=True)
+            assert got == b"HDR" + seg + b"\xff\xd9", (w, h, q, mode, nb)
+
+
+@pytest.mark.parametrize("mode", [1, 3, 4])
+def test_banded_frame_equals_single_device(engine, oracle, mode):
+    """Every rank's half + the root's half: P bands coded independently (sjpeg_hip_encode_band_src),
+    gathered, stitched == the one-device encode == the reference."""
+    for (w, h, q) in ((1920, 1080, 75.0), (640, 353, 92.0), (97, 61, 50.0)):
+        img = synth.g_struct(w, h, 21)
+        dev_img = torch.from_numpy(img).cuda().unsqueeze(0)
+        src, _ = sj.make_source(sj.SRC_RGB, [dev_img.reshape(1, h, 3 * w)])
+        tables, quant = sj.make_tables(quality=q)
+        header = sj.make_header(w, h, mode, quant)
+        want = oracle.encode(img, q, mode)
+        nseg = sj.segment_count(w, h, mode)
+        from sjpeg_amd.dist import band_ranges
+        for world in (1, 2, 3, 8):
+            ranges = [(b, e) for (b, e) in band_ranges(nseg, world)]
+            stride = max(sj.band_bound(w, h, mode, b, e) for (b, e) in ranges if e > b)
+            allw = torch.zeros((world, stride), dtype=torch.int32, device="cuda")
+            alln = torch.zeros(world, dtype=torch.int64, device="cuda")
+            for r, (b, e) in enumerate(ranges):
+                if e > b:
+                    words, nbits = engine.encode_band(src, w, h, tables, mode, b, e)
+                    allw[r, :words.numel()] = words
+                    alln[r] = nbits[0]
+            got = engine.stitch_bands(allw, alln, header)
+            assert got == want, (w, h, q, mode, world)
+
+
+def test_band_argument_errors(engine):
+    img = torch.zeros((1, 16, 48), dtype=torch.uint8, device="cuda")
+    src, _ = sj.make_source(sj.SRC_RGB, [img])
+    t, _ = sj.make_tables(quality=75)
+    with pytest.raises(sj.SjpegError):
+        sj.band_bound(16, 16, 1, 0, 2)                          # only one segment
+    with pytest.raises(sj.SjpegError):
+        engine.encode_band(src, 16, 16, t, 1, 0, 1, cap_words=8)    # buffer too small
+    w = torch.zeros((2, 8), dtype=torch.int32, device="cuda")
+    with pytest.raises(sj.SjpegError):
+        engine.stitch_bands(w, torch.zeros(2, dtype=torch.int64, device="cuda"), b"", out_cap=16)
+    torch.cuda.synchronize()
