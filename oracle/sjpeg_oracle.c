@@ -422,6 +422,82 @@ int orc_quantize_block(const int16_t in[64], const orc_quantizer* q, int16_t zz[
   return dc;
 }
 
+/* Trellis quantization of one block: src/quantize.cc:325-457 (TrellisNode, SearchBestPrev,
+ * Encoder::TrellisQuantizeBlock).  For every non-zero coefficient two candidate levels (the
+ * rounded one, and the largest level of the next smaller size class) become nodes of a graph
+ * whose edges cost distortion + lambda * bits; ac_codes = the (code << 16 | length) table the
+ * rate is priced with.  Integer arithmetic throughout, 32-bit wrap-around like the reference. */
+int orc_trellis_block(const int16_t in[64], const orc_quantizer* q, const uint32_t ac_codes[256],
+                      int16_t zz[64]) {
+  enum { kNodes = 1 + 2 * 63 };
+  uint32_t n_score[kNodes], n_disto[kNodes];
+  int n_level[kNodes], n_pos[kNodes], n_rank[kNodes], n_prev[kNodes], n_neg[kNodes];
+  uint32_t disto0[64];
+  int count = 1;                                   /* node 0 = the sink */
+  n_score[0] = 0; n_disto[0] = 0; n_pos[0] = 0; n_rank[0] = 0;
+  n_prev[0] = -1; n_level[0] = 0; n_neg[0] = 0;
+  disto0[0] = 0;
+  const uint32_t zrl_len = ac_codes[0xf0] & 0xff;
+  for (int i = 1; i < 64; ++i) {
+    const int j = orc_zigzag[i];
+    const uint32_t qq = (uint32_t)q->quant[j] << 4;
+    const uint32_t lambda = qq * qq / 32u;
+    const int raw = in[j];
+    const int neg = raw < 0;
+    const int V = neg ? -raw : raw;
+    disto0[i] = (uint32_t)(V * V) + disto0[i - 1];
+    int v = quantize_abs((uint32_t)V, q->iquant[j], q->bias[j]);
+    if (v == 0) continue;
+    int nbits = bit_length((uint32_t)v);
+    for (int k = 0; k < 2; ++k) {
+      const int err = V - v * (int)qq;
+      const int me = count;
+      n_level[me] = v; n_neg[me] = neg; n_pos[me] = i;
+      n_disto[me] = (uint32_t)(err * err);
+      n_score[me] = 0xffffffffu;
+      /* best predecessor, walking back towards the sink */
+      int found = 0;
+      const uint32_t base_disto = n_disto[me] + disto0[i - 1];
+      for (int c = me - 1; c >= 0; --c) {
+        const int run = i - 1 - n_pos[c];
+        if (run < 0) continue;
+        uint32_t bits = (uint32_t)nbits + (uint32_t)(run >> 4) * zrl_len;
+        const uint32_t disto = base_disto - disto0[n_pos[c]];
+        if (disto + lambda * bits >= n_score[me]) break;
+        bits += ac_codes[((run & 15) << 4) | nbits] & 0xff;
+        const uint32_t score = disto + lambda * bits + n_score[c];
+        if (score < n_score[me]) {
+          n_score[me] = score; n_disto[me] = disto;
+          n_prev[me] = c; n_rank[me] = n_rank[c] + 1;
+          found = 1;
+        }
+      }
+      if (found) ++count;
+      --nbits;
+      if (nbits <= 0) break;
+      v = (1 << nbits) - 1;
+    }
+  }
+  /* best entry point, searched backwards (the EOB cost is the same for all but position 63) */
+  int best = 0;
+  if (count > 1) {
+    uint32_t best_score = 0xffffffffu;
+    for (int c = count - 1; c >= 0; --c) {
+      const uint32_t disto = disto0[63] - disto0[n_pos[c]];
+      n_disto[c] += disto;
+      n_score[c] += disto;
+      if (n_score[c] < best_score) { best = c; best_score = n_score[c]; }
+    }
+  }
+  for (int i = 1; i < 64; ++i) zz[i] = 0;
+  for (int c = best; c > 0; c = n_prev[c]) zz[n_pos[c]] = (int16_t)(n_neg[c] ? -n_level[c] : n_level[c]);
+  const int d = in[0];
+  const int dc = d < 0 ? -quantize_abs((uint32_t)-d, q->iquant[0], q->bias[0])
+                       : quantize_abs((uint32_t)d, q->iquant[0], q->bias[0]);
+  zz[0] = (int16_t)dc;
+  return dc;
+}
+
 /* ---------------------------------------------------------------- bit writer */
 
 typedef struct {
@@ -512,7 +588,13 @@ typedef struct {
   orc_layout L;
   orc_quantizer q[2];
   int W, H, mb_w, mb_h;
+  const uint32_t (*trellis_ac)[256];   /* non-NULL: trellis quantization priced with these AC codes */
 } orc_scan;
+
+static int scan_quantize(const orc_scan* s, const int16_t* blk, int t, int16_t zz[64]) {
+  if (s->trellis_ac != NULL) return orc_trellis_block(blk, &s->q[t], s->trellis_ac[t], zz);
+  return orc_quantize_block(blk, &s->q[t], zz);
+}
 
 static int scan_init(orc_scan* s, int W, int H, int yuv_mode, const uint8_t quant[2][64],
                      const uint8_t* min_quant, int q_bias) {
@@ -526,6 +608,7 @@ static int scan_init(orc_scan* s, int W, int H, int yuv_mode, const uint8_t quan
     else memset(s->q[c].min_quant, 1, 64);
     orc_finalize_quant(&s->q[c], q_bias);
   }
+  s->trellis_ac = NULL;
   s->W = W; s->H = H;
   s->mb_w = (W + s->L.block_w - 1) / s->L.block_w;     /* src/enc.cc:410-411 */
   s->mb_h = (H + s->L.block_h - 1) / s->L.block_h;
@@ -572,7 +655,7 @@ static void scan_emit(orc_scan* s, const orc_source* S, int yuv_mode, orc_bw* w,
       for (int c = 0; c < s->L.nb_comps; ++c) {
         const int t = s->L.quant_idx[c];
         for (int i = 0; i < s->L.nb_blocks[c]; ++i, blk += 64) {
-          orc_quantize_block(blk, &s->q[t], zz);
+          scan_quantize(s, blk, t, zz);
           code_block(w, zz, &pred[c], dc_codes[t], ac_codes[t]);
         }
       }
@@ -826,7 +909,7 @@ static void scan_stats(orc_scan* s, const orc_source* S, int yuv_mode, uint32_t*
       for (int c = 0; c < s->L.nb_comps; ++c) {
         const int t = s->L.quant_idx[c];
         for (int i = 0; i < s->L.nb_blocks[c]; ++i, blk += 64) {
-          orc_quantize_block(blk, &s->q[t], zz);
+          scan_quantize(s, blk, t, zz);
           block_stats(zz, &pred[c], freq + 272 * t);
         }
       }
@@ -928,9 +1011,14 @@ size_t orc_encode_src(const orc_source* S, int W, int H, const uint8_t quant[2][
   else if (S->format == ORC_SRC_YUV444) yuv_mode = ORC_YUV_444;
   else if (S->format >= ORC_SRC_YUV420) yuv_mode = ORC_YUV_420;
   if (method < 0) method = 0;
-  if (method > 6) return 0;                       /* trellis: outside the oracle's scope */
+  if (method > 8) method = 8;                     /* src/enc.cc:122 */
   if (!scan_init(&s, W, H, yuv_mode, quant, min_quant, q_bias)) return 0;
   const int adaptive = method >= 3, optimize = (method != 0 && method != 3);
+  /* methods 7, 8: trellis quantization, priced with the standard AC tables (InitCodes(true) in
+   * SinglePassScanOptimized, src/enc.cc:330-334) */
+  uint32_t std_dc[2][12], std_ac[2][256];
+  orc_default_codes(std_dc, std_ac);
+  if (method >= 7) s.trellis_ac = (const uint32_t (*)[256])std_ac;
   if (adaptive) {
     uint32_t* hist = (uint32_t*)malloc(2 * 64 * 128 * sizeof(uint32_t));
     orc_histogram_src(S, W, H, yuv_mode, hist);
