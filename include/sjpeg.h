@@ -8,10 +8,11 @@
 // stays on the host and mirrors the reference bit for bit.
 //
 // What this build runs on the GPU: YUV 4:2:0 / 4:4:4 / 4:0:0 from every input layout of the
-// API, compression methods 0..6 (standard or optimised Huffman tables, fixed or adaptive
-// quantization), and the multi-pass size / PSNR search (every pass is a GPU pass over the resident
-// picture).  SJPEG_YUV_AUTO / SJPEG_YUV_SHARP and trellis quantization are not available
-// (DESIGN.md section 1): such requests FAIL (0 / false), there is no CPU fallback.
+// API, compression methods 0..8 (standard or optimised Huffman tables, fixed or adaptive
+// quantization, trellis quantization), and the multi-pass size / PSNR search (every pass is a GPU
+// pass over the resident picture; not together with trellis).  SJPEG_YUV_AUTO / SJPEG_YUV_SHARP
+// are not available: such requests FAIL (0 / false), there is no CPU
+// fallback.
 // The reason of the last failure on the calling thread: SjpegHipLastError().
 #ifndef SJPEG_AMD_SJPEG_H_
 #define SJPEG_AMD_SJPEG_H_

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SJPEG_HIP_ABI_VERSION 3
+#define SJPEG_HIP_ABI_VERSION 4
 
 enum {
   SJPEG_HIP_OK = 0,
@@ -57,9 +57,18 @@ typedef struct sjpeg_hip_scan_tables {
   uint16_t bias[2][64];
   uint32_t dc_codes[2][12];
   uint32_t ac_codes[2][256];
-  uint8_t quant[2][64];        /* the (final, clamped) quantizer steps; only the quantization-
-                                  error pass reads them (src/quantize.cc:553-565) */
+  uint8_t quant[2][64];        /* the (final, clamped) quantizer steps; read by the quantization-
+                                  error pass (src/quantize.cc:553-565) and the trellis */
+  uint8_t trellis_len[2][256]; /* SJPEG_HIP_QUANT_TRELLIS: AC code LENGTHS the rate term is priced
+                                  with (what Quantizer::codes_ points at, src/quantize.cc:151,396):
+                                  the standard tables in the reference's single-pass flow */
+  uint32_t flags;              /* SJPEG_HIP_QUANT_* */
 } sjpeg_hip_scan_tables;
+
+/* flags: quantize with the trellis search of the reference's methods 7 / 8
+ * (Encoder::TrellisQuantizeBlock, src/quantize.cc:325-457) instead of plain rounding.  Applies to
+ * the encode and symbol-statistics passes. */
+#define SJPEG_HIP_QUANT_TRELLIS 1u
 
 /* Pixel sources.  Packed colour and gray use plane[0]; planar YUV uses Y, U, V; NV12/NV21 use
  * Y and the interleaved chroma plane in plane[1].  Chroma planes of the 4:2:0 layouts are

@@ -28,7 +28,12 @@ class ScanTables(C.Structure):
                 ("bias", (C.c_uint16 * 64) * 2),
                 ("dc_codes", (C.c_uint32 * 12) * 2),
                 ("ac_codes", (C.c_uint32 * 256) * 2),
-                ("quant", (C.c_uint8 * 64) * 2)]
+                ("quant", (C.c_uint8 * 64) * 2),
+                ("trellis_len", (C.c_uint8 * 256) * 2),
+                ("flags", C.c_uint32)]
+
+
+QUANT_TRELLIS = 1
 
 
 SRC_RGB, SRC_BGRA, SRC_RGBA, SRC_GRAY, SRC_YUV444, SRC_YUV420, SRC_NV12, SRC_NV21 = range(8)

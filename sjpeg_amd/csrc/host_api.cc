@@ -237,9 +237,10 @@ bool Encoder::Run() {
   // method flags, reference: src/enc.cc:121-129
   const bool adaptive = method_ >= 3;
   const bool optimize = (method_ != 0) && (method_ != 3);
-  if (method_ >= 7) {
-    return Fail("trellis quantization (methods 7, 8 / use_trellis) is not available in this build: "
-                "it is a per-block dynamic program outside the GPU hot path; no CPU fallback exists");
+  const bool trellis = method_ >= 7;
+  if (trellis && passes_ > 1) {
+    return Fail("trellis quantization together with the multi-pass size/PSNR search is not available "
+                "in this build");
   }
   if (qdelta_luma_ < 0 || qdelta_luma_ > 12 || qdelta_chroma_ < 0 || qdelta_chroma_ > 12) {
     return Fail("qdelta_max_luma / qdelta_max_chroma must be in [0, 12]");
@@ -304,6 +305,17 @@ bool Encoder::Run() {
   memset(&tables, 0, sizeof(tables));
   sjpeg_host::FinalizeQuantizer(quant_[0], min_quant_[0], q_bias_, 0, &tables);
   sjpeg_host::FinalizeQuantizer(quant_[1], min_quant_[1], q_bias_, 1, &tables);
+  if (trellis) {
+    // methods 7, 8: the trellis prices its rate with the standard AC tables (InitCodes(true) in
+    // SinglePassScanOptimized, src/enc.cc:330-334), whatever tables the stream ends up with
+    tables.flags |= SJPEG_HIP_QUANT_TRELLIS;
+    for (int c = 0; c < 2; ++c) {
+      uint32_t codes[256];
+      memset(codes, 0, sizeof(codes));
+      sjpeg_host::BuildCodes(sjpeg_host::DefaultHuff(1, c), codes);
+      for (int i = 0; i < 256; ++i) tables.trellis_len[c][i] = static_cast<uint8_t>(codes[i] & 0xff);
+    }
+  }
   if (!ctx.Ensure(&ctx.d_stats, &ctx.stats_cap, 2 * 64 * 128 * sizeof(uint32_t))) return false;
 
   if (passes_ > 1 && !search_ok_) return Fail("SearchHook::Setup() failed");

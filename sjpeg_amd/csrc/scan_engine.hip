@@ -71,6 +71,7 @@ struct DevTables {
   uint4 q[2][32];          // per natural-order PAIR (2j, 2j+1): {iq0 | iq1<<16, bias0*iq0, bias1*iq1, q0 | q1<<16}
   uint32_t dc[2][12];
   uint32_t ac[2][256];
+  uint8_t tlen[2][256];    // trellis quantization: AC code lengths the rate is priced with
 };
 
 // source classes the colour phase is specialised for
@@ -101,12 +102,13 @@ constexpr int kOffWin = kSamplesBytes;
 // touched (P2 / DC coding), so they live INSIDE the window region.
 constexpr int kOffQ = kOffWin;                                  // uint4[64]
 constexpr int kOffDc = kOffWin + 1024;                          // uint32[24]
+constexpr int kOffTlen = kOffWin + 1152;                        // uint8[2][256], trellis kinds only
 constexpr int kOffAc = kOffWin + kWinWords * 4 + 16;            // +1 spare word (16 B keeps alignment)
 constexpr int kOffMisc = kOffAc + 2 * 256 * 4;                  // scan scratch
 constexpr int kLdsBytes = kOffMisc + 64;                        // 47184: three workgroups per CU
 constexpr int kOffStats = kLdsBytes;                            // kKindStats only: u32[2][272]
 constexpr int kLdsBytesStats = kOffStats + 2 * 272 * 4;
-static_assert(kWinWords * 4 >= 1024 + 96 && kWinWords >= 64 + 64 + kScanThreads, "window region too small");
+static_assert(kWinWords * 4 >= 1152 + 512 && kWinWords >= 64 + 512 + 512, "window region too small");
 static_assert(3 * kLdsBytes <= 160 * 1024, "three workgroups per CU");
 
 // ------------------------------------------------------------------------------------
@@ -345,6 +347,23 @@ __device__ __forceinline__ void row_quant(const uint32_t* row, const uint4* qt, 
   }
 }
 
+// One row, transform only: the raw coefficients (int16 pairs, natural order) for the trellis.
+template <int C1, int C2, int C3, int C4, int C5, int C6, int C7>
+__device__ __forceinline__ void row_raw(const uint32_t* row, uint32_t* ent) {
+  int acc[8];
+  fdct_row8_pk<C1, C2, C3, C4, C5, C6, C7>(row, acc);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    ent[k] = __builtin_amdgcn_perm(static_cast<uint32_t>(acc[2 * k + 1]), static_cast<uint32_t>(acc[2 * k]), 0x07060302u);
+  }
+}
+
+// zig-zag position -> natural index, as data (the trellis walks positions in a run-time loop)
+__device__ const unsigned char kZigTab[64] = {
+    0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
+    41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
+    30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+
 // byte-permute selector that builds (E16[a], E16[b]) from the dwords holding them
 __device__ constexpr uint32_t kPairSel(int a, int b) {
   const uint32_t lo = (a & 1) ? 0x0302u : 0x0100u;       // from S1 (second operand)
@@ -514,12 +533,15 @@ __device__ __forceinline__ uint32_t wg_exclusive_scan(uint32_t x, uint32_t* scra
 // ------------------------------------------------------------------------------------
 // K1: colour + fDCT + quantize + entropy-code one segment
 
-enum { kKindEncode = 0, kKindTap = 1, kKindHisto = 2, kKindStats = 3, kKindError = 4 };
+enum { kKindEncode = 0, kKindTap = 1, kKindHisto = 2, kKindStats = 3, kKindError = 4,
+       kKindEncodeTrellis = 5, kKindStatsTrellis = 6 };   // the same two with trellis quantization
 constexpr int kHistoWords = 2 * 64 * 32;          // per-workgroup partial: u8 counters [2][64][128]
 constexpr int kStatsWords = 2 * 272;              // per-workgroup partial: u32 [2][256 AC + 16 DC]
 
-template <int MODE, int KIND, int SRC>
+template <int MODE, int KINDX, int SRC>
 __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) {
+  constexpr bool TRELLIS = (KINDX == kKindEncodeTrellis || KINDX == kKindStatsTrellis);
+  constexpr int KIND = (KINDX == kKindEncodeTrellis) ? kKindEncode : (KINDX == kKindStatsTrellis) ? kKindStats : KINDX;
   using G = Geo<MODE>;
   constexpr int BPM = G::kBpm;
   constexpr int PX = G::kMcuPx;
@@ -549,6 +571,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
     if (tid < 64) lq[tid] = (&t->q[0][0])[tid];
     for (int i = tid; i < 512; i += kScanThreads) lac[i] = (&t->ac[0][0])[i];
     if (tid < 24) ldc[tid] = (&t->dc[0][0])[tid];
+    if (TRELLIS && tid < 128) reinterpret_cast<uint32_t*>(smem + kOffTlen)[tid] = reinterpret_cast<const uint32_t*>(&t->tlen[0][0])[tid];
   }
 
   // ---- P1: colour conversion, strips of 8 pixels (x2 rows for 4:2:0) --------------------
@@ -829,19 +852,26 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
   {
     const uint4* qt = lq + tbl * 32;
     // cos(k*pi/16)/sqrt(2) tables, rows 1/7, 2/6, 3/5 pre-scaled (src/fdct.cc:28-35,599-606)
-    row_quant<0, 22725, 21407, 19266, 16384, 12873, 8867, 4520>(p[0], qt, ent + 0, nzq);
-    row_quant<1, 31521, 29692, 26722, 22725, 17855, 12299, 6270>(p[1], qt, ent + 4, nzq);
-    row_quant<2, 29692, 27969, 25172, 21407, 16819, 11585, 5906>(p[2], qt, ent + 8, nzq);
-    row_quant<3, 26722, 25172, 22654, 19266, 15137, 10426, 5315>(p[3], qt, ent + 12, nzq);
-    row_quant<4, 22725, 21407, 19266, 16384, 12873, 8867, 4520>(p[4], qt, ent + 16, nzq);
-    row_quant<5, 26722, 25172, 22654, 19266, 15137, 10426, 5315>(p[5], qt, ent + 20, nzq);
-    row_quant<6, 29692, 27969, 25172, 21407, 16819, 11585, 5906>(p[6], qt, ent + 24, nzq);
-    row_quant<7, 31521, 29692, 26722, 22725, 17855, 12299, 6270>(p[7], qt, ent + 28, nzq);
+    if (!TRELLIS) {
+      row_quant<0, 22725, 21407, 19266, 16384, 12873, 8867, 4520>(p[0], qt, ent + 0, nzq);
+      row_quant<1, 31521, 29692, 26722, 22725, 17855, 12299, 6270>(p[1], qt, ent + 4, nzq);
+      row_quant<2, 29692, 27969, 25172, 21407, 16819, 11585, 5906>(p[2], qt, ent + 8, nzq);
+      row_quant<3, 26722, 25172, 22654, 19266, 15137, 10426, 5315>(p[3], qt, ent + 12, nzq);
+      row_quant<4, 22725, 21407, 19266, 16384, 12873, 8867, 4520>(p[4], qt, ent + 16, nzq);
+      row_quant<5, 26722, 25172, 22654, 19266, 15137, 10426, 5315>(p[5], qt, ent + 20, nzq);
+      row_quant<6, 29692, 27969, 25172, 21407, 16819, 11585, 5906>(p[6], qt, ent + 24, nzq);
+      row_quant<7, 31521, 29692, 26722, 22725, 17855, 12299, 6270>(p[7], qt, ent + 28, nzq);
+    } else {
+      row_raw<22725, 21407, 19266, 16384, 12873, 8867, 4520>(p[0], ent + 0);
+      row_raw<31521, 29692, 26722, 22725, 17855, 12299, 6270>(p[1], ent + 4);
+      row_raw<29692, 27969, 25172, 21407, 16819, 11585, 5906>(p[2], ent + 8);
+      row_raw<26722, 25172, 22654, 19266, 15137, 10426, 5315>(p[3], ent + 12);
+      row_raw<22725, 21407, 19266, 16384, 12873, 8867, 4520>(p[4], ent + 16);
+      row_raw<26722, 25172, 22654, 19266, 15137, 10426, 5315>(p[5], ent + 20);
+      row_raw<29692, 27969, 25172, 21407, 16819, 11585, 5906>(p[6], ent + 24);
+      row_raw<31521, 29692, 26722, 22725, 17855, 12299, 6270>(p[7], ent + 28);
+    }
   }
-  nzq[0] &= ~1u;                                // DC is coded separately
-  const uint32_t nz_lo = nzq[0] | (nzq[1] << 16), nz_hi = nzq[2] | (nzq[3] << 16);
-  const int dc_mag = static_cast<int>(ent[0] & 0x7fffu);
-  const int dc_val = (ent[0] & 0x8000u) ? -dc_mag : dc_mag;
   // zig-zag reorder with byte permutes, 4 entries per ds_write_b64
 #pragma unroll
   for (int i = 0; i < 64; i += 4) {
@@ -851,6 +881,111 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
                                               kPairSel(kZig(i + 2), kZig(i + 3)));
     *reinterpret_cast<uint2*>(slot + 2 * i) = make_uint2(w0, w1);
   }
+  int dc_val;
+  if (!TRELLIS) {
+    const int dc_mag = static_cast<int>(ent[0] & 0x7fffu);
+    dc_val = (ent[0] & 0x8000u) ? -dc_mag : dc_mag;
+  } else {
+    // Trellis quantization (reference Encoder::TrellisQuantizeBlock + SearchBestPrev,
+    // src/quantize.cc:325-457): the slot holds the RAW coefficients in zig-zag order.  For every
+    // coefficient that does not quantize to zero, two candidate levels become nodes of a graph;
+    // an edge costs distortion + lambda * bits (bits priced with the AC code lengths in `tl`).
+    // One thread per block, nodes in private memory: a correct, not a fast, path.
+    typedef int16_t __attribute__((may_alias)) i16_alias;
+    typedef uint16_t __attribute__((may_alias)) u16_alias2;
+    const i16_alias* const raw = reinterpret_cast<const i16_alias*>(slot);
+    const uint4* const qt = lq + tbl * 32;
+    const uint8_t* const tl = smem + kOffTlen + tbl * 256;
+    {
+      const int d = raw[0];
+      const uint4 t0 = qt[0];
+      const uint32_t ad = static_cast<uint32_t>(d < 0 ? -d : d);
+      const int lv = static_cast<int>((ad * (t0.x & 0xffffu) + t0.y) >> 20);
+      dc_val = d < 0 ? -lv : lv;
+    }
+    unsigned long long nzm = 0;
+    if (emits) {
+      constexpr int kNodes = 1 + 2 * 63;
+      uint32_t n_score[kNodes];
+      uint32_t n_info[kNodes];                     // level | neg << 11 | pos << 12 | rank << 18 | prev << 25
+      uint32_t disto0[64];
+      n_score[0] = 0; n_info[0] = 0;
+      disto0[0] = 0;
+      int count = 1;                               // node 0 = the sink
+      const uint32_t zrl_len = tl[0xf0];
+      for (int i = 1; i < 64; ++i) {
+        const int j = kZigTab[i];
+        const uint4 t = qt[j >> 1];
+        const uint32_t iq = (j & 1) ? (t.x >> 16) : (t.x & 0xffffu);
+        const uint32_t biq = (j & 1) ? t.z : t.y;
+        const uint32_t qq = ((j & 1) ? (t.w >> 16) : (t.w & 0xffffu)) << 4;
+        const uint32_t lambda = qq * qq / 32u;
+        const int rv = raw[i];
+        const uint32_t neg = rv < 0 ? 1u : 0u;
+        const int V = rv < 0 ? -rv : rv;
+        disto0[i] = static_cast<uint32_t>(V * V) + disto0[i - 1];
+        int v = static_cast<int>((static_cast<uint32_t>(V) * iq + biq) >> 20);
+        if (v == 0) continue;
+        int nbits = 32 - __clz(v);
+        for (int kk = 0; kk < 2; ++kk) {
+          const int err = V - v * static_cast<int>(qq);
+          const int me = count;
+          uint32_t my_score = 0xffffffffu, my_prev = 0, my_rank = 0;
+          bool found = false;
+          const uint32_t base_disto = static_cast<uint32_t>(err * err) + disto0[i - 1];
+          for (int c = me - 1; c >= 0; --c) {
+            const uint32_t ci = n_info[c];
+            const int cpos = static_cast<int>((ci >> 12) & 63u);
+            const int run = i - 1 - cpos;
+            if (run < 0) continue;
+            uint32_t bits = static_cast<uint32_t>(nbits) + static_cast<uint32_t>(run >> 4) * zrl_len;
+            const uint32_t disto = base_disto - disto0[cpos];
+            if (disto + lambda * bits >= my_score) break;
+            bits += tl[((run & 15) << 4) | nbits];
+            const uint32_t score = disto + lambda * bits + n_score[c];
+            if (score < my_score) {
+              my_score = score; my_prev = static_cast<uint32_t>(c); my_rank = ((ci >> 18) & 127u) + 1u;
+              found = true;
+            }
+          }
+          if (found) {
+            n_score[me] = my_score;
+            n_info[me] = static_cast<uint32_t>(v) | (neg << 11) | (static_cast<uint32_t>(i) << 12) | (my_rank << 18) | (my_prev << 25);
+            ++count;
+          }
+          --nbits;
+          if (nbits <= 0) break;
+          v = (1 << nbits) - 1;
+        }
+      }
+      // best entry point, searched backwards (the EOB cost is the same for all but position 63)
+      int best = 0;
+      if (count > 1) {
+        uint32_t best_score = 0xffffffffu;
+        for (int c = count - 1; c >= 0; --c) {
+          const uint32_t sc = n_score[c] + (disto0[63] - disto0[(n_info[c] >> 12) & 63u]);
+          if (sc < best_score) { best = c; best_score = sc; }
+        }
+      }
+      // the slot becomes the usual sign-magnitude entries: zeros but for the chosen chain
+#pragma unroll
+      for (int r = 0; r < 8; ++r) *reinterpret_cast<uint4*>(slot + 16 * r) = make_uint4(0, 0, 0, 0);
+      u16_alias2* const zzw = reinterpret_cast<u16_alias2*>(slot);
+      for (int c = best; c > 0; c = static_cast<int>(n_info[c] >> 25)) {
+        const uint32_t ci = n_info[c];
+        const uint32_t pos = (ci >> 12) & 63u;
+        zzw[pos] = static_cast<uint16_t>((ci & 0x7ffu) | (((ci >> 11) & 1u) << 15));
+        nzm |= 1ull << pos;
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) *reinterpret_cast<uint4*>(slot + 16 * r) = make_uint4(0, 0, 0, 0);
+    }
+    nzq[0] = static_cast<uint32_t>(nzm) & 0xffffu; nzq[1] = static_cast<uint32_t>(nzm >> 16) & 0xffffu;
+    nzq[2] = static_cast<uint32_t>(nzm >> 32) & 0xffffu; nzq[3] = static_cast<uint32_t>(nzm >> 48);
+  }
+  nzq[0] &= ~1u;                                // DC is coded separately
+  const uint32_t nz_lo = nzq[0] | (nzq[1] << 16), nz_hi = nzq[2] | (nzq[3] << 16);
   if (KIND == kKindTap) {
     if (emits) {
       const long long nblk_frame = static_cast<long long>(a.n_mcus) * BPM;
@@ -1597,12 +1732,13 @@ void digest_tables(const sjpeg_hip_scan_tables* t, DevTables* d) {
   }
   memcpy(d->dc, t->dc_codes, sizeof(d->dc));
   memcpy(d->ac, t->ac_codes, sizeof(d->ac));
+  memcpy(d->tlen, t->trellis_len, sizeof(d->tlen));
 }
 
 template <int KIND, int SRC>
 int launch_scan_src(int mode, dim3 grid, hipStream_t st, const ScanArgs& a) {
   static const int kLdsPad = getenv("SJPEG_HIP_LDS_PAD") ? atoi(getenv("SJPEG_HIP_LDS_PAD")) : 0;  // occupancy experiments
-  const int lds = (KIND == kKindStats ? kLdsBytesStats : kLdsBytes) + kLdsPad;
+  const int lds = ((KIND == kKindStats || KIND == kKindStatsTrellis) ? kLdsBytesStats : kLdsBytes) + kLdsPad;
   switch (mode) {
     case SJPEG_HIP_YUV420:
       hipLaunchKernelGGL((scan_segments<SJPEG_HIP_YUV420, KIND, SRC>), grid, dim3(kScanThreads), lds, st, a);
@@ -1837,6 +1973,7 @@ static int scan_statistics(sjpeg_hip_engine* e, const sjpeg_hip_source* src, int
   if ((rc = e->partial.ensure(static_cast<size_t>(nframes) * g.nseg * words))) return rc;
   a.partial = e->partial.p;
   if (histogram) rc = launch_scan<kKindHisto>(yuv_mode, cls, dim3(g.nseg, nframes), st, a);
+  else if (tables != nullptr && (tables->flags & SJPEG_HIP_QUANT_TRELLIS)) rc = launch_scan<kKindStatsTrellis>(yuv_mode, cls, dim3(g.nseg, nframes), st, a);
   else rc = launch_scan<kKindStats>(yuv_mode, cls, dim3(g.nseg, nframes), st, a);
   if (rc) return rc;
   const dim3 grid((words + kThreads - 1) / kThreads, nframes);
@@ -1958,7 +2095,9 @@ int sjpeg_hip_encode_scan_src(sjpeg_hip_engine* e, const sjpeg_hip_source* src, 
   s.seg_nbits64 = nullptr; s.total_bits_out = nullptr; s.subs = 1;
 
   if (e->timing) HIP_TRY(hipEventRecord(e->ev[0], st));
-  if ((rc = launch_scan<kKindEncode>(yuv_mode, cls, dim3(g.nseg, nframes), st, a))) return rc;
+  if (tables->flags & SJPEG_HIP_QUANT_TRELLIS) rc = launch_scan<kKindEncodeTrellis>(yuv_mode, cls, dim3(g.nseg, nframes), st, a);
+  else rc = launch_scan<kKindEncode>(yuv_mode, cls, dim3(g.nseg, nframes), st, a);
+  if (rc) return rc;
   if (e->timing) HIP_TRY(hipEventRecord(e->ev[1], st));
 
   hipLaunchKernelGGL(scan_seg_offsets, dim3(nframes), dim3(kThreads), 0, st, s);
@@ -2026,7 +2165,9 @@ int sjpeg_hip_encode_band_src(sjpeg_hip_engine* e, const sjpeg_hip_source* src, 
   s.chunk_ff = e->chunk_ff.p; s.max_chunks = max_chunks;
   s.total_bits_out = reinterpret_cast<unsigned long long*>(d_nbits);
   s.subs = 1;
-  if ((rc = launch_scan<kKindEncode>(yuv_mode, cls, dim3(nloc, 1), st, a))) return rc;
+  if (tables->flags & SJPEG_HIP_QUANT_TRELLIS) rc = launch_scan<kKindEncodeTrellis>(yuv_mode, cls, dim3(nloc, 1), st, a);
+  else rc = launch_scan<kKindEncode>(yuv_mode, cls, dim3(nloc, 1), st, a);
+  if (rc) return rc;
   hipLaunchKernelGGL(scan_seg_offsets, dim3(1), dim3(kThreads), 0, st, s);
   HIP_TRY(hipGetLastError());
   hipLaunchKernelGGL(place_segments, dim3((nloc + 3) / 4, 1), dim3(kThreads), 0, st, s);

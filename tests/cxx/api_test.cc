@@ -124,6 +124,25 @@ int main(int argc, char** argv) {
     CHECK(!sjpeg::Encode(rgb.data(), W, H, 3 * W, param, &out));
   }
 
+  {   // use_trellis: only with Huffman_compress + adaptive_quantization (method 4 -> 7, src/api.cc:153-157)
+    sjpeg::EncoderParam param(70.f);
+    param.yuv_mode = SJPEG_YUV_420;
+    param.use_trellis = true;
+    std::string out, plain;
+    CHECK(sjpeg::Encode(rgb.data(), W, H, 3 * W, param, &out));
+    Save(dir, "trellis_q70_420", out);
+    param.use_trellis = false;
+    CHECK(sjpeg::Encode(rgb.data(), W, H, 3 * W, param, &plain));
+    CHECK(out != plain && out.size() <= plain.size());
+    param.use_trellis = true;
+    param.Huffman_compress = false;                    // method 3: the flag is ignored
+    std::string a, b;
+    CHECK(sjpeg::Encode(rgb.data(), W, H, 3 * W, param, &a));
+    param.use_trellis = false;
+    CHECK(sjpeg::Encode(rgb.data(), W, H, 3 * W, param, &b));
+    CHECK(a == b);
+  }
+
   // ---- multi-pass size / PSNR search (reference: src/dichotomy.cc; unit_test.cc TargetSize idea)
   {
     int idx = 0;

@@ -78,6 +78,7 @@ def test_cxx_api_behaviour_and_parity(tmp_path, oracle):
     extra = meta[20:len(meta) - (len(plain) - 20)]
     assert extra.startswith(b"\xff\xe5\x00\x04zz" + b"\xff\xe1") and b"\xff\xe1\x00\x1cExif\x00\x00II*\x00fake-exif-payloa\xff\xe2\xff\xffICC_PROFILE\x00\x01\x02" in extra
     assert extra.count(b"ICC_PROFILE\x00") == 2 and b"http://ns.adobe.com/xap/1.0/\x00<x:xmpmeta/>" in extra
+    assert read("trellis_q70_420") == oracle.encode_full(img, sj.make_tables(quality=70.0)[1], yuv_mode=1, method=7)
     # multi-pass searches: same nested loops as api_test.cc
     q60 = sj.make_tables(quality=60.0)[1]
     idx = 0

@@ -164,8 +164,6 @@ def test_unsupported_requests_fail_loudly():
     img = synth.g_struct(32, 32, 1)
     assert sj.SjpegEncode(img, 75.0, 0, sj.YUV_SHARP) is None
     assert "not available" in sj.last_error()
-    assert sj.SjpegEncode(img, 75.0, 7, sj.YUV_420) is None        # trellis
-    assert "trellis" in sj.last_error()
     lib = sj.lib()
     out = C.POINTER(C.c_uint8)()
     assert lib.SjpegEncode(img.ctypes.data, 32, 32, 96, C.byref(out), 75.0, 0, 7) == 0   # bad mode
@@ -444,3 +442,30 @@ def test_band_argument_errors(engine):
     with pytest.raises(sj.SjpegError):
         engine.stitch_bands(w, torch.zeros(2, dtype=torch.int64, device="cuda"), b"", out_cap=16)
     torch.cuda.synchronize()
+
+
+# ---- trellis quantization: methods 7 / 8 (reference src/quantize.cc:325-457) -----------------------
+
+def test_trellis_golden_and_random(oracle, golden_small):
+    n = 0
+    for key, want in golden_small.items():
+        img, mode, q, method = golden_input(key)
+        if method == 7:
+            assert sj.SjpegEncode(img, q, 7, mode) == want, key
+            assert sj.SjpegEncode(img, q, 8, mode) == want, key
+            n += 1
+    assert n == 3
+    rng = np.random.RandomState(77)
+    for _ in range(24):
+        w, h = int(rng.randint(1, 200)), int(rng.randint(1, 150))
+        img = synth.g_struct(w, h, int(rng.randint(1 << 30))) if rng.rand() < 0.6 else \
+            rng.randint(0, 256, (h, w, 3)).astype(np.uint8)
+        mode = int(rng.choice([1, 3, 4]))
+        q = float(rng.choice([5, 30, 60, 75, 90, 98]))
+        m = int(rng.choice([7, 8]))
+        assert sj.SjpegEncode(img, q, m, mode) == oracle.encode_method(img, q, mode, m), (w, h, mode, q, m)
+
+
+def test_trellis_1080p(oracle):
+    img = synth.g_struct(1920, 1080, 7654321)
+    assert sj.SjpegEncode(img, 75.0, 7, sj.YUV_420) == oracle.encode_method(img, 75.0, 1, 7)
