@@ -80,7 +80,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--frames", type=int, default=16, help="device-resident 4K frames per GPU per step")
+    ap.add_argument("--frames", type=int, default=64, help="device-resident 4K frames per GPU per step")
     ap.add_argument("--input", choices=["struct", "noise"], default="struct")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -155,12 +155,12 @@ def main():
     traffic = None
     try:
         import re
-        txt = open(os.path.join(ROOT, "profiles", "r01", "v3_pmc_summary.txt")).read()
+        txt = open(os.path.join(ROOT, "profiles", "r01", "v4_pmc_summary.txt")).read()
         blk = txt[txt.index("scan_segments<1"):]
         blk = blk[:blk.index("==", 5)] if "==" in blk[5:] else blk
         fetch = float(re.search(r"FETCH_SIZE\s+total=\S+\s+per_dispatch=(\S+)", blk).group(1))
         write = float(re.search(r"WRITE_SIZE\s+total=\S+\s+per_dispatch=(\S+)", blk).group(1))
-        if F == 16 and args.input == "struct":
+        if F == 64 and args.input == "struct":
             traffic = int((2.0 * fetch + write) * 1024)
     except Exception:
         traffic = None
