@@ -277,6 +277,22 @@ void sjpeg_hip_optimize_huffman(const uint32_t* freq, int yuv_mode,
 size_t sjpeg_hip_make_header_ex(int width, int height, int yuv_mode, const uint8_t quant[2][64],
                                 const sjpeg_hip_huffman_spec* specs, uint8_t* buf, size_t cap);
 
+/* The same with the metadata segments of the reference's EncoderParam (src/sjpeg.h:258-266) in
+ * front of the tables, in its order: raw application markers (verbatim), EXIF (one APP1), ICC
+ * profile (numbered APP2 chunks), XMP (one APP1, or main packet + extension chunks tied by the
+ * MD5 of the extension when it exceeds 64 KiB): src/headers.cc:63-180.  Returns 0 on invalid
+ * metadata (EXIF > 64 KiB, ICC >= 256 chunks, malformed extended XMP) or if cap is too small. */
+typedef struct sjpeg_hip_metadata {
+  const void* app_markers; size_t app_markers_size;
+  const void* exif;        size_t exif_size;
+  const void* iccp;        size_t iccp_size;
+  const void* xmp;         size_t xmp_size;
+  uint16_t xmp_split_point;                     /* 0 = default split of a long XMP packet */
+} sjpeg_hip_metadata;
+size_t sjpeg_hip_make_header_meta(int width, int height, int yuv_mode, const uint8_t quant[2][64],
+                                  const sjpeg_hip_huffman_spec* specs,
+                                  const sjpeg_hip_metadata* meta, uint8_t* buf, size_t cap);
+
 /* Duration in milliseconds of the dominant kernel (the fused colour+fDCT+quant+entropy
  * kernel) in the most recent sjpeg_hip_encode_scan() call on this engine, measured with
  * HIP events on the caller's stream.  Timing is recorded only after

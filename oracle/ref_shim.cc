@@ -42,6 +42,23 @@ size_t ref_encode_param(const uint8_t* rgb, int w, int h, int stride,
   return sjpeg::Encode(rgb, w, h, stride, param, out);
 }
 
+// sjpeg::Encode() with metadata (src/sjpeg.h:258-266), method 0.
+size_t ref_encode_meta(const uint8_t* rgb, int w, int h, int stride, float quality, int yuv_mode,
+                       const char* app, size_t app_size, const char* exif, size_t exif_size,
+                       const char* iccp, size_t iccp_size, const char* xmp, size_t xmp_size,
+                       int xmp_split, uint8_t** out) {
+  sjpeg::EncoderParam param(quality);
+  param.yuv_mode = static_cast<SjpegYUVMode>(yuv_mode);
+  param.Huffman_compress = false;
+  param.adaptive_quantization = false;
+  if (app != nullptr) param.app_markers.assign(app, app_size);
+  if (exif != nullptr) param.exif.assign(exif, exif_size);
+  if (iccp != nullptr) param.iccp.assign(iccp, iccp_size);
+  if (xmp != nullptr) param.xmp.assign(xmp, xmp_size);
+  param.xmp_split_point = static_cast<uint16_t>(xmp_split);
+  return sjpeg::Encode(rgb, w, h, stride, param, out);
+}
+
 // sjpeg::Encode() with the size/PSNR search enabled (src/dichotomy.cc:113-205).
 // target_mode: 1 = size (bytes), 2 = PSNR (dB).  q_out / value_out: what the default hook found.
 size_t ref_encode_search(const uint8_t* rgb, int w, int h, int stride, float quality, int yuv_mode,

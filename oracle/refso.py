@@ -111,6 +111,20 @@ class Ref:
                                        qmin, qmax, C.byref(out))
         return self._take(n, out)
 
+    def encode_meta(self, rgb, quality=75.0, yuv_mode=YUV_420, app_markers=b"", exif=b"", iccp=b"", xmp=b"",
+                    xmp_split_point=0):
+        rgb, w, h, stride = self._img(rgb, None)
+        out = _u8p()
+        self.lib.ref_encode_meta.restype = C.c_size_t
+        self.lib.ref_encode_meta.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int,
+                                             C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_char_p,
+                                             C.c_size_t, C.c_char_p, C.c_size_t, C.c_int, C.POINTER(_u8p)]
+        n = self.lib.ref_encode_meta(rgb.ctypes.data, w, h, stride, quality, yuv_mode,
+                                     app_markers or None, len(app_markers), exif or None, len(exif),
+                                     iccp or None, len(iccp), xmp or None, len(xmp), xmp_split_point,
+                                     C.byref(out))
+        return self._take(n, out)
+
     def compress(self, rgb, quality=75.0):
         rgb, w, h, _ = self._img(rgb, None)
         out = _u8p()

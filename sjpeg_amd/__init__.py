@@ -193,7 +193,7 @@ EXPORTED_C_SYMBOLS = [
     "sjpeg_hip_scan_histogram", "sjpeg_hip_scan_symbol_stats", "sjpeg_hip_adapt_quant",
     "sjpeg_hip_encode_scan_src", "sjpeg_hip_scan_coeffs_src", "sjpeg_hip_scan_histogram_src",
     "sjpeg_hip_scan_symbol_stats_src", "sjpeg_hip_scan_quant_error_src", "sjpeg_hip_engine_entropy_bits",
-    "sjpeg_hip_optimize_huffman", "sjpeg_hip_make_header_ex",
+    "sjpeg_hip_optimize_huffman", "sjpeg_hip_make_header_ex", "sjpeg_hip_make_header_meta",
     "sjpeg_hip_segment_count", "sjpeg_hip_band_bound", "sjpeg_hip_encode_band_src", "sjpeg_hip_stitch_bands",
     "sjpeg_hip_engine_set_timing", "sjpeg_hip_engine_last_scan_ms",
     "sjpeg_hip_engine_last_total_ms",
@@ -290,6 +290,31 @@ def make_header_ex(w, h, yuv_mode, quant, specs) -> bytes:
     if n == 0:
         raise SjpegError("sjpeg_hip_make_header_ex failed")
     return buf[:n].tobytes()
+
+
+class Metadata(C.Structure):
+    """struct sjpeg_hip_metadata (include/sjpeg_hip.h)."""
+    _fields_ = [("app_markers", C.c_char_p), ("app_markers_size", C.c_size_t),
+                ("exif", C.c_char_p), ("exif_size", C.c_size_t),
+                ("iccp", C.c_char_p), ("iccp_size", C.c_size_t),
+                ("xmp", C.c_char_p), ("xmp_size", C.c_size_t),
+                ("xmp_split_point", C.c_uint16)]
+
+
+def make_header_meta(w, h, yuv_mode, quant, specs=None, app_markers=b"", exif=b"", iccp=b"", xmp=b"",
+                     xmp_split_point=0):
+    """Header bytes SOI..SOS with metadata segments; None if the metadata is invalid."""
+    m = Metadata(app_markers or None, len(app_markers), exif or None, len(exif), iccp or None, len(iccp),
+                 xmp or None, len(xmp), xmp_split_point)
+    cap = 4096 + len(app_markers) + len(exif) + len(iccp) + len(xmp) + 64 * (len(iccp) // 65000 + len(xmp) // 65000 + 4)
+    buf = np.zeros(cap, np.uint8)
+    q = np.ascontiguousarray(quant, np.uint8).reshape(2, 64)
+    L = lib()
+    L.sjpeg_hip_make_header_meta.restype = C.c_size_t
+    L.sjpeg_hip_make_header_meta.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                             C.c_void_p, C.c_size_t]
+    n = L.sjpeg_hip_make_header_meta(w, h, yuv_mode, q.ctypes.data, specs, C.byref(m), buf.ctypes.data, cap)
+    return buf[:n].tobytes() if n else None
 
 
 def frame_bound(w, h, yuv_mode, header_size) -> int:

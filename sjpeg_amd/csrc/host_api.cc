@@ -832,6 +832,31 @@ size_t sjpeg_hip_make_header_ex(int width, int height, int yuv_mode, const uint8
   return h.size();
 }
 
+size_t sjpeg_hip_make_header_meta(int width, int height, int yuv_mode, const uint8_t quant[2][64],
+                                  const sjpeg_hip_huffman_spec* specs, const sjpeg_hip_metadata* meta,
+                                  uint8_t* buf, size_t cap) {
+  if (buf == nullptr || width <= 0 || height <= 0 || width > 65535 || height > 65535) return 0;
+  const HuffSpec* dc[2] = {&sjpeg_host::DefaultHuff(0, 0), &sjpeg_host::DefaultHuff(0, 1)};
+  const HuffSpec* ac[2] = {&sjpeg_host::DefaultHuff(1, 0), &sjpeg_host::DefaultHuff(1, 1)};
+  if (specs != nullptr) {
+    const int ntables = (yuv_mode == SJPEG_HIP_YUV400) ? 1 : 2;
+    for (int t = 0; t < ntables; ++t) { dc[t] = &specs[t]; ac[t] = &specs[2 + t]; }
+  }
+  sjpeg_host::Metadata m;
+  if (meta != nullptr) {
+    if (meta->app_markers != nullptr) m.app_markers.assign(static_cast<const char*>(meta->app_markers), meta->app_markers_size);
+    if (meta->exif != nullptr) m.exif.assign(static_cast<const char*>(meta->exif), meta->exif_size);
+    if (meta->iccp != nullptr) m.iccp.assign(static_cast<const char*>(meta->iccp), meta->iccp_size);
+    if (meta->xmp != nullptr) m.xmp.assign(static_cast<const char*>(meta->xmp), meta->xmp_size);
+    m.xmp_split = meta->xmp_split_point;
+  }
+  std::vector<uint8_t> h;
+  if (!sjpeg_host::AppendHeaders(width, height, yuv_mode, quant, dc, ac, &m, &h)) return 0;
+  if (h.size() > cap) return 0;
+  memcpy(buf, h.data(), h.size());
+  return h.size();
+}
+
 }  // extern "C"
 
 bool SjpegCompress(const uint8_t* rgb, int width, int height, float quality, std::string* output) {

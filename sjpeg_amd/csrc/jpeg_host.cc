@@ -163,6 +163,106 @@ bool LayoutFor(int yuv_mode, FrameLayout* L) {
   }
 }
 
+// MD5 (RFC 1321) of the extension part of a long XMP packet: its upper-case hex digest is the
+// GUID that ties the APP1 extension chunks to the main packet (headers.cc:114-160).
+static void Md5Hex(const uint8_t* data, size_t size, char out[32]) {
+  static const uint32_t kSine[64] = {
+      0xd76aa478u, 0xe8c7b756u, 0x242070dbu, 0xc1bdceeeu, 0xf57c0fafu, 0x4787c62au, 0xa8304613u, 0xfd469501u,
+      0x698098d8u, 0x8b44f7afu, 0xffff5bb1u, 0x895cd7beu, 0x6b901122u, 0xfd987193u, 0xa679438eu, 0x49b40821u,
+      0xf61e2562u, 0xc040b340u, 0x265e5a51u, 0xe9b6c7aau, 0xd62f105du, 0x02441453u, 0xd8a1e681u, 0xe7d3fbc8u,
+      0x21e1cde6u, 0xc33707d6u, 0xf4d50d87u, 0x455a14edu, 0xa9e3e905u, 0xfcefa3f8u, 0x676f02d9u, 0x8d2a4c8au,
+      0xfffa3942u, 0x8771f681u, 0x6d9d6122u, 0xfde5380cu, 0xa4beea44u, 0x4bdecfa9u, 0xf6bb4b60u, 0xbebfbc70u,
+      0x289b7ec6u, 0xeaa127fau, 0xd4ef3085u, 0x04881d05u, 0xd9d4d039u, 0xe6db99e5u, 0x1fa27cf8u, 0xc4ac5665u,
+      0xf4292244u, 0x432aff97u, 0xab9423a7u, 0xfc93a039u, 0x655b59c3u, 0x8f0ccc92u, 0xffeff47du, 0x85845dd1u,
+      0x6fa87e4fu, 0xfe2ce6e0u, 0xa3014314u, 0x4e0811a1u, 0xf7537e82u, 0xbd3af235u, 0x2ad7d2bbu, 0xeb86d391u};
+  static const int kRot[4][4] = {{7, 12, 17, 22}, {5, 9, 14, 20}, {4, 11, 16, 23}, {6, 10, 15, 21}};
+  uint32_t h[4] = {0x67452301u, 0xefcdab89u, 0x98badcfeu, 0x10325476u};
+  const uint64_t bit_len = static_cast<uint64_t>(size) * 8;
+  const size_t padded = ((size + 8) / 64 + 1) * 64;
+  std::vector<uint8_t> msg(padded, 0);
+  if (size > 0) memcpy(msg.data(), data, size);
+  msg[size] = 0x80;
+  for (int i = 0; i < 8; ++i) msg[padded - 8 + i] = static_cast<uint8_t>(bit_len >> (8 * i));
+  for (size_t off = 0; off < padded; off += 64) {
+    uint32_t w[16];
+    for (int i = 0; i < 16; ++i) {
+      const uint8_t* p = &msg[off + 4 * i];
+      w[i] = p[0] | (p[1] << 8) | (p[2] << 16) | (static_cast<uint32_t>(p[3]) << 24);
+    }
+    uint32_t a = h[0], b = h[1], c = h[2], d = h[3];
+    for (int i = 0; i < 64; ++i) {
+      uint32_t f;
+      int g;
+      switch (i >> 4) {
+        case 0: f = (b & c) | (~b & d); g = i; break;
+        case 1: f = (d & b) | (~d & c); g = (5 * i + 1) & 15; break;
+        case 2: f = b ^ c ^ d; g = (3 * i + 5) & 15; break;
+        default: f = c ^ (b | ~d); g = (7 * i) & 15; break;
+      }
+      const uint32_t t = a + f + kSine[i] + w[g];
+      const int r = kRot[i >> 4][i & 3];
+      a = d; d = c; c = b;
+      b = b + ((t << r) | (t >> (32 - r)));
+    }
+    h[0] += a; h[1] += b; h[2] += c; h[3] += d;
+  }
+  static const char kHex[] = "0123456789ABCDEF";
+  for (int i = 0; i < 16; ++i) {
+    const uint8_t byte = static_cast<uint8_t>(h[i >> 2] >> (8 * (i & 3)));
+    out[2 * i] = kHex[byte >> 4];
+    out[2 * i + 1] = kHex[byte & 15];
+  }
+}
+
+// WriteXMP / WriteXMPExtended (headers.cc:114-180)
+static bool AppendXmp(const std::string& xmp, uint16_t xmp_split, std::vector<uint8_t>* o) {
+  static const char kXmp[] = "http://ns.adobe.com/xap/1.0/";
+  const size_t seg = 2 + xmp.size() + sizeof(kXmp);
+  if (seg <= 0xffff) {
+    Put16(o, 0xffe1); Put16(o, static_cast<uint32_t>(seg));
+    PutBytes(o, kXmp, sizeof(kXmp));
+    PutBytes(o, xmp.data(), xmp.size());
+    return true;
+  }
+  // too long for one APP1: main packet (its HasExtendedXMP attribute receives the MD5 of the
+  // rest) + numbered extension chunks
+  const size_t kMainSize = 65503;
+  if (xmp.size() > (1u << 31)) return false;
+  size_t split = (xmp_split == 0) ? kMainSize : xmp_split;
+  split = std::min(split, xmp.size());
+  static const char kNote[] = "xmpNote:HasExtendedXMP=\"";
+  const size_t note = xmp.find(kNote);
+  if (note == std::string::npos) return false;                     // no extension attribute
+  if (note + 24 + 32 + 1 > split) return false;                     // ill-formed
+  if (xmp[note + 24 + 32] != '"') return false;
+  std::string main_part(xmp, 0, split);
+  const std::string ext(xmp, split);
+  char guid[32];
+  Md5Hex(reinterpret_cast<const uint8_t*>(ext.data()), ext.size(), guid);
+  memcpy(&main_part[note + 24], guid, 32);
+  const size_t main_seg = 2 + main_part.size() + sizeof(kXmp);
+  if (main_seg > 0xffff) return false;
+  Put16(o, 0xffe1); Put16(o, static_cast<uint32_t>(main_seg));
+  PutBytes(o, kXmp, sizeof(kXmp));
+  PutBytes(o, main_part.data(), main_part.size());
+  static const char kXmpExt[] = "http://ns.adobe.com/xmp/extension/";
+  const size_t kBuf = 65458;
+  const size_t head = sizeof(kXmpExt) + 40;                         // + GUID, total size, offset
+  const size_t nchunks = ext.size() / kBuf + 1;
+  size_t pos = 0;
+  for (size_t chunk = 0; chunk < nchunks; ++chunk) {
+    const size_t n = std::min(kBuf, ext.size() - pos);
+    Put16(o, 0xffe1); Put16(o, static_cast<uint32_t>(2 + head + n));
+    PutBytes(o, kXmpExt, sizeof(kXmpExt));
+    PutBytes(o, guid, 32);
+    Put16(o, static_cast<uint32_t>(ext.size() >> 16)); Put16(o, static_cast<uint32_t>(ext.size() & 0xffff));
+    Put16(o, static_cast<uint32_t>(pos >> 16)); Put16(o, static_cast<uint32_t>(pos & 0xffff));
+    PutBytes(o, ext.data() + pos, n);
+    pos += n;
+  }
+  return true;
+}
+
 bool AppendHeaders(int W, int H, int yuv_mode, const uint8_t quant[2][64],
                    const HuffSpec* dc[2], const HuffSpec* ac[2], const Metadata* meta,
                    std::vector<uint8_t>* o) {
@@ -199,15 +299,8 @@ bool AppendHeaders(int W, int H, int yuv_mode, const uint8_t quant[2][64],
         pos += n;
       }
     }
-    // XMP: a single APP1 when it fits (headers.cc:162-180)
-    if (!meta->xmp.empty()) {
-      static const char kXmp[] = "http://ns.adobe.com/xap/1.0/";
-      const size_t seg = 2 + meta->xmp.size() + sizeof(kXmp);
-      if (seg > 0xffff) return false;      // extended XMP: not supported by this build
-      Put16(o, 0xffe1); Put16(o, static_cast<uint32_t>(seg));
-      PutBytes(o, kXmp, sizeof(kXmp));
-      PutBytes(o, meta->xmp.data(), meta->xmp.size());
-    }
+    // XMP: a single APP1 when it fits (headers.cc:162-180), else main + extension chunks
+    if (!meta->xmp.empty() && !AppendXmp(meta->xmp, meta->xmp_split, o)) return false;
   }
   // DQT, 8-bit precision, zig-zag order (headers.cc:182-196)
   const int nq = (yuv_mode == SJPEG_HIP_YUV400) ? 1 : 2;

@@ -55,6 +55,23 @@ def search_cases():
                                 yield key, img, 60.0, mode, huff, adapt, tm, target, passes, tol
 
 
+def xmp_long(n):
+    """A long XMP packet with the HasExtendedXMP attribute the extension mechanism needs."""
+    head = b'<x:xmpmeta xmlns:x="adobe:ns:meta/"><rdf:Description xmpNote:HasExtendedXMP="' + b"0" * 32 + b'"/>'
+    return head + bytes(((i * 7 + 3) & 0x7f) | 0x20 for i in range(n - len(head)))
+
+
+def meta_cases():
+    """(key, kwargs of metadata) on the 40x24 G_struct picture, q80 4:2:0 method 0"""
+    yield "meta|none", dict()
+    yield "meta|exif+icc2+xmp+app", dict(exif=b"II*\0abc" * 10, iccp=b"i" * 70000, xmp=b"<x/>",
+                                         app_markers=b"\xff\xe5\x00\x04zz")
+    yield "meta|xmp70000", dict(xmp=xmp_long(70000))
+    yield "meta|xmp200000", dict(xmp=xmp_long(200000))
+    yield "meta|xmp66000|split200", dict(xmp=xmp_long(66000), xmp_split_point=200)
+    yield "meta|xmp_exact_two_chunks", dict(xmp=xmp_long(65503 + 65458))
+
+
 def main():
     from oracle import refso
     r = refso.ref()
@@ -64,6 +81,10 @@ def main():
         dig[key] = dict(size=len(out), md5=synth.md5(out))
     for key, img, q, mode, huff, adapt, tm, target, passes, tol in search_cases():
         out = r.encode_search(img, q, mode, huff, adapt, tm, target, passes, tol)
+        dig[key] = dict(size=len(out), md5=synth.md5(out))
+    img = synth.g_struct(40, 24, 3)
+    for key, kw in meta_cases():
+        out = r.encode_meta(img, 80.0, 1, **kw)
         dig[key] = dict(size=len(out), md5=synth.md5(out))
     with open(os.path.join(HERE, "extra.json"), "w") as f:
         json.dump(dig, f, indent=0, sort_keys=True)

@@ -222,3 +222,34 @@ def test_product_never_references_oracle():
     import subprocess
     needed = subprocess.check_output(["readelf", "-d", sj.LIB_PATH]).decode()
     assert "oracle" not in needed and "sjpeg_ref" not in needed
+
+
+def test_metadata_headers_match_reference_digests():
+    """APP markers, EXIF, chunked ICC, XMP and extended XMP (MD5-tied extension chunks,
+    reference src/headers.cc:63-180): header with metadata + the oracle's entropy segment must be
+    the reference's file (tests/golden/extra.json, generated from the real reference)."""
+    import importlib.util
+    import json
+    from oracle import orc, synth
+    here = os.path.join(ROOT, "tests", "golden")
+    spec = importlib.util.spec_from_file_location("make_golden_extra", os.path.join(here, "make_golden_extra.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    dig = json.load(open(os.path.join(here, "extra.json")))
+    img = synth.g_struct(40, 24, 3)
+    quant = sj.make_tables(quality=80.0)[1]
+    plain = orc.oracle().encode(img, 80.0, 1)
+    plain_hdr = sj.make_header(40, 24, 1, quant)
+    assert plain.startswith(plain_hdr)
+    n = 0
+    for key, kw in mod.meta_cases():
+        hdr = sj.make_header_meta(40, 24, 1, quant, **kw)
+        assert hdr is not None, key
+        full = hdr + plain[len(plain_hdr):]
+        assert len(full) == dig[key]["size"] and synth.md5(full) == dig[key]["md5"], key
+        n += 1
+    assert n == 6
+    # invalid metadata fails like the reference (src/headers.cc:77,95,122-125)
+    assert sj.make_header_meta(40, 24, 1, quant, exif=b"e" * 70000) is None
+    assert sj.make_header_meta(40, 24, 1, quant, iccp=b"i" * (256 * 65519)) is None
+    assert sj.make_header_meta(40, 24, 1, quant, xmp=b"x" * 70000) is None          # no HasExtendedXMP
