@@ -574,6 +574,203 @@ static void code_block(orc_bw* w, const int16_t zz[64], int* dc_pred,
   if (run > 0) bw_code(w, ac_codes[0x00]);      /* EOB iff last nonzero index < 63 */
 }
 
+/* ---------------------------------------------------------------- sharp YUV 4:2:0 (SJPEG_YUV_SHARP)
+ * src/yuv_convert.cc (the iterative "sharp" RGB -> YUV 4:2:0 conversion): the picture is held as
+ * luma-like W (10-bit) + chroma differences (R-W, G-W, B-W at half resolution); four sweeps
+ * upsample the chroma, compare with the gamma-correct targets and feed the differences back.  A
+ * sweep walks the row pairs top to bottom and updates the chroma rows IN PLACE (the row above a
+ * pair is already this sweep's, the row below is still the previous sweep's): that order is
+ * normative.  The two gamma tables come from libm's pow() exactly as the reference builds them. */
+#include <math.h>
+enum { kSfix = 2, kMaxY = (256 << kSfix) - 1, kGammaTab = 32, kG2LBits = 14 };
+static uint32_t g_g2l[kMaxY + 1];
+static uint32_t g_l2g[kGammaTab + 2];
+static int g_gamma_ready = 0;
+
+static void sharp_init_tables(void) {                       /* src/yuv_convert.cc:114-152 */
+  if (g_gamma_ready) return;
+  const double norm = 1. / kMaxY, scale = 1. / kGammaTab;
+  const double a = 0.099, thresh = 0.018, gamma = 1. / 0.45;
+  const double final_scale = 1 << kG2LBits;
+  for (int v = 0; v <= kMaxY; ++v) {
+    const double g = norm * v;
+    double value;
+    if (g <= thresh * 4.5) {
+      value = g / 4.5;
+    } else {
+      const double a_rec = 1. / (1. + a);
+      value = pow(a_rec * (g + a), gamma);
+    }
+    g_g2l[v] = (uint32_t)(value * final_scale + .5);
+  }
+  for (int v = 0; v <= kGammaTab; ++v) {
+    const double g = scale * v;
+    double value;
+    if (g <= thresh) value = 4.5 * g;
+    else value = (1. + a) * pow(g, 1. / gamma) - a;
+    g_l2g[v] = (uint32_t)(kMaxY * value) + (1 << kG2LBits >> 1);
+  }
+  g_l2g[kGammaTab + 1] = g_l2g[kGammaTab];
+  g_gamma_ready = 1;
+}
+
+static uint32_t lin2gamma(uint32_t value) {                 /* src/yuv_convert.cc:158-171 */
+  const uint32_t v = value * kGammaTab;
+  const uint32_t pos = v >> kG2LBits;
+  const uint32_t x = v - (pos << kG2LBits);
+  const uint32_t v0 = g_l2g[pos], v1 = g_l2g[pos + 1];
+  return v0 + (((v1 - v0) * x) >> kG2LBits);
+}
+static int sharp_clip_y(int y) { return y < 0 ? 0 : y > kMaxY ? kMaxY : y; }
+static int sharp_clip8(int v) { return v < 0 ? 0 : v > 255 ? 255 : v; }
+static uint32_t sharp_gray(uint32_t r, uint32_t g, uint32_t b) {            /* :435-438 */
+  return (13933u * r + 46871u * g + 4732u * b + (1u << 16 >> 1)) >> 16;
+}
+static uint32_t sharp_down(int a, int b, int c, int d) {                    /* :440-446 */
+  return lin2gamma((g_g2l[a] + g_g2l[b] + g_g2l[c] + g_g2l[d] + 2) >> 2);
+}
+
+/* W and chroma targets of one row pair of (interpolated or imported) 10-bit RGB: rows[row][c][x] */
+static void sharp_eval(const uint16_t* r0, const uint16_t* r1, int w, uint16_t* w0, uint16_t* w1,
+                       int16_t* uv /* [3][uv_w] */) {
+  const int uv_w = w >> 1;
+  for (int i = 0; i < w; ++i) {                                              /* UpdateW, :467-475 */
+    w0[i] = (uint16_t)lin2gamma(sharp_gray(g_g2l[r0[i]], g_g2l[r0[w + i]], g_g2l[r0[2 * w + i]]));
+    w1[i] = (uint16_t)lin2gamma(sharp_gray(g_g2l[r1[i]], g_g2l[r1[w + i]], g_g2l[r1[2 * w + i]]));
+  }
+  for (int i = 0; i < uv_w; ++i) {                                           /* UpdateChroma, :448-465 */
+    uint32_t c[3];
+    for (int k = 0; k < 3; ++k) {
+      c[k] = sharp_down(r0[k * w + 2 * i], r0[k * w + 2 * i + 1], r1[k * w + 2 * i], r1[k * w + 2 * i + 1]);
+    }
+    const int W = (int)sharp_gray(c[0], c[1], c[2]);
+    for (int k = 0; k < 3; ++k) uv[k * uv_w + i] = (int16_t)((int)c[k] - W);
+  }
+}
+
+void orc_sharp_yuv(const uint8_t* rgb, int W, int H, int stride, uint8_t* yp, uint8_t* up, uint8_t* vp) {
+  const int uv_w_out = (W + 1) >> 1;
+  if (W <= 4 || H <= 4) {
+    /* too small for the iterative conversion: plain averaging with its own constants (:57-100,674-690) */
+    for (int y = 0; y < H; y += 2) {
+      const uint8_t* r1 = rgb + (long)y * stride;
+      const uint8_t* r2 = (y < H - 1) ? r1 + stride : r1;
+      for (int row = 0; row < 2 && y + row < H; ++row) {
+        const uint8_t* rr = row ? r2 : r1;
+        for (int i = 0; i < W; ++i) {
+          const int v = 19595 * rr[3 * i] + 38469 * rr[3 * i + 1] + 7471 * rr[3 * i + 2];
+          yp[(y + row) * W + i] = (uint8_t)((v + (1 << 16 >> 1)) >> 16);
+        }
+      }
+      for (int i = 0; i < uv_w_out; ++i) {
+        int r, g, b;
+        if (2 * i + 1 < W) {
+          r = r1[6 * i] + r1[6 * i + 3] + r2[6 * i] + r2[6 * i + 3];
+          g = r1[6 * i + 1] + r1[6 * i + 4] + r2[6 * i + 1] + r2[6 * i + 4];
+          b = r1[6 * i + 2] + r1[6 * i + 5] + r2[6 * i + 2] + r2[6 * i + 5];
+        } else {
+          r = 2 * (r1[6 * i] + r2[6 * i]); g = 2 * (r1[6 * i + 1] + r2[6 * i + 1]); b = 2 * (r1[6 * i + 2] + r2[6 * i + 2]);
+        }
+        const int rnd = 1 << 18 >> 1;
+        up[(y >> 1) * uv_w_out + i] = (uint8_t)sharp_clip8(128 + ((-11058 * r - 21709 * g + 32768 * b + rnd) >> 18));
+        vp[(y >> 1) * uv_w_out + i] = (uint8_t)sharp_clip8(128 + ((32768 * r - 27439 * g - 5328 * b + rnd) >> 18));
+      }
+    }
+    return;
+  }
+  sharp_init_tables();
+  const int w = (W + 1) & ~1, h = (H + 1) & ~1, uv_w = w >> 1, uv_h = h >> 1;
+  uint16_t* rows = (uint16_t*)malloc((size_t)6 * w * sizeof(uint16_t));     /* two rows of [3][w] */
+  uint16_t* best_y = (uint16_t*)malloc((size_t)w * h * sizeof(uint16_t));
+  uint16_t* target_y = (uint16_t*)malloc((size_t)w * h * sizeof(uint16_t));
+  uint16_t* cur_w = (uint16_t*)malloc((size_t)2 * w * sizeof(uint16_t));
+  int16_t* best_uv = (int16_t*)malloc((size_t)3 * uv_w * uv_h * sizeof(int16_t));
+  int16_t* target_uv = (int16_t*)malloc((size_t)3 * uv_w * uv_h * sizeof(int16_t));
+  int16_t* cur_uv = (int16_t*)malloc((size_t)3 * uv_w * sizeof(int16_t));
+  uint16_t* r0 = rows; uint16_t* r1 = rows + 3 * w;
+  /* import: 8 -> 10 bits with a half, right / bottom replication (:492-510,608-632) */
+  for (int j = 0; j < H; j += 2) {
+    for (int row = 0; row < 2; ++row) {
+      uint16_t* dst = row ? r1 : r0;
+      const int yy = (j + row < H) ? j + row : j;
+      const uint8_t* src = rgb + (long)yy * stride;
+      for (int i = 0; i < w; ++i) {
+        const int xx = i < W ? i : W - 1;
+        for (int k = 0; k < 3; ++k) dst[k * w + i] = (uint16_t)((src[3 * xx + k] << kSfix) | (1 << kSfix >> 1));
+      }
+    }
+    for (int i = 0; i < w; ++i) {                                            /* StoreGray */
+      best_y[j * w + i] = (uint16_t)sharp_gray(r0[i], r0[w + i], r0[2 * w + i]);
+      best_y[(j + 1) * w + i] = (uint16_t)sharp_gray(r1[i], r1[w + i], r1[2 * w + i]);
+    }
+    sharp_eval(r0, r1, w, target_y + j * w, target_y + (j + 1) * w, target_uv + (j >> 1) * 3 * uv_w);
+  }
+  memcpy(best_uv, target_uv, (size_t)3 * uv_w * uv_h * sizeof(int16_t));
+  /* sweeps (:634-668) */
+  const uint64_t threshold = (uint64_t)(3.0 * w * h);
+  uint64_t prev_diff = ~(uint64_t)0;
+  for (int iter = 0; iter < 4; ++iter) {
+    uint64_t diff_sum = 0;
+    for (int j = 0; j < h; j += 2) {
+      const int ry = j >> 1;
+      const int16_t* cur = best_uv + ry * 3 * uv_w;
+      const int16_t* prev = best_uv + (ry > 0 ? ry - 1 : 0) * 3 * uv_w;
+      const int16_t* next = best_uv + (j < h - 2 ? ry + 1 : ry) * 3 * uv_w;
+      /* chroma upsampled 9:3:3:1 onto the two rows, added to W (InterpolateTwoRows, :512-541) */
+      for (int k = 0; k < 3; ++k) {
+        const int16_t *A = cur + k * uv_w, *P = prev + k * uv_w, *N = next + k * uv_w;
+        for (int x = 0; x < w; ++x) {
+          const int near = x >> 1;
+          int v_up, v_dn;
+          if (x == 0 || x == w - 1) {
+            v_up = (A[near] * 3 + P[near] + 2) >> 2;
+            v_dn = (A[near] * 3 + N[near] + 2) >> 2;
+          } else {
+            const int far = (x & 1) ? near + 1 : near - 1;
+            v_up = (A[near] * 9 + A[far] * 3 + P[near] * 3 + P[far] + 8) >> 4;
+            v_dn = (A[near] * 9 + A[far] * 3 + N[near] * 3 + N[far] + 8) >> 4;
+          }
+          r0[k * w + x] = (uint16_t)sharp_clip_y(best_y[j * w + x] + v_up);
+          r1[k * w + x] = (uint16_t)sharp_clip_y(best_y[(j + 1) * w + x] + v_dn);
+        }
+      }
+      sharp_eval(r0, r1, w, cur_w, cur_w + w, cur_uv);
+      for (int i = 0; i < 2 * w; ++i) {                                      /* SharpUpdateY, :175-185 */
+        const int d = (int)target_y[j * w + i] - (int)cur_w[i];
+        best_y[j * w + i] = (uint16_t)sharp_clip_y((int)best_y[j * w + i] + d);
+        diff_sum += (uint64_t)(d < 0 ? -d : d);
+      }
+      int16_t* bu = best_uv + ry * 3 * uv_w;                                 /* SharpUpdateRGB */
+      const int16_t* tu = target_uv + ry * 3 * uv_w;
+      for (int i = 0; i < 3 * uv_w; ++i) bu[i] = (int16_t)(bu[i] + (tu[i] - cur_uv[i]));
+    }
+    if (iter > 0) {
+      if (diff_sum < threshold) break;
+      if (diff_sum > prev_diff) break;
+    }
+    prev_diff = diff_sum;
+  }
+  /* back to 8-bit Y / U / V (:543-575; note the -11058 / -5328 constants of this file) */
+  const int rnd = 1 << 18 >> 1;
+  for (int j = 0; j < H; ++j) {
+    const int16_t* uvr = best_uv + (j >> 1) * 3 * uv_w;
+    for (int i = 0; i < W; ++i) {
+      const int Wv = best_y[j * w + i];
+      const int r = uvr[(i >> 1)] + Wv, g = uvr[uv_w + (i >> 1)] + Wv, b = uvr[2 * uv_w + (i >> 1)] + Wv;
+      yp[j * W + i] = (uint8_t)sharp_clip8((19595 * r + 38469 * g + 7471 * b + rnd) >> 18);
+    }
+  }
+  for (int j = 0; j < uv_h; ++j) {
+    const int16_t* uvr = best_uv + j * 3 * uv_w;
+    for (int i = 0; i < uv_w; ++i) {
+      const int r = uvr[i], g = uvr[uv_w + i], b = uvr[2 * uv_w + i];
+      up[j * uv_w + i] = (uint8_t)sharp_clip8(128 + ((-11058 * r - 21709 * g + 32768 * b + rnd) >> 18));
+      vp[j * uv_w + i] = (uint8_t)sharp_clip8(128 + ((32768 * r - 27439 * g - 5328 * b + rnd) >> 18));
+    }
+  }
+  free(rows); free(best_y); free(target_y); free(cur_w); free(best_uv); free(target_uv); free(cur_uv);
+}
+
 /* ---------------------------------------------------------------- scan drivers */
 
 static orc_source rgb_source(const uint8_t* rgb, int stride) {
@@ -1007,6 +1204,26 @@ size_t orc_encode_src(const orc_source* S, int W, int H, const uint8_t quant[2][
                       int qdelta_max_chroma, int yuv_mode, int method, uint8_t** out) {
   orc_scan s;
   *out = NULL;
+  if (yuv_mode == ORC_YUV_SHARP) {
+    /* EncoderSharp420 (src/encoders.cc:512-541): the sharp conversion makes planes, the planar
+     * 4:2:0 encoder takes them from there.  Packed RGB only (BGRA / RGBA are repacked first,
+     * src/api.cc:208-224). */
+    if (S->format != ORC_SRC_RGB) return 0;
+    const int uv_w = (W + 1) >> 1, uv_h = (H + 1) >> 1;
+    uint8_t* planes = (uint8_t*)malloc((size_t)W * H + 2 * (size_t)uv_w * uv_h);
+    orc_sharp_yuv(S->plane[0], W, H, S->stride[0], planes, planes + (size_t)W * H,
+                  planes + (size_t)W * H + (size_t)uv_w * uv_h);
+    orc_source P;
+    memset(&P, 0, sizeof(P));
+    P.format = ORC_SRC_YUV420;
+    P.plane[0] = planes; P.stride[0] = W;
+    P.plane[1] = planes + (size_t)W * H; P.stride[1] = uv_w;
+    P.plane[2] = P.plane[1] + (size_t)uv_w * uv_h; P.stride[2] = uv_w;
+    const size_t n = orc_encode_src(&P, W, H, quant, min_quant, q_bias, qdelta_max_luma,
+                                    qdelta_max_chroma, ORC_YUV_420, method, out);
+    free(planes);
+    return n;
+  }
   if (S->format == ORC_SRC_GRAY) yuv_mode = ORC_YUV_400;
   else if (S->format == ORC_SRC_YUV444) yuv_mode = ORC_YUV_444;
   else if (S->format >= ORC_SRC_YUV420) yuv_mode = ORC_YUV_420;
