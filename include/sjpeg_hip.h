@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SJPEG_HIP_ABI_VERSION 4
+#define SJPEG_HIP_ABI_VERSION 5
 
 enum {
   SJPEG_HIP_OK = 0,
@@ -191,6 +191,20 @@ int sjpeg_hip_scan_quant_error_src(sjpeg_hip_engine* engine, const struct sjpeg_
  * Synchronises the device.  With the coded size this gives what the reference's BitCounter
  * reports (src/bit_writer.h:292-365). */
 int sjpeg_hip_engine_entropy_bits(sjpeg_hip_engine* engine, uint64_t* bits, int nframes);
+
+/* ---- SJPEG_YUV_SHARP: the iterative sharp RGB -> YUV 4:2:0 conversion -----------------------------
+ * Replaces sjpeg::ApplySharpYUVConversion (src/yuv_convert.cc:674-697; the pre-pass of
+ * EncoderSharp420, src/encoders.cc:512-541).  `src` is packed RGB / BGRA / RGBA in device memory;
+ * the result is three tightly packed 8-bit planes per frame: Y width x height, U and V
+ * ((width+1)/2) x ((height+1)/2), frames y_frame_stride / uv_frame_stride bytes apart -- exactly
+ * what a SJPEG_HIP_SRC_YUV420 source of sjpeg_hip_encode_scan_src() then takes.  The row pairs of
+ * a picture are sequential by construction (in-place sweeps), pictures of a batch run in
+ * parallel.  d_workspace: sjpeg_hip_sharp_workspace() bytes of device memory. */
+size_t sjpeg_hip_sharp_workspace(int width, int height, int nframes);
+int sjpeg_hip_sharp_yuv(const sjpeg_hip_source* src, int width, int height, int nframes,
+                        uint8_t* d_y, uint8_t* d_u, uint8_t* d_v, int64_t y_frame_stride,
+                        int64_t uv_frame_stride, void* d_workspace, size_t workspace_size,
+                        void* stream);
 
 /* ---- one frame over several GPUs ------------------------------------------
  * The reference codes a frame as ONE entropy segment (src/enc.cc:276-307; no restart markers,

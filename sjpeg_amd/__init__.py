@@ -194,6 +194,7 @@ EXPORTED_C_SYMBOLS = [
     "sjpeg_hip_encode_scan_src", "sjpeg_hip_scan_coeffs_src", "sjpeg_hip_scan_histogram_src",
     "sjpeg_hip_scan_symbol_stats_src", "sjpeg_hip_scan_quant_error_src", "sjpeg_hip_engine_entropy_bits",
     "sjpeg_hip_optimize_huffman", "sjpeg_hip_make_header_ex", "sjpeg_hip_make_header_meta",
+    "sjpeg_hip_sharp_workspace", "sjpeg_hip_sharp_yuv",
     "sjpeg_hip_segment_count", "sjpeg_hip_band_bound", "sjpeg_hip_encode_band_src", "sjpeg_hip_stitch_bands",
     "sjpeg_hip_engine_set_timing", "sjpeg_hip_engine_last_scan_ms",
     "sjpeg_hip_engine_last_total_ms",

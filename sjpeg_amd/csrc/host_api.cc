@@ -108,6 +108,8 @@ struct DeviceContext {
   void* d_in = nullptr;  size_t in_cap = 0;
   void* d_out = nullptr; size_t out_cap = 0;
   void* d_stats = nullptr; size_t stats_cap = 0;
+  void* d_planes = nullptr; size_t planes_cap = 0;   // SJPEG_YUV_SHARP: converted planes
+  void* d_work = nullptr; size_t work_cap = 0;       //                  and the conversion's workspace
   uint64_t* d_size = nullptr;
   ~DeviceContext() {
     if (engine == nullptr) return;
@@ -115,6 +117,8 @@ struct DeviceContext {
     if (d_in) (void)hipFree(d_in);
     if (d_out) (void)hipFree(d_out);
     if (d_stats) (void)hipFree(d_stats);
+    if (d_planes) (void)hipFree(d_planes);
+    if (d_work) (void)hipFree(d_work);
     if (d_size) (void)hipFree(d_size);
     sjpeg_hip_engine_destroy(engine);
   }
@@ -227,13 +231,14 @@ bool Encoder::Run() {
     case SJPEG_YUV_420: mode = SJPEG_HIP_YUV420; break;
     case SJPEG_YUV_444: mode = SJPEG_HIP_YUV444; break;
     case SJPEG_YUV_400: mode = SJPEG_HIP_YUV400; break;
+    case SJPEG_YUV_SHARP: mode = SJPEG_HIP_YUV420; break;            // planes from the sharp pre-pass
     case SJPEG_YUV_AUTO:
-    case SJPEG_YUV_SHARP:
-      return Fail("SJPEG_YUV_AUTO / SJPEG_YUV_SHARP are not available in this build "
-                  "(riskiness analysis and sharp-YUV conversion are host features outside "
-                  "the GPU hot path); pick 420, 444 or 400");
+      return Fail("SJPEG_YUV_AUTO is not available in this build (the riskiness analysis needs the "
+                  "reference's trained score table, which this library does not ship); pick 420, "
+                  "sharp, 444 or 400");
     default: return Fail("unknown yuv_mode");                        // src/encoders.cc:553-567
   }
+  const bool sharp = (yuv_mode_ == SJPEG_YUV_SHARP);
   // method flags, reference: src/enc.cc:121-129
   const bool adaptive = method_ >= 3;
   const bool optimize = (method_ != 0) && (method_ != 3);
@@ -297,6 +302,24 @@ bool Encoder::Run() {
       dsrc.plane[i] = st < 0 ? d + pitch[i] * (rows[i] - 1) : d;
       dsrc.row_stride[i] = st < 0 ? -static_cast<long long>(pitch[i]) : static_cast<long long>(pitch[i]);
     }
+  }
+  if (sharp) {
+    // EncoderSharp420 (src/encoders.cc:512-541): the sharp conversion turns the RGB picture into
+    // Y / U / V planes on the device; from here on this is the planar 4:2:0 encoder.
+    const size_t cw = (static_cast<size_t>(W_) + 1) / 2, ch = (static_cast<size_t>(H_) + 1) / 2;
+    const size_t ysz = static_cast<size_t>(W_) * H_, csz = cw * ch;
+    const size_t wsz = sjpeg_hip_sharp_workspace(W_, H_, 1);
+    if (!ctx.Ensure(&ctx.d_planes, &ctx.planes_cap, ysz + 2 * csz + 64)) return false;
+    if (!ctx.Ensure(&ctx.d_work, &ctx.work_cap, wsz)) return false;
+    uint8_t* const py = static_cast<uint8_t*>(ctx.d_planes);
+    if (sjpeg_hip_sharp_yuv(&dsrc, W_, H_, 1, py, py + ysz, py + ysz + csz, 0, 0, ctx.d_work, wsz, nullptr) != 0) {
+      return Fail("sjpeg_hip_sharp_yuv failed");
+    }
+    memset(&dsrc, 0, sizeof(dsrc));
+    dsrc.format = SJPEG_HIP_SRC_YUV420;
+    dsrc.plane[0] = py; dsrc.row_stride[0] = W_;
+    dsrc.plane[1] = py + ysz; dsrc.row_stride[1] = static_cast<long long>(cw);
+    dsrc.plane[2] = py + ysz + csz; dsrc.row_stride[2] = static_cast<long long>(cw);
   }
   const int nb_comps = (mode == SJPEG_HIP_YUV400) ? 1 : 3;
 

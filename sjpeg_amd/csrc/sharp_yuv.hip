@@ -1,0 +1,370 @@
+// sharp_yuv.hip -- SJPEG_YUV_SHARP: the iterative "sharp" RGB -> YUV 4:2:0 conversion on gfx950.
+//
+// Reference: /root/reference/src/yuv_convert.cc (ApplySharpYUVConversion / PreprocessARGB).  The
+// picture is held as a 10-bit luma-like plane W plus chroma differences (R-W, G-W, B-W) at half
+// resolution; up to four sweeps upsample the chroma (9:3:3:1), compare the result with the
+// gamma-correct targets and feed the differences back.  A sweep walks the row pairs top to bottom
+// and updates the chroma rows IN PLACE -- the row above a pair already belongs to this sweep, the
+// row below still to the previous one -- so the row pairs of one picture are inherently
+// sequential; the parallelism is across the width of a row pair (one workgroup per picture,
+// barriers between row pairs) and across the pictures of a batch.  The import and the final
+// conversion have no such dependency and run one thread per chroma sample.
+//
+// Everything is integer arithmetic on the reference's fixed-point formats; the two gamma tables
+// are built on the host with libm's pow() exactly as the reference builds them (:114-152).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+#include <mutex>
+#include <string>
+
+#include "sjpeg_hip.h"
+
+namespace {
+
+constexpr int kSfix = 2;                          // extra precision bits of W and RGB
+constexpr int kMaxY = (256 << kSfix) - 1;
+constexpr int kGammaTab = 32;
+constexpr int kG2LBits = 14;
+constexpr int kSweepThreads = 1024;
+
+struct GammaTables {
+  uint32_t g2l[kMaxY + 1];                        // gamma -> linear, 14 fractional bits
+  uint32_t l2g[kGammaTab + 2];                    // linear -> gamma, interpolated
+};
+
+struct SharpArgs {
+  const uint8_t* rgb;
+  long long row_stride, frame_stride;
+  int pix_step, r_off, g_off, b_off;              // bytes per pixel and channel positions
+  int W, H, w, h, uv_w, uv_h;                     // w, h: padded to even
+  const GammaTables* tab;
+  uint16_t* best_y;  uint16_t* target_y;          // [nframes][h][w]
+  int16_t* best_uv;  int16_t* target_uv;          // [nframes][uv_h][3][uv_w]
+  int16_t* row_uv;                                // [nframes][3][uv_w]: chroma of the row pair in flight
+  uint8_t* y; uint8_t* u; uint8_t* v;
+  long long y_frame_stride, uv_frame_stride;
+};
+
+__device__ __forceinline__ uint32_t lin2gamma(const uint32_t* l2g, uint32_t value) {   // :158-171
+  const uint32_t v = value * kGammaTab;
+  const uint32_t pos = v >> kG2LBits;
+  const uint32_t x = v - (pos << kG2LBits);
+  const uint32_t v0 = l2g[pos], v1 = l2g[pos + 1];
+  return v0 + (((v1 - v0) * x) >> kG2LBits);
+}
+__device__ __forceinline__ int clip_y(int y) { return y < 0 ? 0 : y > kMaxY ? kMaxY : y; }
+__device__ __forceinline__ int clip8(int v) { return v < 0 ? 0 : v > 255 ? 255 : v; }
+__device__ __forceinline__ uint32_t gray(uint32_t r, uint32_t g, uint32_t b) {          // :435-438
+  return (13933u * r + 46871u * g + 4732u * b + (1u << 16 >> 1)) >> 16;
+}
+
+// W targets of a 2x2 group of 10-bit RGB pixels (UpdateW, :467-475) and its chroma target
+// (UpdateChroma / ScaleDown, :440-465).  px[row][col][channel].
+__device__ __forceinline__ void eval_group(const uint32_t* g2l, const uint32_t* l2g, const int px[2][2][3],
+                                           int wout[2][2], int uv[3]) {
+  uint32_t lin[2][2][3];
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) lin[r][c][k] = g2l[px[r][c][k]];
+      wout[r][c] = static_cast<int>(lin2gamma(l2g, gray(lin[r][c][0], lin[r][c][1], lin[r][c][2])));
+    }
+  }
+  uint32_t ch[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    ch[k] = lin2gamma(l2g, (lin[0][0][k] + lin[0][1][k] + lin[1][0][k] + lin[1][1][k] + 2) >> 2);
+  }
+  const int Wv = static_cast<int>(gray(ch[0], ch[1], ch[2]));
+#pragma unroll
+  for (int k = 0; k < 3; ++k) uv[k] = static_cast<int16_t>(static_cast<int>(ch[k]) - Wv);
+}
+
+// ---- import: 8 -> 10 bits, W and chroma targets (:492-510,608-632); one thread per chroma sample
+__global__ __launch_bounds__(256) void sharp_import(const SharpArgs a) {
+  const int frame = blockIdx.z;
+  const int c = blockIdx.x * 256 + threadIdx.x, ry = blockIdx.y;
+  if (c >= a.uv_w) return;
+  const uint8_t* base = a.rgb + frame * a.frame_stride;
+  int px[2][2][3];
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const int yy = min(2 * ry + r, a.H - 1);                 // bottom replication
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc) {
+      const int xx = min(2 * c + cc, a.W - 1);               // right replication
+      const uint8_t* p = base + yy * a.row_stride + static_cast<long long>(xx) * a.pix_step;
+      px[r][cc][0] = (p[a.r_off] << kSfix) | (1 << kSfix >> 1);
+      px[r][cc][1] = (p[a.g_off] << kSfix) | (1 << kSfix >> 1);
+      px[r][cc][2] = (p[a.b_off] << kSfix) | (1 << kSfix >> 1);
+    }
+  }
+  int wt[2][2], uv[3];
+  eval_group(a.tab->g2l, a.tab->l2g, px, wt, uv);
+  const size_t yo = static_cast<size_t>(frame) * a.w * a.h;
+  const size_t uo = (static_cast<size_t>(frame) * a.uv_h + ry) * 3 * a.uv_w;
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc) {
+      const size_t o = yo + static_cast<size_t>(2 * ry + r) * a.w + 2 * c + cc;
+      a.best_y[o] = static_cast<uint16_t>(gray(px[r][cc][0], px[r][cc][1], px[r][cc][2]));   // StoreGray
+      a.target_y[o] = static_cast<uint16_t>(wt[r][cc]);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    a.target_uv[uo + k * a.uv_w + c] = static_cast<int16_t>(uv[k]);
+    a.best_uv[uo + k * a.uv_w + c] = static_cast<int16_t>(uv[k]);
+  }
+}
+
+// ---- the sweeps (:634-668): one workgroup per picture
+__global__ __launch_bounds__(kSweepThreads) void sharp_sweeps(const SharpArgs a) {
+  __shared__ uint32_t g2l[kMaxY + 1];
+  __shared__ uint32_t l2g[kGammaTab + 2];
+  __shared__ unsigned long long red[kSweepThreads / 64];
+  __shared__ int stop;
+  const int frame = blockIdx.x, tid = threadIdx.x;
+  for (int i = tid; i <= kMaxY; i += kSweepThreads) g2l[i] = a.tab->g2l[i];
+  if (tid < kGammaTab + 2) l2g[tid] = a.tab->l2g[tid];
+  uint16_t* const best_y = a.best_y + static_cast<size_t>(frame) * a.w * a.h;
+  const uint16_t* const target_y = a.target_y + static_cast<size_t>(frame) * a.w * a.h;
+  int16_t* const best_uv = a.best_uv + static_cast<size_t>(frame) * a.uv_h * 3 * a.uv_w;
+  const int16_t* const target_uv = a.target_uv + static_cast<size_t>(frame) * a.uv_h * 3 * a.uv_w;
+  int16_t* const row_uv = a.row_uv + static_cast<size_t>(frame) * 3 * a.uv_w;
+  const int w = a.w, h = a.h, uv_w = a.uv_w;
+  const unsigned long long threshold = static_cast<unsigned long long>(3.0 * w * h);
+  unsigned long long prev_diff = ~0ull;
+  __syncthreads();
+  for (int iter = 0; iter < 4; ++iter) {
+    unsigned long long diff = 0;
+    for (int j = 0; j < h; j += 2) {
+      const int ry = j >> 1;
+      const int16_t* const cur = best_uv + static_cast<size_t>(ry) * 3 * uv_w;
+      const int16_t* const prev = best_uv + static_cast<size_t>(ry > 0 ? ry - 1 : 0) * 3 * uv_w;
+      const int16_t* const next = best_uv + static_cast<size_t>(j < h - 2 ? ry + 1 : ry) * 3 * uv_w;
+      // the chroma this sweep measures goes to a side row until all reads of the row pair are done
+      for (int c = tid; c < uv_w; c += kSweepThreads) {
+        // chroma upsampled 9:3:3:1 onto the four pixels of the group, added to W
+        // (InterpolateTwoRows / SharpFilterRow / Filter2, :195-203,485-541)
+        int px[2][2][3];
+        const int cl = c > 0 ? c - 1 : 0, cr = c < uv_w - 1 ? c + 1 : uv_w - 1;
+        const int wy[2][2] = {{best_y[static_cast<size_t>(j) * w + 2 * c], best_y[static_cast<size_t>(j) * w + 2 * c + 1]},
+                              {best_y[static_cast<size_t>(j + 1) * w + 2 * c], best_y[static_cast<size_t>(j + 1) * w + 2 * c + 1]}};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const int A = cur[k * uv_w + c], Al = cur[k * uv_w + cl], Ar = cur[k * uv_w + cr];
+          const int P = prev[k * uv_w + c], Pl = prev[k * uv_w + cl], Pr = prev[k * uv_w + cr];
+          const int N = next[k * uv_w + c], Nl = next[k * uv_w + cl], Nr = next[k * uv_w + cr];
+          int up0, up1, dn0, dn1;
+          if (c == 0) { up0 = (A * 3 + P + 2) >> 2; dn0 = (A * 3 + N + 2) >> 2; }
+          else { up0 = (A * 9 + Al * 3 + P * 3 + Pl + 8) >> 4; dn0 = (A * 9 + Al * 3 + N * 3 + Nl + 8) >> 4; }
+          if (c == uv_w - 1) { up1 = (A * 3 + P + 2) >> 2; dn1 = (A * 3 + N + 2) >> 2; }
+          else { up1 = (A * 9 + Ar * 3 + P * 3 + Pr + 8) >> 4; dn1 = (A * 9 + Ar * 3 + N * 3 + Nr + 8) >> 4; }
+          px[0][0][k] = clip_y(wy[0][0] + up0); px[0][1][k] = clip_y(wy[0][1] + up1);
+          px[1][0][k] = clip_y(wy[1][0] + dn0); px[1][1][k] = clip_y(wy[1][1] + dn1);
+        }
+        int wt[2][2], uv[3];
+        eval_group(g2l, l2g, px, wt, uv);
+        // SharpUpdateY (:175-185) on the four pixels
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+#pragma unroll
+          for (int cc = 0; cc < 2; ++cc) {
+            const size_t o = static_cast<size_t>(j + r) * w + 2 * c + cc;
+            const int d = static_cast<int>(target_y[o]) - wt[r][cc];
+            best_y[o] = static_cast<uint16_t>(clip_y(wy[r][cc] + d));
+            diff += static_cast<unsigned long long>(d < 0 ? -d : d);
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) row_uv[k * uv_w + c] = static_cast<int16_t>(uv[k]);
+      }
+      __syncthreads();                              // all neighbours have read this chroma row
+      // SharpUpdateRGB (:187-193): the row becomes this sweep's
+      for (int c = tid; c < uv_w; c += kSweepThreads) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const size_t o = static_cast<size_t>(ry) * 3 * uv_w + k * uv_w + c;
+          best_uv[o] = static_cast<int16_t>(best_uv[o] + (target_uv[o] - row_uv[k * uv_w + c]));
+        }
+      }
+      __syncthreads();
+    }
+    // exit test (:660-666): sum of |dW| over the picture
+    for (int d = 32; d > 0; d >>= 1) diff += __shfl_down(diff, d, 64);
+    if ((tid & 63) == 0) red[tid >> 6] = diff;
+    __syncthreads();
+    if (tid == 0) {
+      unsigned long long sum = 0;
+      for (int i = 0; i < kSweepThreads / 64; ++i) sum += red[i];
+      stop = (iter > 0 && (sum < threshold || sum > prev_diff)) ? 1 : 0;
+      red[0] = sum;
+    }
+    __syncthreads();
+    prev_diff = red[0];
+    const int s = stop;
+    __syncthreads();
+    if (s) break;
+  }
+}
+
+// ---- back to 8-bit planes (:543-575; this file's own -11058 / -5328 constants)
+__global__ __launch_bounds__(256) void sharp_export(const SharpArgs a) {
+  const int frame = blockIdx.z;
+  const int c = blockIdx.x * 256 + threadIdx.x, ry = blockIdx.y;
+  if (c >= a.uv_w) return;
+  const size_t uo = (static_cast<size_t>(frame) * a.uv_h + ry) * 3 * a.uv_w;
+  const int r = a.best_uv[uo + c], g = a.best_uv[uo + a.uv_w + c], b = a.best_uv[uo + 2 * a.uv_w + c];
+  const int rnd = 1 << 18 >> 1;
+  const int cw = (a.W + 1) >> 1;
+  if (c < cw && ry < ((a.H + 1) >> 1)) {
+    uint8_t* up = a.u + frame * a.uv_frame_stride + static_cast<size_t>(ry) * cw;
+    uint8_t* vp = a.v + frame * a.uv_frame_stride + static_cast<size_t>(ry) * cw;
+    up[c] = static_cast<uint8_t>(clip8(128 + ((-11058 * r - 21709 * g + 32768 * b + rnd) >> 18)));
+    vp[c] = static_cast<uint8_t>(clip8(128 + ((32768 * r - 27439 * g - 5328 * b + rnd) >> 18)));
+  }
+  const size_t yo = static_cast<size_t>(frame) * a.w * a.h;
+#pragma unroll
+  for (int rr = 0; rr < 2; ++rr) {
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc) {
+      const int x = 2 * c + cc, y = 2 * ry + rr;
+      if (x < a.W && y < a.H) {
+        const int Wv = a.best_y[yo + static_cast<size_t>(y) * a.w + x];
+        a.y[frame * a.y_frame_stride + static_cast<size_t>(y) * a.W + x] =
+            static_cast<uint8_t>(clip8((19595 * (r + Wv) + 38469 * (g + Wv) + 7471 * (b + Wv) + rnd) >> 18));
+      }
+    }
+  }
+}
+
+// ---- pictures too small for the iterative conversion (:57-100,674-690): plain averaging
+__global__ __launch_bounds__(64) void sharp_small(const SharpArgs a) {
+  const int frame = blockIdx.x;
+  const uint8_t* base = a.rgb + frame * a.frame_stride;
+  const int cw = (a.W + 1) >> 1, ch = (a.H + 1) >> 1;
+  for (int i = threadIdx.x; i < a.W * a.H; i += 64) {
+    const int x = i % a.W, y = i / a.W;
+    const uint8_t* p = base + y * a.row_stride + static_cast<long long>(x) * a.pix_step;
+    const int v = 19595 * p[a.r_off] + 38469 * p[a.g_off] + 7471 * p[a.b_off];
+    a.y[frame * a.y_frame_stride + i] = static_cast<uint8_t>((v + (1 << 16 >> 1)) >> 16);
+  }
+  for (int i = threadIdx.x; i < cw * ch; i += 64) {
+    const int cx = i % cw, cy = i / cw;
+    const int y0 = 2 * cy, y1 = min(2 * cy + 1, a.H - 1);
+    const int x0 = 2 * cx, x1 = 2 * cx + 1;
+    const uint8_t* p00 = base + y0 * a.row_stride + static_cast<long long>(x0) * a.pix_step;
+    const uint8_t* p10 = base + y1 * a.row_stride + static_cast<long long>(x0) * a.pix_step;
+    int r, g, b;
+    if (x1 < a.W) {
+      const uint8_t* p01 = p00 + a.pix_step;
+      const uint8_t* p11 = p10 + a.pix_step;
+      r = p00[a.r_off] + p01[a.r_off] + p10[a.r_off] + p11[a.r_off];
+      g = p00[a.g_off] + p01[a.g_off] + p10[a.g_off] + p11[a.g_off];
+      b = p00[a.b_off] + p01[a.b_off] + p10[a.b_off] + p11[a.b_off];
+    } else {
+      r = 2 * (p00[a.r_off] + p10[a.r_off]); g = 2 * (p00[a.g_off] + p10[a.g_off]); b = 2 * (p00[a.b_off] + p10[a.b_off]);
+    }
+    const int rnd = 1 << 18 >> 1;
+    a.u[frame * a.uv_frame_stride + i] = static_cast<uint8_t>(clip8(128 + ((-11058 * r - 21709 * g + 32768 * b + rnd) >> 18)));
+    a.v[frame * a.uv_frame_stride + i] = static_cast<uint8_t>(clip8(128 + ((32768 * r - 27439 * g - 5328 * b + rnd) >> 18)));
+  }
+}
+
+GammaTables g_tables;
+std::once_flag g_tables_once;
+
+void build_tables() {                               // reference InitGammaTablesF, :114-152
+  const double norm = 1. / kMaxY, scale = 1. / kGammaTab;
+  const double a = 0.099, thresh = 0.018, gamma = 1. / 0.45;
+  const double final_scale = 1 << kG2LBits;
+  for (int v = 0; v <= kMaxY; ++v) {
+    const double g = norm * v;
+    double value;
+    if (g <= thresh * 4.5) {
+      value = g / 4.5;
+    } else {
+      const double a_rec = 1. / (1. + a);
+      value = pow(a_rec * (g + a), gamma);
+    }
+    g_tables.g2l[v] = static_cast<uint32_t>(value * final_scale + .5);
+  }
+  for (int v = 0; v <= kGammaTab; ++v) {
+    const double g = scale * v;
+    double value;
+    if (g <= thresh) value = 4.5 * g;
+    else value = (1. + a) * pow(g, 1. / gamma) - a;
+    g_tables.l2g[v] = static_cast<uint32_t>(kMaxY * value) + (1 << kG2LBits >> 1);
+  }
+  g_tables.l2g[kGammaTab + 1] = g_tables.l2g[kGammaTab];
+}
+
+size_t align256(size_t n) { return (n + 255) & ~size_t(255); }
+
+}  // namespace
+
+extern "C" {
+
+size_t sjpeg_hip_sharp_workspace(int width, int height, int nframes) {
+  if (width <= 0 || height <= 0 || width > 65535 || height > 65535 || nframes <= 0) return 0;
+  const size_t w = (static_cast<size_t>(width) + 1) & ~size_t(1), h = (static_cast<size_t>(height) + 1) & ~size_t(1);
+  const size_t per = 2 * align256(w * h * 2) + 2 * align256(3 * (w / 2) * (h / 2) * 2) + align256(3 * (w / 2) * 2);
+  return align256(sizeof(GammaTables)) + per * static_cast<size_t>(nframes);
+}
+
+int sjpeg_hip_sharp_yuv(const sjpeg_hip_source* src, int width, int height, int nframes,
+                        uint8_t* d_y, uint8_t* d_u, uint8_t* d_v, int64_t y_frame_stride,
+                        int64_t uv_frame_stride, void* d_workspace, size_t workspace_size, void* stream) {
+  if (src == nullptr || src->plane[0] == nullptr || d_y == nullptr || d_u == nullptr || d_v == nullptr ||
+      d_workspace == nullptr) {
+    return SJPEG_HIP_EINVAL;
+  }
+  if (workspace_size < sjpeg_hip_sharp_workspace(width, height, nframes) || nframes > 65535) return SJPEG_HIP_EINVAL;
+  SharpArgs a;
+  memset(&a, 0, sizeof(a));
+  switch (src->format) {
+    case SJPEG_HIP_SRC_RGB: a.pix_step = 3; a.r_off = 0; a.g_off = 1; a.b_off = 2; break;
+    case SJPEG_HIP_SRC_BGRA: a.pix_step = 4; a.r_off = 2; a.g_off = 1; a.b_off = 0; break;
+    case SJPEG_HIP_SRC_RGBA: a.pix_step = 4; a.r_off = 0; a.g_off = 1; a.b_off = 2; break;
+    default: return SJPEG_HIP_EINVAL;                // the sharp conversion starts from RGB
+  }
+  const int64_t st_abs = src->row_stride[0] < 0 ? -src->row_stride[0] : src->row_stride[0];
+  if (st_abs < static_cast<int64_t>(a.pix_step) * width) return SJPEG_HIP_EINVAL;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  a.rgb = static_cast<const uint8_t*>(src->plane[0]);
+  a.row_stride = src->row_stride[0]; a.frame_stride = src->frame_stride[0];
+  a.W = width; a.H = height;
+  a.w = (width + 1) & ~1; a.h = (height + 1) & ~1; a.uv_w = a.w >> 1; a.uv_h = a.h >> 1;
+  a.y = d_y; a.u = d_u; a.v = d_v;
+  a.y_frame_stride = y_frame_stride; a.uv_frame_stride = uv_frame_stride;
+  if (width <= 4 || height <= 4) {
+    hipLaunchKernelGGL(sharp_small, dim3(nframes), dim3(64), 0, st, a);
+    return hipGetLastError() == hipSuccess ? 0 : SJPEG_HIP_ERUNTIME;
+  }
+  std::call_once(g_tables_once, build_tables);
+  uint8_t* p = static_cast<uint8_t*>(d_workspace);
+  a.tab = reinterpret_cast<const GammaTables*>(p);
+  if (hipMemcpyAsync(p, &g_tables, sizeof(GammaTables), hipMemcpyHostToDevice, st) != hipSuccess) return SJPEG_HIP_ERUNTIME;
+  p += align256(sizeof(GammaTables));
+  const size_t ysz = align256(static_cast<size_t>(a.w) * a.h * 2) , usz = align256(static_cast<size_t>(3) * a.uv_w * a.uv_h * 2);
+  // per-frame arrays are addressed as [frame][...] with the un-padded sizes: keep them contiguous
+  a.best_y = reinterpret_cast<uint16_t*>(p); p += ysz * nframes;
+  a.target_y = reinterpret_cast<uint16_t*>(p); p += ysz * nframes;
+  a.best_uv = reinterpret_cast<int16_t*>(p); p += usz * nframes;
+  a.target_uv = reinterpret_cast<int16_t*>(p); p += usz * nframes;
+  a.row_uv = reinterpret_cast<int16_t*>(p);
+  const dim3 grid((a.uv_w + 255) / 256, a.uv_h, nframes);
+  hipLaunchKernelGGL(sharp_import, grid, dim3(256), 0, st, a);
+  hipLaunchKernelGGL(sharp_sweeps, dim3(nframes), dim3(kSweepThreads), 0, st, a);
+  hipLaunchKernelGGL(sharp_export, grid, dim3(256), 0, st, a);
+  return hipGetLastError() == hipSuccess ? 0 : SJPEG_HIP_ERUNTIME;
+}
+
+}  // extern "C"

@@ -4,6 +4,7 @@ sizes through digests + size-independent properties.  Bar: BIT-EXACT (integer/by
 import ctypes as C
 import hashlib
 import io
+import os
 import threading
 
 import numpy as np
@@ -16,6 +17,8 @@ pytestmark = pytest.mark.gpu
 
 torch = pytest.importorskip("torch")
 import sjpeg_amd as sj  # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.fixture(scope="module")
@@ -162,7 +165,7 @@ def test_abi_argument_errors(engine):
 
 def test_unsupported_requests_fail_loudly():
     img = synth.g_struct(32, 32, 1)
-    assert sj.SjpegEncode(img, 75.0, 0, sj.YUV_SHARP) is None
+    assert sj.SjpegEncode(img, 75.0, 0, sj.YUV_AUTO) is None        # needs the reference's score table
     assert "not available" in sj.last_error()
     lib = sj.lib()
     out = C.POINTER(C.c_uint8)()
@@ -469,3 +472,38 @@ def test_trellis_golden_and_random(oracle, golden_small):
 def test_trellis_1080p(oracle):
     img = synth.g_struct(1920, 1080, 7654321)
     assert sj.SjpegEncode(img, 75.0, 7, sj.YUV_420) == oracle.encode_method(img, 75.0, 1, 7)
+
+
+# ---- SJPEG_YUV_SHARP: iterative sharp RGB -> YUV 4:2:0 conversion (reference src/yuv_convert.cc) ----
+
+def test_sharp_yuv_c1_known_answer(oracle):
+    """BASELINE config #1 picture: SjpegCompress(q75) of the reference resolves to (method 4, SHARP)
+    = 2571 bytes, MD5 acc8ce81...."""
+    img = np.fromfile(os.path.join(ROOT, "tests", "golden", "test128.rgb"), np.uint8).reshape(128, 128, 3)
+    got = sj.SjpegEncode(img, 75.0, 4, sj.YUV_SHARP)
+    assert got is not None, sj.last_error()
+    assert len(got) == 2571 and hashlib.md5(got).hexdigest() == "acc8ce8111f5ff4b32b3faa15ad5d994"
+    assert got == oracle.encode_method(img, 75.0, 2, 4)
+
+
+def test_sharp_yuv_random_vs_oracle(oracle):
+    rng = np.random.RandomState(41)
+    for _ in range(30):
+        w, h = int(rng.randint(1, 200)), int(rng.randint(1, 160))
+        kind = rng.rand()
+        if kind < 0.4:
+            img = synth.g_struct(w, h, int(rng.randint(1 << 30)))
+        elif kind < 0.8:
+            img = rng.randint(0, 256, (h, w, 3)).astype(np.uint8)
+        else:
+            img = (rng.randint(0, 2, (h, w, 3)) * 255).astype(np.uint8)      # saturated colours: clipping sweeps
+        q = float(rng.choice([30, 75, 95]))
+        m = int(rng.choice([0, 4]))
+        got = sj.SjpegEncode(img, q, m, sj.YUV_SHARP)
+        assert got == oracle.encode_method(img, q, 2, m), (w, h, q, m)
+
+
+def test_sharp_yuv_wide_and_1080p(oracle):
+    for (w, h) in ((1920, 1080), (4099, 37), (5, 700)):
+        img = synth.g_struct(w, h, 77)
+        assert sj.SjpegEncode(img, 80.0, 0, sj.YUV_SHARP) == oracle.encode_method(img, 80.0, 2, 0), (w, h)
