@@ -10,9 +10,11 @@
 // What this build runs on the GPU: YUV 4:2:0 / 4:4:4 / 4:0:0 from every input layout of the
 // API, compression methods 0..8 (standard or optimised Huffman tables, fixed or adaptive
 // quantization, trellis quantization), and the multi-pass size / PSNR search (every pass is a GPU
-// pass over the resident picture; not together with trellis).  SJPEG_YUV_AUTO / SJPEG_YUV_SHARP
-// are not available: such requests FAIL (0 / false), there is no CPU
-// fallback.
+// pass over the resident picture; not together with trellis), SJPEG_YUV_SHARP (the sharp
+// conversion runs on the device).  SJPEG_YUV_AUTO, SjpegCompress() and SjpegRiskiness() need the
+// reference's trained score table, which this library does not ship: install it with
+// sjpeg_hip_set_riskiness_table() or SJPEG_HIP_RISKINESS_TABLE (sjpeg_hip.h); without it those
+// requests FAIL (0 / false).  There is no CPU fallback for anything.
 // The reason of the last failure on the calling thread: SjpegHipLastError().
 #ifndef SJPEG_AMD_SJPEG_H_
 #define SJPEG_AMD_SJPEG_H_
@@ -62,6 +64,9 @@ bool SjpegDimensions(const uint8_t* data, size_t size,
 int SjpegFindQuantizer(const uint8_t* data, size_t size, uint8_t quant[2][64]);
 float SjpegEstimateQuality(const uint8_t matrix[64], bool for_chroma);
 void SjpegQuantMatrix(float quality, bool for_chroma, uint8_t matrix[64]);
+// reference: src/sjpeg.h:149.  Needs the riskiness score table (sjpeg_hip.h): without it the
+// result is SJPEG_YUV_AUTO ("undecided"), *risk = -1 and SjpegHipLastError() says why.
+SjpegYUVMode SjpegRiskiness(const uint8_t* rgb, int width, int height, int stride, float* risk);
 
 // Not part of the reference: text of the last failure on this thread ("" if none).
 const char* SjpegHipLastError();

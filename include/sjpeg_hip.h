@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SJPEG_HIP_ABI_VERSION 5
+#define SJPEG_HIP_ABI_VERSION 6
 
 enum {
   SJPEG_HIP_OK = 0,
@@ -205,6 +205,21 @@ int sjpeg_hip_sharp_yuv(const sjpeg_hip_source* src, int width, int height, int 
                         uint8_t* d_y, uint8_t* d_u, uint8_t* d_v, int64_t y_frame_stride,
                         int64_t uv_frame_stride, void* d_workspace, size_t workspace_size,
                         void* stream);
+
+/* ---- SJPEG_YUV_AUTO / SjpegRiskiness (src/jpeg_tools.cc:170-236) -------------------------------
+ * The decision between 4:2:0 / sharp / 4:4:4 / 4:0:0 is made of three sums of a stencil over the
+ * picture; the stencil looks pairs of 7x7x7 YUV cells up in a 343 x 343 byte table.  That table
+ * is trained data of the reference (src/score_7.cc, `sjpeg::kSharpnessScore`) and is NOT part of
+ * this library: install it once per process with sjpeg_hip_set_riskiness_table() (117649 bytes,
+ * host memory; copied), or point the environment variable SJPEG_HIP_RISKINESS_TABLE at a file
+ * holding those bytes.  Without it SJPEG_YUV_AUTO, SjpegCompress() and SjpegRiskiness() fail.
+ * sjpeg_hip_riskiness_sums: device part; d_sums[nframes][3] = sum of the scores above the noise
+ * level, their count, the count of neutral-chroma samples. */
+#define SJPEG_HIP_RISKINESS_TABLE_SIZE 117649
+int sjpeg_hip_set_riskiness_table(const uint8_t* table, size_t size);
+int sjpeg_hip_has_riskiness_table(void);
+int sjpeg_hip_riskiness_sums(const sjpeg_hip_source* src, int width, int height, int nframes,
+                             const uint8_t* d_table, uint64_t* d_sums, void* stream);
 
 /* ---- one frame over several GPUs ------------------------------------------
  * The reference codes a frame as ONE entropy segment (src/enc.cc:276-307; no restart markers,

@@ -177,6 +177,17 @@ class Oracle:
                                        target_value, passes, tolerance, qmin, qmax, C.byref(out))
         return self._take(n, out)
 
+    def riskiness(self, rgb, table: bytes, stride=None):
+        """(SjpegYUVMode, risk) of orc_riskiness; table = the reference's 117649-byte score table."""
+        rgb, w, h, stride = self._img(rgb, stride)
+        assert len(table) == 117649
+        tab = np.frombuffer(table, np.uint8)
+        risk = C.c_float(0)
+        self.lib.orc_riskiness.restype = C.c_int
+        mode = self.lib.orc_riskiness(C.c_void_p(rgb.ctypes.data), C.c_int(w), C.c_int(h), C.c_int(stride),
+                                      C.c_void_p(tab.ctypes.data), C.byref(risk))
+        return int(mode), float(risk.value)
+
     def quant_error(self, fmt, planes, w, h, quant, yuv_mode=YUV_420, q_bias=0x78):
         src, keep = make_source(fmt, planes)
         q = np.ascontiguousarray(quant, np.uint8).reshape(2, 64)

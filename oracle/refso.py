@@ -125,6 +125,19 @@ class Ref:
                                      C.byref(out))
         return self._take(n, out)
 
+    def sharpness_table(self) -> bytes:
+        """The reference's trained riskiness score table (sjpeg::kSharpnessScore, src/score_7.cc), read
+        out of the built reference.  Test data only: never written into the repository."""
+        arr = (C.c_uint8 * 117649).in_dll(self.lib, "_ZN5sjpeg15kSharpnessScoreE")
+        return bytes(arr)
+
+    def riskiness(self, rgb):
+        rgb, w, h, stride = self._img(rgb, None)
+        risk = C.c_float(0)
+        self.lib.ref_riskiness.restype = C.c_int
+        mode = self.lib.ref_riskiness(C.c_void_p(rgb.ctypes.data), C.c_int(w), C.c_int(h), C.c_int(stride), C.byref(risk))
+        return int(mode), float(risk.value)
+
     def compress(self, rgb, quality=75.0):
         rgb, w, h, _ = self._img(rgb, None)
         out = _u8p()

@@ -771,6 +771,46 @@ void orc_sharp_yuv(const uint8_t* rgb, int W, int H, int stride, uint8_t* yp, ui
   free(rows); free(best_y); free(target_y); free(cur_w); free(best_uv); free(target_uv); free(cur_uv);
 }
 
+/* ---------------------------------------------------------------- SjpegRiskiness / SJPEG_YUV_AUTO
+ * src/jpeg_tools.cc:170-236 with the pixel -> 7x7x7 cell index of src/colors_rgb.cc:1085-1122.
+ * `table` = the reference's trained 343 x 343 score table (src/score_7.cc), supplied by the caller
+ * (tests read it out of the built reference, oracle/_ref): it is not part of this repository. */
+static int risk_index(const uint8_t* p) {
+  const int r = p[0], g = p[1], b = p[2];
+  const uint32_t y = (uint32_t)((19595 * r + 38469 * g + 7471 * b + 32768) >> 16);
+  int u = 128 + ((-11059 * r - 21709 * g + 32768 * b + 32768) >> 16);
+  int v = 128 + ((32768 * r - 27439 * g - 5329 * b + 32768) >> 16);
+  u = u < 0 ? 0 : u > 255 ? 255 : u;
+  v = v < 0 ? 0 : v > 255 ? 255 : v;
+  const uint32_t k = 0x0101u * 6u;
+  return (int)(((y * k) >> 16) + 7 * (((uint32_t)u * k) >> 16) + 49 * (((uint32_t)v * k) >> 16));
+}
+
+int orc_riskiness(const uint8_t* rgb, int W, int H, int stride, const uint8_t* table, float* risk) {
+  int64_t score_sum = 0, score_num = 0, gray_num = 0;
+  const int gray = (7 / 2) * (1 + 7) * 7, gray_min = gray - gray % 7;
+  for (int j = 1; j < H; ++j) {
+    const uint8_t* r1 = rgb + (long)(j - 1) * stride;
+    const uint8_t* r2 = r1 + stride;
+    for (int i = 0; i < W - 1; ++i) {
+      const int idx0 = risk_index(r1 + 3 * i), idx1 = risk_index(r1 + 3 * i + 3), idx2 = risk_index(r2 + 3 * i);
+      const int score = table[idx0 + 343 * idx1] + table[idx0 + 343 * idx2] + table[idx1 + 343 * idx2];
+      if (score > 4) { score_sum += score; score_num += 1; }
+      gray_num += (idx0 >= gray_min && idx0 < gray_min + 7);
+    }
+  }
+  const double count = (double)score_num;
+  double gray_count = (double)gray_num;
+  double total = (count > 0) ? score_sum / count : 0.;
+  const double num_samples = (W - 1.) * (H - 1.);
+  if (num_samples > 0.) gray_count /= num_samples;
+  const double frac = 100. * count / ((double)W * H);
+  if (frac < 1.) total = 0.;
+  total = (total > 25.) ? 100. : total * 100. / 25.;
+  if (risk != NULL) *risk = (float)total;
+  return (gray_count > 0.995) ? ORC_YUV_400 : (total < 40.0) ? ORC_YUV_420 : (total < 70.0) ? ORC_YUV_SHARP : ORC_YUV_444;
+}
+
 /* ---------------------------------------------------------------- scan drivers */
 
 static orc_source rgb_source(const uint8_t* rgb, int stride) {

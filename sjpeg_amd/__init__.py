@@ -184,7 +184,7 @@ def lib() -> C.CDLL:
 EXPORTED_C_SYMBOLS = [
     # include/sjpeg.h (extern "C" part)
     "SjpegVersion", "SjpegCompress", "SjpegEncode", "SjpegFreeBuffer", "SjpegDimensions",
-    "SjpegFindQuantizer", "SjpegEstimateQuality", "SjpegQuantMatrix", "SjpegHipLastError",
+    "SjpegFindQuantizer", "SjpegEstimateQuality", "SjpegQuantMatrix", "SjpegRiskiness", "SjpegHipLastError",
     # include/sjpeg_hip.h
     "sjpeg_hip_abi_version", "sjpeg_hip_device_count", "sjpeg_hip_last_error",
     "sjpeg_hip_engine_create", "sjpeg_hip_engine_destroy", "sjpeg_hip_frame_bound",
@@ -195,6 +195,7 @@ EXPORTED_C_SYMBOLS = [
     "sjpeg_hip_scan_symbol_stats_src", "sjpeg_hip_scan_quant_error_src", "sjpeg_hip_engine_entropy_bits",
     "sjpeg_hip_optimize_huffman", "sjpeg_hip_make_header_ex", "sjpeg_hip_make_header_meta",
     "sjpeg_hip_sharp_workspace", "sjpeg_hip_sharp_yuv",
+    "sjpeg_hip_set_riskiness_table", "sjpeg_hip_has_riskiness_table", "sjpeg_hip_riskiness_sums",
     "sjpeg_hip_segment_count", "sjpeg_hip_band_bound", "sjpeg_hip_encode_band_src", "sjpeg_hip_stitch_bands",
     "sjpeg_hip_engine_set_timing", "sjpeg_hip_engine_last_scan_ms",
     "sjpeg_hip_engine_last_total_ms",
@@ -205,6 +206,30 @@ EXPORTED_C_SYMBOLS = [
 
 def last_error() -> str:
     return (lib().SjpegHipLastError() or b"").decode()
+
+
+def set_riskiness_table(table: bytes) -> None:
+    """Installs the reference's riskiness score table (117649 bytes) for SJPEG_YUV_AUTO."""
+    buf = (C.c_uint8 * len(table)).from_buffer_copy(table)
+    if lib().sjpeg_hip_set_riskiness_table(buf, len(table)) != 0:
+        raise SjpegError("sjpeg_hip_set_riskiness_table: wrong size")
+
+
+def SjpegRiskiness(rgb: np.ndarray):
+    """(SjpegYUVMode, risk) like the reference's SjpegRiskiness; (YUV_AUTO, -1.0) if the table is missing."""
+    rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+    h, w = rgb.shape[0], rgb.shape[1]
+    risk = C.c_float(0)
+    L = lib()
+    L.SjpegRiskiness.restype = C.c_int
+    L.SjpegRiskiness.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]
+    mode = L.SjpegRiskiness(rgb.ctypes.data, w, h, 3 * w, C.byref(risk))
+    return int(mode), float(risk.value)
+
+
+def SjpegCompress(rgb: np.ndarray, quality: float = 75.0):
+    """SjpegCompress() of include/sjpeg.h (method 4, SJPEG_YUV_AUTO).  Returns bytes or None."""
+    return SjpegEncode(rgb, quality, 4, YUV_AUTO)
 
 
 def SjpegEncode(rgb: np.ndarray, quality: float = 75.0, method: int = 0,

@@ -11,6 +11,8 @@
 
 #include <cmath>
 #include <math.h>
+#include <stdio.h>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -102,8 +104,47 @@ template <class T> class ContainerSink : public sjpeg::ByteSink {
 
 // ---- per-thread device context ------------------------------------------------------------
 
+// The riskiness score table (reference data, supplied by the caller: see sjpeg_hip.h)
+std::mutex g_risk_mutex;
+std::vector<uint8_t> g_risk_table;
+int g_risk_generation = 0;
+
+bool LoadRiskTableFromEnv() {                      // under g_risk_mutex
+  if (!g_risk_table.empty()) return true;
+  const char* path = getenv("SJPEG_HIP_RISKINESS_TABLE");
+  if (path == nullptr) return false;
+  FILE* f = fopen(path, "rb");
+  if (f == nullptr) return false;
+  std::vector<uint8_t> t(SJPEG_HIP_RISKINESS_TABLE_SIZE + 1);
+  const size_t n = fread(t.data(), 1, t.size(), f);
+  fclose(f);
+  if (n != SJPEG_HIP_RISKINESS_TABLE_SIZE) return false;
+  t.resize(SJPEG_HIP_RISKINESS_TABLE_SIZE);
+  g_risk_table.swap(t);
+  ++g_risk_generation;
+  return true;
+}
+
+// SjpegRiskiness' arithmetic on the three sums (src/jpeg_tools.cc:212-236)
+SjpegYUVMode RiskVerdict(uint64_t score_sum, uint64_t score_num, uint64_t gray_num, int width, int height,
+                         float* risk) {
+  const double count = static_cast<double>(score_num);
+  double gray_count = static_cast<double>(gray_num);
+  double total_score = (count > 0) ? score_sum / count : 0.;
+  const double num_samples = (width - 1.) * (height - 1.);
+  if (num_samples > 0.) gray_count /= num_samples;
+  const double frac = 100. * count / (static_cast<double>(width) * height);
+  if (frac < 1.) total_score = 0.;
+  total_score = (total_score > 25.) ? 100. : total_score * 100. / 25.;
+  if (risk != nullptr) *risk = static_cast<float>(total_score);
+  return (gray_count > 0.995) ? SJPEG_YUV_400 : (total_score < 40.0) ? SJPEG_YUV_420
+       : (total_score < 70.0) ? SJPEG_YUV_SHARP : SJPEG_YUV_444;
+}
+
 struct DeviceContext {
   sjpeg_hip_engine* engine = nullptr;
+  void* d_risk = nullptr; int risk_generation = -1;   // device copy of the riskiness table
+  uint64_t* d_sums = nullptr;
   int device = 0;
   void* d_in = nullptr;  size_t in_cap = 0;
   void* d_out = nullptr; size_t out_cap = 0;
@@ -117,6 +158,8 @@ struct DeviceContext {
     if (d_in) (void)hipFree(d_in);
     if (d_out) (void)hipFree(d_out);
     if (d_stats) (void)hipFree(d_stats);
+    if (d_risk) (void)hipFree(d_risk);
+    if (d_sums) (void)hipFree(d_sums);
     if (d_planes) (void)hipFree(d_planes);
     if (d_work) (void)hipFree(d_work);
     if (d_size) (void)hipFree(d_size);
@@ -130,6 +173,34 @@ struct DeviceContext {
     if (hipMalloc(reinterpret_cast<void**>(&d_size), sizeof(uint64_t)) != hipSuccess) {
       return Fail("hipMalloc(size word) failed");
     }
+    return true;
+  }
+  // the caller's riskiness table on this device; false (with the reason) if none was supplied
+  bool EnsureRiskTable() {
+    std::lock_guard<std::mutex> lock(g_risk_mutex);
+    if (!LoadRiskTableFromEnv()) {
+      return Fail("the riskiness score table is not installed: SJPEG_YUV_AUTO / SjpegCompress / "
+                  "SjpegRiskiness need the reference's trained table (sjpeg_hip_set_riskiness_table() "
+                  "or SJPEG_HIP_RISKINESS_TABLE), which this library does not ship");
+    }
+    if (risk_generation == g_risk_generation) return true;
+    if (d_risk == nullptr && hipMalloc(&d_risk, SJPEG_HIP_RISKINESS_TABLE_SIZE) != hipSuccess) return Fail("hipMalloc failed");
+    if (d_sums == nullptr && hipMalloc(reinterpret_cast<void**>(&d_sums), 3 * sizeof(uint64_t)) != hipSuccess) return Fail("hipMalloc failed");
+    if (hipMemcpy(d_risk, g_risk_table.data(), SJPEG_HIP_RISKINESS_TABLE_SIZE, hipMemcpyHostToDevice) != hipSuccess) {
+      return Fail("riskiness table upload failed");
+    }
+    risk_generation = g_risk_generation;
+    return true;
+  }
+  // riskiness of a device-resident RGB / BGRA / RGBA picture
+  bool Riskiness(const sjpeg_hip_source& dsrc, int W, int H, SjpegYUVMode* mode, float* risk) {
+    if (!EnsureRiskTable()) return false;
+    if (sjpeg_hip_riskiness_sums(&dsrc, W, H, 1, static_cast<const uint8_t*>(d_risk), d_sums, nullptr) != 0) {
+      return Fail("sjpeg_hip_riskiness_sums failed");
+    }
+    uint64_t sums[3];
+    if (hipMemcpy(sums, d_sums, sizeof(sums), hipMemcpyDeviceToHost) != hipSuccess) return Fail("riskiness read-back failed");
+    *mode = RiskVerdict(sums[0], sums[1], sums[2], W, H, risk);
     return true;
   }
   bool Ensure(void** p, size_t* cap, size_t need) {
@@ -226,19 +297,10 @@ bool Encoder::Run() {
   if (src_.format == SJPEG_HIP_SRC_GRAY) yuv_mode_ = SJPEG_YUV_400;                 // src/encoders.cc:256-276
   else if (src_.format == SJPEG_HIP_SRC_YUV444) yuv_mode_ = SJPEG_YUV_444;          // :384-419
   else if (src_.format >= SJPEG_HIP_SRC_YUV420) yuv_mode_ = SJPEG_YUV_420;          // :281-344, :442-490
-  int mode;
-  switch (yuv_mode_) {
-    case SJPEG_YUV_420: mode = SJPEG_HIP_YUV420; break;
-    case SJPEG_YUV_444: mode = SJPEG_HIP_YUV444; break;
-    case SJPEG_YUV_400: mode = SJPEG_HIP_YUV400; break;
-    case SJPEG_YUV_SHARP: mode = SJPEG_HIP_YUV420; break;            // planes from the sharp pre-pass
-    case SJPEG_YUV_AUTO:
-      return Fail("SJPEG_YUV_AUTO is not available in this build (the riskiness analysis needs the "
-                  "reference's trained score table, which this library does not ship); pick 420, "
-                  "sharp, 444 or 400");
-    default: return Fail("unknown yuv_mode");                        // src/encoders.cc:553-567
+  if (yuv_mode_ != SJPEG_YUV_AUTO && yuv_mode_ != SJPEG_YUV_420 && yuv_mode_ != SJPEG_YUV_SHARP &&
+      yuv_mode_ != SJPEG_YUV_444 && yuv_mode_ != SJPEG_YUV_400) {
+    return Fail("unknown yuv_mode");                                 // src/encoders.cc:553-567
   }
-  const bool sharp = (yuv_mode_ == SJPEG_YUV_SHARP);
   // method flags, reference: src/enc.cc:121-129
   const bool adaptive = method_ >= 3;
   const bool optimize = (method_ != 0) && (method_ != 3);
@@ -303,6 +365,13 @@ bool Encoder::Run() {
       dsrc.row_stride[i] = st < 0 ? -static_cast<long long>(pitch[i]) : static_cast<long long>(pitch[i]);
     }
   }
+  if (yuv_mode_ == SJPEG_YUV_AUTO) {
+    // EncoderFactory (src/encoders.cc:549-551): the picture decides
+    if (!ctx.Riskiness(dsrc, W_, H_, &yuv_mode_, nullptr)) return false;
+  }
+  const bool sharp = (yuv_mode_ == SJPEG_YUV_SHARP);
+  const int mode = (yuv_mode_ == SJPEG_YUV_444) ? SJPEG_HIP_YUV444
+                 : (yuv_mode_ == SJPEG_YUV_400) ? SJPEG_HIP_YUV400 : SJPEG_HIP_YUV420;
   if (sharp) {
     // EncoderSharp420 (src/encoders.cc:512-541): the sharp conversion turns the RGB picture into
     // Y / U / V planes on the device; from here on this is the planar 4:2:0 encoder.
@@ -853,6 +922,51 @@ size_t sjpeg_hip_make_header_ex(int width, int height, int yuv_mode, const uint8
   if (h.size() > cap) return 0;
   memcpy(buf, h.data(), h.size());
   return h.size();
+}
+
+int sjpeg_hip_set_riskiness_table(const uint8_t* table, size_t size) {
+  if (table == nullptr || size != SJPEG_HIP_RISKINESS_TABLE_SIZE) return SJPEG_HIP_EINVAL;
+  std::lock_guard<std::mutex> lock(g_risk_mutex);
+  g_risk_table.assign(table, table + size);
+  ++g_risk_generation;
+  return 0;
+}
+
+int sjpeg_hip_has_riskiness_table(void) {
+  std::lock_guard<std::mutex> lock(g_risk_mutex);
+  return LoadRiskTableFromEnv() ? 1 : 0;
+}
+
+// reference: src/jpeg_tools.cc:177-236
+SjpegYUVMode SjpegRiskiness(const uint8_t* rgb, int width, int height, int stride, float* risk) {
+  if (risk != nullptr) *risk = -1.f;
+  const int abs_stride = stride < 0 ? -stride : stride;
+  if (rgb == nullptr || width <= 0 || height <= 0 || abs_stride < 3 * width) {
+    Fail("SjpegRiskiness: bad arguments");
+    return SJPEG_YUV_AUTO;
+  }
+  DeviceContext& ctx = g_ctx;
+  if (!ctx.Init() || hipSetDevice(ctx.device) != hipSuccess) return SJPEG_YUV_AUTO;
+  const size_t pitch = (3 * static_cast<size_t>(width) + 15) & ~static_cast<size_t>(15);
+  if (!ctx.Ensure(&ctx.d_in, &ctx.in_cap, pitch * height + 64)) return SJPEG_YUV_AUTO;
+  const uint8_t* lowest = stride < 0 ? rgb + static_cast<long long>(height - 1) * stride : rgb;
+  if (hipMemcpy2D(ctx.d_in, pitch, lowest, abs_stride, 3 * static_cast<size_t>(width), height,
+                  hipMemcpyHostToDevice) != hipSuccess) {
+    Fail("hipMemcpy2D(host -> device) failed");
+    return SJPEG_YUV_AUTO;
+  }
+  sjpeg_hip_source dsrc;
+  memset(&dsrc, 0, sizeof(dsrc));
+  dsrc.format = SJPEG_HIP_SRC_RGB;
+  uint8_t* d = static_cast<uint8_t*>(ctx.d_in);
+  dsrc.plane[0] = stride < 0 ? d + pitch * (height - 1) : d;
+  dsrc.row_stride[0] = stride < 0 ? -static_cast<long long>(pitch) : static_cast<long long>(pitch);
+  SjpegYUVMode mode = SJPEG_YUV_AUTO;
+  if (!ctx.Riskiness(dsrc, width, height, &mode, risk)) {
+    if (risk != nullptr) *risk = -1.f;
+    return SJPEG_YUV_AUTO;
+  }
+  return mode;
 }
 
 size_t sjpeg_hip_make_header_meta(int width, int height, int yuv_mode, const uint8_t quant[2][64],

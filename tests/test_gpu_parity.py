@@ -166,7 +166,7 @@ def test_abi_argument_errors(engine):
 def test_unsupported_requests_fail_loudly():
     img = synth.g_struct(32, 32, 1)
     assert sj.SjpegEncode(img, 75.0, 0, sj.YUV_AUTO) is None        # needs the reference's score table
-    assert "not available" in sj.last_error()
+    assert "not installed" in sj.last_error()
     lib = sj.lib()
     out = C.POINTER(C.c_uint8)()
     assert lib.SjpegEncode(img.ctypes.data, 32, 32, 96, C.byref(out), 75.0, 0, 7) == 0   # bad mode
@@ -507,3 +507,55 @@ def test_sharp_yuv_wide_and_1080p(oracle):
     for (w, h) in ((1920, 1080), (4099, 37), (5, 700)):
         img = synth.g_struct(w, h, 77)
         assert sj.SjpegEncode(img, 80.0, 0, sj.YUV_SHARP) == oracle.encode_method(img, 80.0, 2, 0), (w, h)
+
+
+# ---- SJPEG_YUV_AUTO / SjpegRiskiness / SjpegCompress: need the reference's score table ---------------
+
+@pytest.fixture(scope="module")
+def risk_table():
+    """The trained table lives in the reference (src/score_7.cc); tests read it out of the built
+    reference (oracle/_ref travels to the GPU box) and hand it to the library at run time."""
+    from oracle import refso
+    if not refso.available():
+        pytest.skip("oracle/_ref/libsjpeg_ref.so not built: no riskiness table to install")
+    tab = refso.ref().sharpness_table()
+    sj.set_riskiness_table(tab)
+    return tab
+
+
+def test_riskiness_matches_oracle(oracle, risk_table):
+    rng = np.random.RandomState(61)
+    seen = set()
+    for _ in range(60):
+        w, h = int(rng.randint(1, 300)), int(rng.randint(1, 200))
+        k = rng.rand()
+        if k < 0.3:
+            img = synth.g_struct(w, h, int(rng.randint(1 << 30)))
+        elif k < 0.6:
+            img = rng.randint(0, 256, (h, w, 3)).astype(np.uint8)
+        elif k < 0.8:
+            img = np.repeat(rng.randint(0, 256, (h, w, 1)), 3, 2).astype(np.uint8)        # gray: 4:0:0
+        else:
+            img = (rng.randint(0, 2, (h, w, 3)) * 255).astype(np.uint8)
+        got = sj.SjpegRiskiness(img)
+        want = oracle.riskiness(img, risk_table)
+        assert got == want, (w, h, got, want)
+        seen.add(got[0])
+    assert len(seen) >= 3                                     # the pictures really exercise several verdicts
+
+
+def test_sjpeg_compress_c1_and_auto_modes(oracle, risk_table):
+    """BASELINE config #1: SjpegCompress(q75) of the 128x128 test picture = 2571 bytes, MD5 acc8ce81...
+    (AUTO resolves to SHARP, method 4).  Plus AUTO on pictures that resolve to the other modes."""
+    img = np.fromfile(os.path.join(ROOT, "tests", "golden", "test128.rgb"), np.uint8).reshape(128, 128, 3)
+    got = sj.SjpegCompress(img, 75.0)
+    assert got is not None, sj.last_error()
+    assert len(got) == 2571 and hashlib.md5(got).hexdigest() == "acc8ce8111f5ff4b32b3faa15ad5d994"
+    rng = np.random.RandomState(62)
+    pics = [synth.g_struct(211, 97, 5), rng.randint(0, 256, (64, 80, 3)).astype(np.uint8),
+            np.repeat(rng.randint(0, 256, (50, 70, 1)), 3, 2).astype(np.uint8),
+            (rng.randint(0, 2, (90, 60, 3)) * 255).astype(np.uint8)]
+    for img in pics:
+        mode, _ = oracle.riskiness(img, risk_table)
+        for q, m in ((75.0, 4), (40.0, 0)):
+            assert sj.SjpegEncode(img, q, m, sj.YUV_AUTO) == oracle.encode_method(img, q, mode, m), (img.shape, mode, q, m)
