@@ -10,7 +10,7 @@
 // What this build runs on the GPU: YUV 4:2:0 / 4:4:4 / 4:0:0 from every input layout of the
 // API, compression methods 0..8 (standard or optimised Huffman tables, fixed or adaptive
 // quantization, trellis quantization), and the multi-pass size / PSNR search (every pass is a GPU
-// pass over the resident picture; not together with trellis), SJPEG_YUV_SHARP (the sharp
+// pass over the resident picture), SJPEG_YUV_SHARP (the sharp
 // conversion runs on the device).  SJPEG_YUV_AUTO, SjpegCompress() and SjpegRiskiness() need the
 // reference's trained score table, which this library does not ship: install it with
 // sjpeg_hip_set_riskiness_table() or SJPEG_HIP_RISKINESS_TABLE (sjpeg_hip.h); without it those

@@ -83,7 +83,7 @@ class Oracle:
         lib.orc_encode_search.restype = C.c_size_t
         lib.orc_encode_search.argtypes = [C.POINTER(Source), C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                           C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
-                                          C.c_float, C.c_int, C.c_float, C.c_float, C.c_float,
+                                          C.c_float, C.c_int, C.c_float, C.c_float, C.c_float, C.c_int,
                                           C.POINTER(_u8p)]
         lib.orc_histogram_src.argtypes = [C.POINTER(Source), C.c_int, C.c_int, C.c_int, C.c_void_p]
         lib.orc_symbol_stats_src.argtypes = [C.POINTER(Source), C.c_int, C.c_int, C.c_int, C.c_void_p,
@@ -166,7 +166,7 @@ class Oracle:
 
     def encode_search(self, fmt, planes, w, h, quant, yuv_mode=YUV_420, huffman=True, adaptive=True,
                       target_mode=1, target_value=0.0, passes=10, tolerance=1.0, qmin=0.0, qmax=100.0,
-                      min_quant=None, q_bias=0x78, dmax_luma=12, dmax_chroma=1):
+                      min_quant=None, q_bias=0x78, dmax_luma=12, dmax_chroma=1, trellis=False):
         src, keep = make_source(fmt, planes)
         q = np.ascontiguousarray(quant, np.uint8).reshape(2, 64)
         mq = None if min_quant is None else np.ascontiguousarray(min_quant, np.uint8).reshape(2, 64)
@@ -174,7 +174,8 @@ class Oracle:
         n = self.lib.orc_encode_search(C.byref(src), w, h, q.ctypes.data,
                                        mq.ctypes.data if mq is not None else None, q_bias, dmax_luma,
                                        dmax_chroma, yuv_mode, int(huffman), int(adaptive), target_mode,
-                                       target_value, passes, tolerance, qmin, qmax, C.byref(out))
+                                       C.c_float(target_value), C.c_int(passes), C.c_float(tolerance), C.c_float(qmin), C.c_float(qmax),
+                                       C.c_int(int(trellis)), C.byref(out))
         return self._take(n, out)
 
     def riskiness(self, rgb, table: bytes, stride=None):

@@ -63,8 +63,9 @@ size_t ref_encode_meta(const uint8_t* rgb, int w, int h, int stride, float quali
 // target_mode: 1 = size (bytes), 2 = PSNR (dB).  q_out / value_out: what the default hook found.
 size_t ref_encode_search(const uint8_t* rgb, int w, int h, int stride, float quality, int yuv_mode,
                          int huffman, int adaptive, int target_mode, float target_value, int passes,
-                         float tolerance, float qmin, float qmax, uint8_t** out) {
+                         float tolerance, float qmin, float qmax, int trellis, uint8_t** out) {
   sjpeg::EncoderParam param(quality);
+  param.use_trellis = (trellis != 0);
   param.yuv_mode = static_cast<SjpegYUVMode>(yuv_mode);
   param.Huffman_compress = (huffman != 0);
   param.adaptive_quantization = (adaptive != 0);

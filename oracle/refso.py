@@ -36,7 +36,7 @@ class Ref:
         lib.ref_encode_search.restype = C.c_size_t
         lib.ref_encode_search.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int,
                                           C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_float,
-                                          C.c_float, C.c_float, C.POINTER(_u8p)]
+                                          C.c_float, C.c_float, C.c_int, C.POINTER(_u8p)]
         lib.ref_compress.restype = C.c_size_t
         lib.ref_compress.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.POINTER(_u8p)]
         lib.ref_free.argtypes = [_u8p]
@@ -103,12 +103,12 @@ class Ref:
 
     def encode_search(self, rgb, quality=75.0, yuv_mode=YUV_420, huffman=True, adaptive=True,
                       target_mode=1, target_value=0.0, passes=10, tolerance=1.0, qmin=0.0, qmax=100.0,
-                      stride=None):
+                      stride=None, trellis=False):
         rgb, w, h, stride = self._img(rgb, stride)
         out = _u8p()
         n = self.lib.ref_encode_search(rgb.ctypes.data, w, h, stride, quality, yuv_mode, int(huffman),
                                        int(adaptive), target_mode, target_value, passes, tolerance,
-                                       qmin, qmax, C.byref(out))
+                                       C.c_float(qmin), C.c_float(qmax), C.c_int(int(trellis)), C.byref(out))
         return self._take(n, out)
 
     def encode_meta(self, rgb, quality=75.0, yuv_mode=YUV_420, app_markers=b"", exif=b"", iccp=b"", xmp=b"",

@@ -1414,7 +1414,7 @@ size_t orc_encode_search(const orc_source* S, int W, int H, const uint8_t quant[
                          const uint8_t* min_quant, int q_bias, int qdelta_max_luma,
                          int qdelta_max_chroma, int yuv_mode, int huffman, int adaptive,
                          int target_mode, float target_value, int passes, float tolerance,
-                         float qmin_in, float qmax_in, uint8_t** out) {
+                         float qmin_in, float qmax_in, int trellis, uint8_t** out) {
   orc_scan s;
   *out = NULL;
   if (S->format == ORC_SRC_GRAY) yuv_mode = ORC_YUV_400;
@@ -1422,6 +1422,16 @@ size_t orc_encode_search(const orc_source* S, int W, int H, const uint8_t quant[
   else if (S->format >= ORC_SRC_YUV420) yuv_mode = ORC_YUV_420;
   if (!scan_init(&s, W, H, yuv_mode, quant, min_quant, q_bias)) return 0;
   passes = passes < 1 ? 1 : passes > 20 ? 20 : passes;            /* src/api.cc:169 */
+  /* use_trellis only takes effect with Huffman_compress + adaptive_quantization (method 4 -> 7,
+   * src/api.cc:153-157).  The trellis prices its rate with the AC tables that are CURRENT when a
+   * pass starts (InitCodes(true) in StoreRunLevels, src/dichotomy.cc:86): the standard ones at
+   * first, then whatever the previous size pass compiled. */
+  trellis = trellis && huffman && adaptive;
+  uint32_t rate_dc[2][12], rate_ac[2][256], pass_rate_ac[2][256];
+  orc_default_codes(rate_dc, rate_ac);
+  orc_huff pass_h[4];
+  default_huff(pass_h);
+  int last_is_best = 0;
   /* SearchHook::Setup, src/dichotomy.cc:41-52 */
   const int for_size = (target_mode == 1);
   const float target = target_value;
@@ -1449,6 +1459,10 @@ size_t orc_encode_search(const orc_source* S, int W, int H, const uint8_t quant[
       orc_huff h[4];
       default_huff(h);
       uint32_t freq[2][272];
+      if (trellis) {
+        memcpy(pass_rate_ac, rate_ac, sizeof(rate_ac));
+        s.trellis_ac = (const uint32_t (*)[256])pass_rate_ac;
+      }
       scan_stats(&s, S, yuv_mode, &freq[0][0]);
       if (huffman) {
         for (int t = 0; t < nt; ++t) {
@@ -1460,6 +1474,13 @@ size_t orc_encode_search(const orc_source* S, int W, int H, const uint8_t quant[
       uint32_t dc[2][12], ac[2][256];
       memset(dc, 0, sizeof(dc)); memset(ac, 0, sizeof(ac));
       for (int t = 0; t < 2; ++t) { orc_build_huffman(h[t].bits, h[t].syms, dc[t]); orc_build_huffman(h[2 + t].bits, h[2 + t].syms, ac[t]); }
+      if (trellis) {
+        /* the compiled tables are the current ones from here on.  InitCodes() writes the codes of the
+         * symbols a table HAS over the encoder's code arrays (src/entropy.cc:98-128) and leaves the
+         * rest as they were: the rate table accumulates, it is never cleared. */
+        for (int t = 0; t < nt; ++t) orc_build_huffman(h[2 + t].bits, h[2 + t].syms, rate_ac[t]);
+        memcpy(pass_h, h, sizeof(pass_h));
+      }
       /* HeaderSize(), src/dichotomy.cc:210-241 (no metadata here) */
       size_t size = 20 + (size_t)nt * 65 + 2 + 2 + 8 + 3 * s.L.nb_comps + 2 + 6 + 2 * s.L.nb_comps + 2 + 2;
       for (int t = 0; t < nt; ++t) size += (2 + 3 + 16 + h[t].nsyms) + (2 + 3 + 16 + h[2 + t].nsyms);
@@ -1476,7 +1497,7 @@ size_t orc_encode_search(const orc_source* S, int W, int H, const uint8_t quant[
     } else {
       result = psnr_of(S, &s, yuv_mode);
     }
-    const int last_is_best = (p == 0 || fabs(result - target) < best);
+    last_is_best = (p == 0 || fabs(result - target) < best);
     if (last_is_best) {
       memcpy(opt_quants[0], s.q[0].quant, 64);
       memcpy(opt_quants[1], s.q[1].quant, 64);
@@ -1492,9 +1513,44 @@ size_t orc_encode_search(const orc_source* S, int W, int H, const uint8_t quant[
     if (done) break;
   }
   free(hist);
-  /* final encode with the best matrices (no further adaptation) */
-  return orc_encode_src(S, W, H, opt_quants, min_quant, q_bias, qdelta_max_luma, qdelta_max_chroma,
-                        yuv_mode, huffman ? 1 : 0, out);
+  if (!trellis) {
+    /* final encode with the best matrices (no further adaptation) */
+    return orc_encode_src(S, W, H, opt_quants, min_quant, q_bias, qdelta_max_luma, qdelta_max_chroma,
+                          yuv_mode, huffman ? 1 : 0, out);
+  }
+  /* trellis (src/dichotomy.cc:176-204): the best matrices come back; if the last pass was a size
+   * pass and also the best one its stored run/levels ARE the stream (quantized with the rate
+   * table that pass started from, coded with the tables it compiled); otherwise the blocks are
+   * quantized once more with the tables current now, and the tables compiled from that. */
+  for (int c = 0; c < 2; ++c) {
+    orc_set_quant_matrix(opt_quants[c], 100.f, s.q[c].quant);
+    orc_finalize_quant(&s.q[c], q_bias);
+  }
+  orc_huff h[4];
+  if (for_size && last_is_best) {
+    s.trellis_ac = (const uint32_t (*)[256])pass_rate_ac;
+    memcpy(h, pass_h, sizeof(h));
+  } else {
+    s.trellis_ac = (const uint32_t (*)[256])rate_ac;
+    uint32_t freq[2][272];
+    scan_stats(&s, S, yuv_mode, &freq[0][0]);
+    default_huff(h);
+    for (int t = 0; t < nt; ++t) {
+      memset(&h[t], 0, sizeof(h[t])); memset(&h[2 + t], 0, sizeof(h[2 + t]));
+      h[t].nsyms = orc_build_optimal(freq[t] + 256, 12, h[t].bits, h[t].syms);
+      h[2 + t].nsyms = orc_build_optimal(freq[t], 256, h[2 + t].bits, h[2 + t].syms);
+    }
+  }
+  uint32_t dc[2][12], ac[2][256];
+  memset(dc, 0, sizeof(dc)); memset(ac, 0, sizeof(ac));
+  for (int t = 0; t < 2; ++t) { orc_build_huffman(h[t].bits, h[t].syms, dc[t]); orc_build_huffman(h[2 + t].bits, h[2 + t].syms, ac[t]); }
+  orc_bw w;
+  memset(&w, 0, sizeof(w));
+  write_headers_huff(&w, &s, yuv_mode, h);
+  scan_emit(&s, S, yuv_mode, &w, dc, ac);
+  put16(&w, 0xffd9);
+  *out = w.buf;
+  return w.size;
 }
 
 void orc_free(void* p) { free(p); }

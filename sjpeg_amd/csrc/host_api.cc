@@ -305,10 +305,6 @@ bool Encoder::Run() {
   const bool adaptive = method_ >= 3;
   const bool optimize = (method_ != 0) && (method_ != 3);
   const bool trellis = method_ >= 7;
-  if (trellis && passes_ > 1) {
-    return Fail("trellis quantization together with the multi-pass size/PSNR search is not available "
-                "in this build");
-  }
   if (qdelta_luma_ < 0 || qdelta_luma_ > 12 || qdelta_chroma_ < 0 || qdelta_chroma_ > 12) {
     return Fail("qdelta_max_luma / qdelta_max_chroma must be in [0, 12]");
   }
@@ -442,12 +438,20 @@ bool Encoder::Run() {
     return true;
   };
 
+  // Trellis + search: the rate table is the encoder's live AC code array (Quantizer::codes_,
+  // src/quantize.cc:151): InitCodes() writes the codes of the symbols a table HAS over it and leaves
+  // the rest as they were, so it accumulates over the passes (standard tables first, then whatever
+  // each size pass compiled).  tables.trellis_len plays that role here.
+  bool final_tables_known = false;               // the last pass' run/levels are the stream
+  HuffSpec pass_specs[4];
+  uint8_t pass_rate[2][256];
   if (passes_ > 1) {
     // Encoder::LoopScan (src/dichotomy.cc:113-205): the search is a host control loop; each pass
     // costs one statistics / error / size pass on the GPU over the resident picture.
     SearchHook* const hook = search_hook_;
     uint8_t opt_quants[2][64];
     float best = 0.f, best_q = 0.f, best_result = 0.f;
+    bool last_is_best = false;
     for (int p = 0; p < passes_; ++p) {
       hook->pass = p;
       for (int c = 0; c < 2; ++c) {
@@ -462,6 +466,7 @@ bool Encoder::Run() {
         HuffSpec popt[4];
         uint32_t freq[2][272];
         if (optimize) {
+          if (trellis) memcpy(pass_rate, tables.trellis_len, sizeof(pass_rate));   // what this pass is priced with
           if (!symbol_stats(freq)) return false;
           for (int t = 0; t < ntables; ++t) {
             sjpeg_host::BuildOptimalSpec(freq[t] + 256, 12, &popt[t]);
@@ -470,6 +475,15 @@ bool Encoder::Run() {
           }
         }
         sjpeg_host::InstallCodes(pdc, pac, ntables, &tables);
+        if (trellis) {                             // InitCodes(true) after CompileEntropyStats (src/dichotomy.cc:152)
+          for (int t = 0; t < ntables; ++t) {
+            for (int i = 0; i < popt[2 + t].nsyms; ++i) {
+              const int sym = popt[2 + t].syms[i];
+              tables.trellis_len[t][sym] = static_cast<uint8_t>(tables.ac_codes[t][sym] & 0xff);
+            }
+          }
+          memcpy(pass_specs, popt, sizeof(pass_specs));
+        }
         // HeaderSize() with the reference's own accounting (src/dichotomy.cc:210-241)
         size_t size = 20 + meta_.app_markers.size();
         if (!meta_.exif.empty()) size += 8 + meta_.exif.size();
@@ -532,7 +546,7 @@ bool Encoder::Run() {
         const uint64_t n = 64ull * nb_mbs * L.mcu_blocks;
         result = (err > 0 && n > 0) ? 4.3429448f * log(n / (err / 255. / 255.)) : 99.f;
       }
-      const bool last_is_best = (p == 0 || fabs(result - hook->target) < best);
+      last_is_best = (p == 0 || fabs(result - hook->target) < best);
       if (last_is_best) {
         memcpy(opt_quants, quant_, sizeof(opt_quants));
         best = fabs(result - hook->target);
@@ -547,6 +561,11 @@ bool Encoder::Run() {
     for (int c = 0; c < 2; ++c) sjpeg_host::FinalizeQuantizer(quant_[c], min_quant_[c], q_bias_, c, &tables);
     hook->q = best_q;
     hook->value = best_result;
+    if (trellis && hook->for_size && last_is_best) {
+      // src/dichotomy.cc:188: nothing is quantized again, the last pass' run/levels are written
+      memcpy(tables.trellis_len, pass_rate, sizeof(pass_rate));
+      final_tables_known = true;
+    }
   } else if (adaptive) {
     adapt();
   }
@@ -555,7 +574,9 @@ bool Encoder::Run() {
   const HuffSpec* dc[2] = {&sjpeg_host::DefaultHuff(0, 0), &sjpeg_host::DefaultHuff(0, 1)};
   const HuffSpec* ac[2] = {&sjpeg_host::DefaultHuff(1, 0), &sjpeg_host::DefaultHuff(1, 1)};
   HuffSpec opt[4];
-  if (optimize) {
+  if (final_tables_known) {
+    for (int t = 0; t < ntables; ++t) { dc[t] = &pass_specs[t]; ac[t] = &pass_specs[2 + t]; }
+  } else if (optimize) {
     // statistics half of SinglePassScanOptimized on the GPU (src/enc.cc:323-372),
     // CompileEntropyStats on the host (src/entropy.cc:432-444)
     uint32_t freq[2][272];

@@ -163,6 +163,21 @@ int main(int argc, char** argv) {
         snprintf(name, sizeof(name), "search_%03d", idx++);
         Save(dir, name, out);
       }
+    // the same search with trellis quantization (rate table accumulating over the passes)
+    for (int m = 0; m < 3; ++m) for (int tm = 1; tm <= 2; ++tm) for (int t = 0; t < 3; ++t) for (int passes = 2; passes <= 6; passes += 4) {
+      sjpeg::EncoderParam param(60.f);
+      param.yuv_mode = modes[m];
+      param.use_trellis = true;
+      param.target_mode = static_cast<sjpeg::EncoderParam::TargetMode>(tm);
+      param.target_value = (tm == 1) ? size_targets[t] : psnr_targets[t];
+      param.passes = passes;
+      param.tolerance = (tm == 1) ? 1.f : 0.1f;
+      std::string out;
+      CHECK(sjpeg::Encode(rgb.data(), W, H, 3 * W, param, &out));
+      char name[40];
+      snprintf(name, sizeof(name), "search_trellis_%03d", idx++);
+      Save(dir, name, out);
+    }
     // a 10-pass size search lands close to the request, and closer than a single pass at the seed
     sjpeg::EncoderParam param(60.f);
     param.yuv_mode = SJPEG_YUV_420;

@@ -95,5 +95,15 @@ def test_cxx_api_behaviour_and_parity(tmp_path, oracle):
                                                         tolerance=1.0 if tm == 1 else 0.1)
                             assert read("search_%03d" % idx) == want, (idx, name, huff, adapt, tm, target, passes)
                             idx += 1
+    for name, mode in modes.items():
+        for tm in (1, 2):
+            for t in range(3):
+                for passes in (2, 6):
+                    target = (1500.0, 4000.0, 9000.0)[t] if tm == 1 else (30.0, 38.0, 45.0)[t]
+                    want = oracle.encode_search(orc.SRC_RGB, [img], 141, 99, q60, yuv_mode=mode, target_mode=tm,
+                                                target_value=target, passes=passes,
+                                                tolerance=1.0 if tm == 1 else 0.1, trellis=True)
+                    assert read("search_trellis_%03d" % idx) == want, (idx, name, tm, target, passes)
+                    idx += 1
     assert read("search_hooked") == oracle.encode_search(orc.SRC_RGB, [img], 141, 99, q60, yuv_mode=1,
                                                          target_mode=1, target_value=5000.0, passes=4)
