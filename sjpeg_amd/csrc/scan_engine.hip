@@ -103,6 +103,7 @@ constexpr int kOffWin = kSamplesBytes;
 constexpr int kOffQ = kOffWin;                                  // uint4[64]
 constexpr int kOffDc = kOffWin + 1024;                          // uint32[24]
 constexpr int kOffTlen = kOffWin + 1152;                        // uint8[2][256], trellis kinds only
+constexpr int kSortHist = 1100;                                 // window word of the sort's bins: beyond everything P2 reads
 constexpr int kOffAc = kOffWin + kWinWords * 4 + 16;            // +1 spare word (16 B keeps alignment)
 constexpr int kOffMisc = kOffAc + 2 * 256 * 4;                  // scan scratch
 constexpr int kLdsBytes = kOffMisc + 64;                        // 47184: three workgroups per CU
@@ -997,6 +998,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
         dst[i] = static_cast<int16_t>((e & 0x8000) ? -mag : mag);
       }
     }
+    return;                                        // the tap ends here: no entropy coding
   }
 
   if (a.ablate == 2) { if (nz_lo + nz_hi + dc_val == 0x7fffffff) a.seg_nbits[0] = 1; return; }
@@ -1006,6 +1008,11 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
   // DC prediction (src/entropy.cc:133-150) through the 16 spare bytes of each slot.
   uint32_t* const tail = reinterpret_cast<uint32_t*>(slot + 128);
   tail[3] = static_cast<uint32_t>(dc_val);
+  // (sort bookkeeping that aliases nothing still in use is cleared under the same barrier)
+  if (KIND == kKindEncode) {
+    if (tid < 32) win[kSortHist + tid] = 0;
+    *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(win + 64 + 512) + 4 * tid) = make_uint2(0u, 0u);
+  }
   __syncthreads();
   int pred = 0;
   {
@@ -1026,8 +1033,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
     const uint32_t code = ldc[tbl * 12 + n];
     dc_word = (((code & 0xffu) + n) << 24) | ((code >> 16) << n) | suffix;
   }
-  __syncthreads();                                 // every pred has been read: tails are free again
-  tail[0] = nz_lo; tail[1] = nz_hi; tail[2] = dc_word;
+  tail[0] = nz_lo; tail[1] = nz_hi; tail[2] = dc_word;   // (the predictors live in tail[3])
 
   if (KIND == kKindStats) {
     // Symbol statistics for optimised Huffman tables (reference AddEntropyStats,
@@ -1073,16 +1079,13 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
   // themselves.  Parts are handed to threads sorted by their number of non-zeros (counting sort,
   // descending), 256 per round: walks of at most 16 symbols with similar trip counts per wave.
   // The unit list and the part lengths live in the bit window, idle until the stitch.
-  uint32_t* const hist = win;                      // [32], bins 0..16
-  uint32_t* const bin_start = win + 32;            // [32]
+  uint32_t* const hist = win + kSortHist;          // [32], bins 0..16 (cleared before the DC barrier)
+  uint32_t* const bin_start = win + kSortHist + 32;   // [32]
   uint16_t* const ulist = reinterpret_cast<uint16_t*>(win + 64);          // [1024] block | quarter << 8
   uint16_t* const ulen = reinterpret_cast<uint16_t*>(win + 64 + 512);     // [256][4] bits per part
   {
     uint32_t c[4] = {static_cast<uint32_t>(__popc(nzq[0])), static_cast<uint32_t>(__popc(nzq[1])),
                      static_cast<uint32_t>(__popc(nzq[2])), static_cast<uint32_t>(__popc(nzq[3]))};
-    if (tid < 32) hist[tid] = 0;
-    *reinterpret_cast<uint2*>(ulen + 4 * tid) = make_uint2(0u, 0u);
-    __syncthreads();
     uint32_t rank[4] = {0, 0, 0, 0};
     if (emits) {
       rank[0] = atomicAdd(&hist[c[0]], 1u);        // quarter 0 always makes a part (DC, EOB)
