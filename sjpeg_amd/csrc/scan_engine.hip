@@ -566,14 +566,14 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
   const int halo = m_first > 0 ? 1 : 0;                        // previous MCU: DC predictors only
   const uint8_t* const frame_px = a.plane[0] + frame * a.frame_stride[0];
 
-  // tables -> LDS
-  {
+  // tables -> LDS; issued once the first pixel loads are in flight (see P1)
+  auto stage_tables = [&]() {
     const DevTables* t = a.tables;
     if (tid < 64) lq[tid] = (&t->q[0][0])[tid];
     for (int i = tid; i < 512; i += kScanThreads) lac[i] = (&t->ac[0][0])[i];
     if (tid < 24) ldc[tid] = (&t->dc[0][0])[tid];
     if (TRELLIS && tid < 128) reinterpret_cast<uint32_t*>(smem + kOffTlen)[tid] = reinterpret_cast<const uint32_t*>(&t->tlen[0][0])[tid];
-  }
+  };
 
   // ---- P1: colour conversion, strips of 8 pixels (x2 rows for 4:2:0) --------------------
   // local MCU index ml: 0 = halo, 1..n_coded = coded MCUs; block slot = ml*BPM + k
@@ -599,6 +599,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
     const uint32_t k7471 = 7471u, k32768 = 32768u;             // multiplier operands (low halves)
     constexpr int kNW = (SRC == kSrcRgb24) ? 6 : 8;             // dwords per 8 pixels
     constexpr int kBatch = 3;                                   // row pairs in flight per thread
+    bool tables_staged = false;
     for (int ypb = yp0; ypb < 8 && yp0 < ngroups; ypb += kBatch * ngroups) {
     // all global loads of the batch are issued before the first one is consumed
     uint32_t raw[kBatch][kRowsPerStrip][kNW];
@@ -614,6 +615,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
         }
       }
     }
+    if (!tables_staged) { stage_tables(); tables_staged = true; }
 #pragma unroll
     for (int it = 0; it < kBatch; ++it) {
       const int yp = ypb + it * ngroups;
@@ -708,6 +710,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
       }
     }
     }
+    if (!tables_staged) stage_tables();
   }
   __syncthreads();
   stamp(1);
