@@ -165,6 +165,29 @@ def main():
     except Exception:
         traffic = None
 
+    # ---- what a read-only stream kernel reaches on this device (context for `peak`) ----------
+    stream_gbps = None
+    if rank == 0:
+        try:
+            import ctypes as C
+            L = sj.lib()
+            L.sjpeg_hip_debug_stream_read.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+            probe = frames.reshape(-1)
+            sink = torch.zeros(4, dtype=torch.int32, device="cuda")
+            nbytes = (probe.numel() // 16) * 16
+            s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            st = torch.cuda.current_stream().cuda_stream
+            for _ in range(2):
+                L.sjpeg_hip_debug_stream_read(probe.data_ptr(), nbytes, sink.data_ptr(), st)
+            s0.record()
+            for _ in range(10):
+                L.sjpeg_hip_debug_stream_read(probe.data_ptr(), nbytes, sink.data_ptr(), st)
+            s1.record()
+            torch.cuda.synchronize()
+            stream_gbps = nbytes * 10 / (s0.elapsed_time(s1) * 1e-3) / 1e9
+        except Exception:
+            stream_gbps = None
+
     # ---- parity: every coded frame must equal the reference bit for bit -------------------
     torch.cuda.synchronize()
     sz = sizes.cpu().numpy()
@@ -211,7 +234,9 @@ def main():
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK, 4), "traffic": traffic,
                          "kernel": "scan_segments<420>", "kernel_ms": round(scan_avg * 1e3, 4),
                          "all_kernels_ms": round(float(np.mean(total_ms)), 4),
-                         "algorithmic_bytes_per_launch": int(algo_bytes)},
+                         "algorithmic_bytes_per_launch": int(algo_bytes),
+                         "stream_read_GBps": None if stream_gbps is None else round(stream_gbps, 1),
+                         "frac_of_stream_read": None if not stream_gbps else round(achieved / 1e9 / stream_gbps, 4)},
         }
         if gather_ms is not None:
             res["gather_ms"] = round(gather_ms, 2)

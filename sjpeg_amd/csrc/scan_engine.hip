@@ -2234,4 +2234,24 @@ int sjpeg_hip_stitch_bands(sjpeg_hip_engine* e, int nbands, const uint32_t* d_wo
   return 0;
 }
 
+// ---- measurement aid: what a read-only streaming kernel reaches on this device ------------------
+// (SURVEY section 8d asks for the achieved read bandwidth beside the 8 TB/s spec figure)
+
+__global__ __launch_bounds__(256) void stream_read_kernel(const uint4* p, size_t n, uint32_t* sink) {
+  uint4 acc = make_uint4(0, 0, 0, 0);
+  for (size_t i = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x; i < n; i += static_cast<size_t>(gridDim.x) * 256) {
+    const uint4 v = p[i];
+    acc.x ^= v.x; acc.y ^= v.y; acc.z ^= v.z; acc.w ^= v.w;
+  }
+  const uint32_t r = acc.x ^ acc.y ^ acc.z ^ acc.w;
+  if (r == 0x9e3779b9u) sink[0] = r;               // keeps the loads alive, practically never taken
+}
+
+int sjpeg_hip_debug_stream_read(const void* d_buf, size_t bytes, uint32_t* d_sink, void* stream) {
+  if (d_buf == nullptr || d_sink == nullptr || bytes < 16) return SJPEG_HIP_EINVAL;
+  hipLaunchKernelGGL(stream_read_kernel, dim3(256 * 16), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     static_cast<const uint4*>(d_buf), bytes / 16, d_sink);
+  return hipGetLastError() == hipSuccess ? 0 : SJPEG_HIP_ERUNTIME;
+}
+
 }  // extern "C"
