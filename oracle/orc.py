@@ -178,6 +178,16 @@ class Oracle:
                                        C.c_int(int(trellis)), C.byref(out))
         return self._take(n, out)
 
+    def sharp_yuv(self, rgb):
+        """(y, u, v) planes of orc_sharp_yuv (SJPEG_YUV_SHARP conversion)."""
+        rgb, w, h, stride = self._img(rgb, None)
+        cw, ch = (w + 1) // 2, (h + 1) // 2
+        y = np.zeros((h, w), np.uint8); u = np.zeros((ch, cw), np.uint8); v = np.zeros((ch, cw), np.uint8)
+        self.lib.orc_sharp_yuv.restype = None
+        self.lib.orc_sharp_yuv(C.c_void_p(rgb.ctypes.data), C.c_int(w), C.c_int(h), C.c_int(stride),
+                               C.c_void_p(y.ctypes.data), C.c_void_p(u.ctypes.data), C.c_void_p(v.ctypes.data))
+        return y, u, v
+
     def riskiness(self, rgb, table: bytes, stride=None):
         """(SjpegYUVMode, risk) of orc_riskiness; table = the reference's 117649-byte score table."""
         rgb, w, h, stride = self._img(rgb, stride)

@@ -47,6 +47,33 @@ class Source(C.Structure):
                 ("row_stride", C.c_int64 * 3), ("frame_stride", C.c_int64 * 3)]
 
 
+def sharp_yuv(fmt, frames):
+    """SJPEG_YUV_SHARP conversion of device-resident packed frames [F, H, row_bytes] (fmt = SRC_RGB /
+    SRC_BGRA / SRC_RGBA) -> (y [F, H, W], u [F, ch, cw], v [F, ch, cw]) uint8 CUDA tensors."""
+    import torch
+    assert frames.is_cuda and frames.dim() == 3
+    f, h, row_bytes = frames.shape
+    bpp = 3 if fmt == SRC_RGB else 4
+    w = row_bytes // bpp
+    cw, ch = (w + 1) // 2, (h + 1) // 2
+    src, _ = make_source(fmt, [frames])
+    y = torch.empty((f, h, w), dtype=torch.uint8, device=frames.device)
+    u = torch.empty((f, ch, cw), dtype=torch.uint8, device=frames.device)
+    v = torch.empty((f, ch, cw), dtype=torch.uint8, device=frames.device)
+    L = lib()
+    L.sjpeg_hip_sharp_workspace.restype = C.c_size_t
+    L.sjpeg_hip_sharp_workspace.argtypes = [C.c_int, C.c_int, C.c_int]
+    L.sjpeg_hip_sharp_yuv.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_int64, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p]
+    wsz = L.sjpeg_hip_sharp_workspace(w, h, f)
+    work = torch.empty(max(wsz, 16), dtype=torch.uint8, device=frames.device)
+    rc = L.sjpeg_hip_sharp_yuv(C.byref(src), w, h, f, y.data_ptr(), u.data_ptr(), v.data_ptr(), h * w, ch * cw,
+                               work.data_ptr(), wsz, torch.cuda.current_stream().cuda_stream)
+    if rc != 0:
+        raise SjpegError("sjpeg_hip_sharp_yuv failed (%d)" % rc)
+    return y, u, v
+
+
 def segment_count(w, h, yuv_mode):
     n = lib().sjpeg_hip_segment_count(w, h, yuv_mode)
     if n <= 0:

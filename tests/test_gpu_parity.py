@@ -559,3 +559,21 @@ def test_sjpeg_compress_c1_and_auto_modes(oracle, risk_table):
         mode, _ = oracle.riskiness(img, risk_table)
         for q, m in ((75.0, 4), (40.0, 0)):
             assert sj.SjpegEncode(img, q, m, sj.YUV_AUTO) == oracle.encode_method(img, q, mode, m), (img.shape, mode, q, m)
+
+
+def test_sharp_yuv_batch_and_bgra_planes(oracle):
+    """The conversion itself through the C-ABI: a batch of pictures in one call (one workgroup per
+    picture), and 4-byte pixels; planes compared with the oracle's."""
+    rng = np.random.RandomState(43)
+    for (w, h) in ((64, 48), (101, 37), (3, 9), (640, 360)):
+        imgs = [rng.randint(0, 256, (h, w, 3)).astype(np.uint8) if k % 2 else synth.g_struct(w, h, 50 + k) for k in range(5)]
+        batch = torch.from_numpy(np.stack(imgs).reshape(5, h, 3 * w)).cuda()
+        y, u, v = sj.sharp_yuv(sj.SRC_RGB, batch)
+        bgra = np.stack([np.concatenate([im[:, :, ::-1], np.full((h, w, 1), 7, np.uint8)], 2) for im in imgs])
+        y4, u4, v4 = sj.sharp_yuv(sj.SRC_BGRA, torch.from_numpy(bgra.reshape(5, h, 4 * w)).cuda())
+        for k, im in enumerate(imgs):
+            wy, wu, wv = oracle.sharp_yuv(im)
+            assert np.array_equal(y[k].cpu().numpy(), wy) and np.array_equal(u[k].cpu().numpy(), wu) and \
+                np.array_equal(v[k].cpu().numpy(), wv), (w, h, k)
+            assert np.array_equal(y4[k].cpu().numpy(), wy) and np.array_equal(u4[k].cpu().numpy(), wu) and \
+                np.array_equal(v4[k].cpu().numpy(), wv), (w, h, k, "bgra")
