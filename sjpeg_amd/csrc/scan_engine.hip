@@ -1303,7 +1303,8 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
 #pragma unroll
   for (int r = 0; r < 4; ++r) if (ur_get(r) != 0xffffffffu) pending |= 1u << r;
   for (;;) {
-    for (int i = tid; i < kWinWords + 1; i += kScanThreads) win[i] = 0;
+    for (int i = tid; i < kWinWords / 4; i += kScanThreads) reinterpret_cast<uint4*>(win)[i] = make_uint4(0, 0, 0, 0);
+    if (tid == 0) win[kWinWords] = 0;
     if (tid == 0) misc[8] = total;
     __syncthreads();
     if (tid == 0 && carry != 0) atomicOr(&win[0], carry);
