@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SJPEG_HIP_ABI_VERSION 6
+#define SJPEG_HIP_ABI_VERSION 7
 
 enum {
   SJPEG_HIP_OK = 0,
@@ -295,6 +295,22 @@ void sjpeg_hip_adapt_quant(const uint32_t* hist, int yuv_mode, uint8_t quant[2][
                            const uint8_t* min_quant /*[2][64]*/, int q_bias,
                            int qdelta_max_luma, int qdelta_max_chroma,
                            sjpeg_hip_scan_tables* tables);
+
+/* The same analysis with its bin loops on the device (src/histogram.cc:150-205): for every table,
+ * position and candidate step (-12 .. +12 around quant) the rate and distortion sums over the
+ * histogram, d_sums[nframes][2][64][25][2] (int64: bits, distortion; distortion == INT64_MIN marks a
+ * step outside [min_quant, 255]), and d_totlast[nframes][2][64][2] (population, highest occupied
+ * bin + 1).  Integer sums: exactly what the reference's double accumulators hold.  quant / min_quant
+ * are host arrays (min_quant NULL = ones).  sjpeg_hip_adapt_quant_sums() is the float half on the
+ * host (regression, lambda, choice of the step) for ONE frame's sums; it updates quant and tables
+ * like sjpeg_hip_adapt_quant(). */
+int sjpeg_hip_adapt_sums(const uint32_t* d_hist, int nframes, const uint8_t quant[2][64],
+                         const uint8_t* min_quant /*[2][64]*/, int64_t* d_sums, int32_t* d_totlast,
+                         void* stream);
+void sjpeg_hip_adapt_quant_sums(const int64_t* sums, const int32_t* totlast, int yuv_mode,
+                                uint8_t quant[2][64], const uint8_t* min_quant /*[2][64]*/, int q_bias,
+                                int qdelta_max_luma, int qdelta_max_chroma,
+                                sjpeg_hip_scan_tables* tables);
 
 /* CompileEntropyStats / BuildOptimalTable (src/entropy.cc:254-444) on ONE frame's symbol
  * statistics (host memory, uint32 [2][272]): fills specs[4] = {DC luma, DC chroma, AC luma,

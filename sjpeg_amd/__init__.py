@@ -218,6 +218,7 @@ EXPORTED_C_SYMBOLS = [
     "sjpeg_hip_encode_scan", "sjpeg_hip_scan_coeffs", "sjpeg_hip_quality_matrices",
     "sjpeg_hip_finalize_quant", "sjpeg_hip_default_huffman", "sjpeg_hip_make_header",
     "sjpeg_hip_scan_histogram", "sjpeg_hip_scan_symbol_stats", "sjpeg_hip_adapt_quant",
+    "sjpeg_hip_adapt_sums", "sjpeg_hip_adapt_quant_sums",
     "sjpeg_hip_encode_scan_src", "sjpeg_hip_scan_coeffs_src", "sjpeg_hip_scan_histogram_src",
     "sjpeg_hip_scan_symbol_stats_src", "sjpeg_hip_scan_quant_error_src", "sjpeg_hip_engine_entropy_bits",
     "sjpeg_hip_optimize_huffman", "sjpeg_hip_make_header_ex", "sjpeg_hip_make_header_meta",
@@ -324,6 +325,34 @@ def adapt_quant(hist: np.ndarray, yuv_mode, quant, min_quant=None, q_bias=0x78, 
                                 mq.ctypes.data if mq is not None else None, q_bias, dmax_luma,
                                 dmax_chroma, C.byref(t))
     lib().sjpeg_hip_default_huffman(C.byref(t))
+    return t, q
+
+
+def adapt_quant_device(hist_dev, yuv_mode, quant, min_quant=None, q_bias=0x78, dmax_luma=12, dmax_chroma=1):
+    """The same with the bin loops on the GPU: hist_dev = CUDA int32 tensor [2, 64, 128] of ONE frame
+    (Engine.scan_histogram()[f]); sums come back (52 KB), the float half runs on the host."""
+    import torch
+    q = np.ascontiguousarray(quant, np.uint8).reshape(2, 64).copy()
+    mq = None if min_quant is None else np.ascontiguousarray(min_quant, np.uint8).reshape(2, 64)
+    sums = torch.zeros((2, 64, 25, 2), dtype=torch.int64, device=hist_dev.device)
+    totlast = torch.zeros((2, 64, 2), dtype=torch.int32, device=hist_dev.device)
+    L = lib()
+    L.sjpeg_hip_adapt_sums.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    rc = L.sjpeg_hip_adapt_sums(hist_dev.contiguous().data_ptr(), 1, q.ctypes.data,
+                                mq.ctypes.data if mq is not None else None, sums.data_ptr(), totlast.data_ptr(),
+                                torch.cuda.current_stream().cuda_stream)
+    if rc != 0:
+        raise SjpegError("sjpeg_hip_adapt_sums: " + L.sjpeg_hip_last_error().decode())
+    s_host = np.ascontiguousarray(sums.cpu().numpy())
+    t_host = np.ascontiguousarray(totlast.cpu().numpy())
+    t = ScanTables()
+    L.sjpeg_hip_finalize_quant(q.ctypes.data, mq.ctypes.data if mq is not None else None, q_bias, C.byref(t))
+    L.sjpeg_hip_adapt_quant_sums.restype = None
+    L.sjpeg_hip_adapt_quant_sums.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                             C.c_int, C.c_void_p]
+    L.sjpeg_hip_adapt_quant_sums(s_host.ctypes.data, t_host.ctypes.data, yuv_mode, q.ctypes.data,
+                                 mq.ctypes.data if mq is not None else None, q_bias, dmax_luma, dmax_chroma, C.byref(t))
+    L.sjpeg_hip_default_huffman(C.byref(t))
     return t, q
 
 

@@ -149,6 +149,7 @@ struct DeviceContext {
   void* d_in = nullptr;  size_t in_cap = 0;
   void* d_out = nullptr; size_t out_cap = 0;
   void* d_stats = nullptr; size_t stats_cap = 0;
+  void* d_hist = nullptr; size_t hist_cap = 0;       // adaptive quantization: histogram + its sums
   void* d_planes = nullptr; size_t planes_cap = 0;   // SJPEG_YUV_SHARP: converted planes
   void* d_work = nullptr; size_t work_cap = 0;       //                  and the conversion's workspace
   uint64_t* d_size = nullptr;
@@ -160,6 +161,7 @@ struct DeviceContext {
     if (d_stats) (void)hipFree(d_stats);
     if (d_risk) (void)hipFree(d_risk);
     if (d_sums) (void)hipFree(d_sums);
+    if (d_hist) (void)hipFree(d_hist);
     if (d_planes) (void)hipFree(d_planes);
     if (d_work) (void)hipFree(d_work);
     if (d_size) (void)hipFree(d_size);
@@ -408,21 +410,33 @@ bool Encoder::Run() {
 
   if (passes_ > 1 && !search_ok_) return Fail("SearchHook::Setup() failed");
   const int ntables = (nb_comps == 1) ? 1 : 2;
-  std::vector<uint32_t> hist;
+  constexpr size_t kHistBytes = 2 * 64 * 128 * sizeof(uint32_t);
+  constexpr size_t kSumsBytes = 2 * 64 * sjpeg_host::kAdaptDeltas * 2 * sizeof(int64_t);
+  constexpr size_t kTotLastBytes = 2 * 64 * 2 * sizeof(int32_t);
   if (adaptive) {
-    // CollectHistograms on the GPU (src/enc.cc:425-429, src/dichotomy.cc:117-121)
+    // CollectHistograms on the GPU (src/enc.cc:425-429, src/dichotomy.cc:117-121); the histogram
+    // stays on the device, only the sums AnalyseHisto makes of it come back
+    if (!ctx.Ensure(&ctx.d_hist, &ctx.hist_cap, kHistBytes + kSumsBytes + kTotLastBytes)) return false;
     if (sjpeg_hip_scan_histogram_src(ctx.engine, &dsrc, W_, H_, mode, 1,
-                                 static_cast<uint32_t*>(ctx.d_stats), nullptr) != 0) {
+                                 static_cast<uint32_t*>(ctx.d_hist), nullptr) != 0) {
       return FailHip("sjpeg_hip_scan_histogram");
     }
-    hist.resize(2 * 64 * 128);
-    if (hipMemcpy(hist.data(), ctx.d_stats, hist.size() * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess) {
-      return Fail(std::string("histogram pass failed: ") + hipGetErrorString(hipGetLastError()));
-    }
   }
-  auto adapt = [&]() {                              // AnalyseHisto on the host
-    sjpeg_host::AdaptQuantMatrices(reinterpret_cast<const uint32_t(*)[64][128]>(hist.data()), nb_comps,
-                                   quant_, min_quant_, qdelta_luma_, qdelta_chroma_);
+  bool adapt_ok = true;
+  auto adapt = [&]() {                              // AnalyseHisto: bin loops on the GPU, the rest here
+    uint8_t* const base = static_cast<uint8_t*>(ctx.d_hist);
+    int64_t* const d_sums = reinterpret_cast<int64_t*>(base + kHistBytes);
+    int32_t* const d_totlast = reinterpret_cast<int32_t*>(base + kHistBytes + kSumsBytes);
+    static thread_local int64_t sums[2][64][sjpeg_host::kAdaptDeltas][2];
+    static thread_local int32_t totlast[2][64][2];
+    if (sjpeg_hip_adapt_sums(static_cast<const uint32_t*>(ctx.d_hist), 1, quant_, &min_quant_[0][0], d_sums,
+                             d_totlast, nullptr) != 0 ||
+        hipMemcpy(sums, d_sums, kSumsBytes, hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(totlast, d_totlast, kTotLastBytes, hipMemcpyDeviceToHost) != hipSuccess) {
+      adapt_ok = false;
+      return;
+    }
+    sjpeg_host::AdaptDecide(sums, totlast, nb_comps, quant_, qdelta_luma_, qdelta_chroma_);
     for (int idx = (nb_comps > 1 ? 1 : 0); idx >= 0; --idx) {
       sjpeg_host::FinalizeQuantizer(quant_[idx], min_quant_[idx], q_bias_, idx, &tables);
     }
@@ -458,7 +472,7 @@ bool Encoder::Run() {
         hook->NextMatrix(c, quant_[c]);
         sjpeg_host::FinalizeQuantizer(quant_[c], min_quant_[c], q_bias_, c, &tables);
       }
-      if (adaptive) adapt();
+      if (adaptive) { adapt(); if (!adapt_ok) return Fail("adaptive-quantization analysis failed on the device"); }
       float result;
       if (hook->for_size) {
         const HuffSpec* pdc[2] = {&sjpeg_host::DefaultHuff(0, 0), &sjpeg_host::DefaultHuff(0, 1)};
@@ -568,6 +582,7 @@ bool Encoder::Run() {
     }
   } else if (adaptive) {
     adapt();
+    if (!adapt_ok) return Fail("adaptive-quantization analysis failed on the device");
   }
 
   // Huffman tables: Annex K defaults (src/enc.cc:399) or optimised for this picture
@@ -910,6 +925,20 @@ void sjpeg_hip_adapt_quant(const uint32_t* hist, int yuv_mode, uint8_t quant[2][
   const int nb_comps = (yuv_mode == SJPEG_HIP_YUV400) ? 1 : 3;
   sjpeg_host::AdaptQuantMatrices(reinterpret_cast<const uint32_t(*)[64][128]>(hist), nb_comps, quant, mq,
                                  qdelta_max_luma, qdelta_max_chroma);
+  for (int idx = (nb_comps > 1 ? 1 : 0); idx >= 0; --idx) {
+    sjpeg_host::FinalizeQuantizer(quant[idx], mq[idx], q_bias, idx, tables);
+  }
+}
+
+void sjpeg_hip_adapt_quant_sums(const int64_t* sums, const int32_t* totlast, int yuv_mode,
+                                uint8_t quant[2][64], const uint8_t* min_quant, int q_bias,
+                                int qdelta_max_luma, int qdelta_max_chroma, sjpeg_hip_scan_tables* tables) {
+  uint8_t mq[2][64];
+  if (min_quant != nullptr) memcpy(mq, min_quant, sizeof(mq)); else memset(mq, 1, sizeof(mq));
+  const int nb_comps = (yuv_mode == SJPEG_HIP_YUV400) ? 1 : 3;
+  sjpeg_host::AdaptDecide(reinterpret_cast<const int64_t(*)[64][sjpeg_host::kAdaptDeltas][2]>(sums),
+                          reinterpret_cast<const int32_t(*)[64][2]>(totlast), nb_comps, quant,
+                          qdelta_max_luma, qdelta_max_chroma);
   for (int idx = (nb_comps > 1 ? 1 : 0); idx >= 0; --idx) {
     sjpeg_host::FinalizeQuantizer(quant[idx], mq[idx], q_bias, idx, tables);
   }

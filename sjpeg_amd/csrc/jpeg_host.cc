@@ -353,14 +353,56 @@ namespace sjpeg_host {
 
 namespace {
 enum { kQDeltaMin = -12, kQDeltaMax = 12, kQSize = kQDeltaMax + 1 - kQDeltaMin };   // sjpegi.h:269-273
+static_assert(kQSize == kAdaptDeltas, "candidate steps");
 // Gaussian weights, sigma ~ 3, centred on delta 0 (histogram.cc:117-124)
 const float kDeltaWeight[kQSize] = {0, 0, 0, 0, 0, 1, 5, 16, 43, 94, 164, 228, 255,
                                     228, 164, 94, 43, 16, 5, 1, 0, 0, 0, 0, 0};
 int BitLength(int v) { int n = 0; while (v) { ++n; v >>= 1; } return n; }
 }  // namespace
 
-void AdaptQuantMatrices(const uint32_t hist[2][64][128], int nb_comps, uint8_t quant[2][64],
-                        const uint8_t min_quant[2][64], int qdelta_max_luma, int qdelta_max_chroma) {
+// The bin loops of AnalyseHisto (src/histogram.cc:150-205) for one table: for every position and
+// candidate step the rate and distortion sums, plus the population / highest occupied bin of the
+// position.  All terms are (wrapping, like the reference's `int` products) 32-bit integers and
+// their running sums stay far below 2^53, so the reference's double accumulators hold exactly
+// these integers: the sums can be made anywhere -- here, or on the device
+// (sjpeg_hip_adapt_sums) -- and the float part below sees the same values.
+void AdaptSums(const uint32_t hist[64][128], const uint8_t quant[64], const uint8_t min_quant[64],
+               int64_t sums[64][kAdaptDeltas][2], int32_t totlast[64][2]) {
+  for (int pos = 0; pos < 64; ++pos) {
+    const uint32_t* const h = hist[pos];
+    int total = 0, last = 0;
+    for (int i = 0; i < 128; ++i) {
+      total += static_cast<int>(h[i]);
+      if (h[i]) last = i + 1;
+    }
+    totlast[pos][0] = total; totlast[pos][1] = last;
+    const int dq0 = quant[pos], min_dq0 = min_quant[pos];
+    const int bias = 1 << 16 >> 1;
+    for (int delta = 0; delta < kAdaptDeltas; ++delta) {
+      const int dq = dq0 + (delta + kQDeltaMin);
+      if (dq < min_dq0 || dq > 255) {
+        sums[pos][delta][0] = 0; sums[pos][delta][1] = INT64_MIN;     // not a candidate
+        continue;
+      }
+      const int idq = ((1 << 16) + dq - 1) / dq;
+      int64_t bsum = 0, dsum = 0;
+      for (int i = 0; i < last; ++i) {
+        const uint32_t hi = h[i];
+        const uint32_t v = (static_cast<uint32_t>(i) << 2) + 2;       // bin centroid: HSHIFT = 2, HHALF = 2
+        const uint32_t qv = (v * static_cast<uint32_t>(idq) + bias) >> 16;
+        const uint32_t bits = qv ? static_cast<uint32_t>(BitLength(static_cast<int>(qv))) : 0u;
+        const uint32_t d = v - qv * static_cast<uint32_t>(dq);        // (qv == 0: v itself)
+        bsum += static_cast<int32_t>(hi * bits);
+        dsum += static_cast<int32_t>(hi * (d * d));
+      }
+      sums[pos][delta][0] = bsum; sums[pos][delta][1] = dsum;
+    }
+  }
+}
+
+// The float / double half of AnalyseHisto (src/histogram.cc:126-315) on those sums.
+void AdaptDecide(const int64_t sums[2][64][kAdaptDeltas][2], const int32_t totlast[2][64][2], int nb_comps,
+                 uint8_t quant[2][64], int qdelta_max_luma, int qdelta_max_chroma) {
   const double r_limit = 0.5;                       // kCorrelationThreshold
   for (int idx = (nb_comps > 1 ? 1 : 0); idx >= 0; --idx) {
     const int delta_max = ((idx == 0) ? qdelta_max_luma : qdelta_max_chroma) - kQDeltaMin;
@@ -370,41 +412,16 @@ void AdaptQuantMatrices(const uint32_t hist[2][64][128], int nb_comps, uint8_t q
     uint64_t omit = 0x103ull;                       // DC and its two neighbours are never touched
     for (int pos = 0; pos < 64; ++pos) {
       if (omit & (1ull << pos)) continue;
-      const int dq0 = quant[idx][pos];
-      const int min_dq0 = min_quant[idx][pos];
-      const int bias = 1 << 16 >> 1;
-      const uint32_t* const h = hist[idx][pos];
-      int total = 0, last = 0;
-      for (int i = 0; i < 128; ++i) {
-        total += static_cast<int>(h[i]);
-        if (h[i]) last = i + 1;
-      }
+      const int total = totlast[idx][pos][0], last = totlast[idx][pos][1];
       if (total < 0.5 * last) {                     // kDensityThreshold
         omit |= 1ull << pos;
         continue;
       }
       double sw = 0., sx = 0., sxx = 0., syy1 = 0., sy1 = 0., sxy1 = 0., sy2 = 0., sxy2 = 0.;
       for (int delta = 0; delta < kQSize; ++delta) {
-        double bsum = 0., dsum = 0.;
-        const int dq = dq0 + (delta + kQDeltaMin);
-        if (dq >= min_dq0 && dq <= 255) {
-          const int idq = ((1 << 16) + dq - 1) / dq;
-          for (int i = 0; i < last; ++i) {
-            if (h[i]) {
-              const int hi = static_cast<int>(h[i]);
-              const int v = (i << 2) + 2;           // bin centroid: HSHIFT = 2, HHALF = 2
-              const int qv = (v * idq + bias) >> 16;
-              if (qv) {
-                const int bits = BitLength(qv);
-                const int dqv = qv * dq;
-                const int error = (v - dqv) * (v - dqv);
-                bsum += hi * bits;
-                dsum += hi * error;
-              } else {
-                dsum += hi * v * v;
-              }
-            }
-          }
+        if (sums[idx][pos][delta][1] != INT64_MIN) {
+          const double bsum = static_cast<double>(sums[idx][pos][delta][0]);
+          const double dsum = static_cast<double>(sums[idx][pos][delta][1]);
           distortions[pos][delta] = static_cast<float>(dsum);
           sizes[pos][delta] = static_cast<float>(bsum);
           const double w = kDeltaWeight[delta];
@@ -453,6 +470,14 @@ void AdaptQuantMatrices(const uint32_t hist[2][64][128], int nb_comps, uint8_t q
       quant[idx][pos] = static_cast<uint8_t>(quant[idx][pos] + best_dq);
     }
   }
+}
+
+void AdaptQuantMatrices(const uint32_t hist[2][64][128], int nb_comps, uint8_t quant[2][64],
+                        const uint8_t min_quant[2][64], int qdelta_max_luma, int qdelta_max_chroma) {
+  static thread_local int64_t sums[2][64][kAdaptDeltas][2];
+  static thread_local int32_t totlast[2][64][2];
+  for (int idx = 0; idx < (nb_comps > 1 ? 2 : 1); ++idx) AdaptSums(hist[idx], quant[idx], min_quant[idx], sums[idx], totlast[idx]);
+  AdaptDecide(sums, totlast, nb_comps, quant, qdelta_max_luma, qdelta_max_chroma);
 }
 
 void BuildOptimalSpec(const uint32_t* freq, int size, HuffSpec* out) {

@@ -69,6 +69,11 @@ namespace sjpeg_host {
 // reference: Encoder::AnalyseHisto, src/histogram.cc:126-315.  hist[idx][pos][bin] counts the
 // coefficients of table idx (0 luma, 1 chroma) at NATURAL position pos with |c| >> 2 == bin
 // (bin < 128).  Rewrites quant[idx][pos] (within min_quant and the delta limits).
+enum { kAdaptDeltas = 25 };        // candidate steps per position: -12 .. +12 (sjpegi.h:269-273)
+void AdaptSums(const uint32_t hist[64][128], const uint8_t quant[64], const uint8_t min_quant[64],
+               int64_t sums[64][kAdaptDeltas][2], int32_t totlast[64][2]);
+void AdaptDecide(const int64_t sums[2][64][kAdaptDeltas][2], const int32_t totlast[2][64][2], int nb_comps,
+                 uint8_t quant[2][64], int qdelta_max_luma, int qdelta_max_chroma);
 void AdaptQuantMatrices(const uint32_t hist[2][64][128], int nb_comps, uint8_t quant[2][64],
                         const uint8_t min_quant[2][64], int qdelta_max_luma, int qdelta_max_chroma);
 

@@ -1379,6 +1379,49 @@ __global__ __launch_bounds__(kThreads) void reduce_error(const unsigned long lon
 }
 
 // ------------------------------------------------------------------------------------
+// The bin loops of AnalyseHisto (reference src/histogram.cc:150-205) on the device-resident
+// histogram: one small workgroup per (frame, table, position), one thread per candidate step.
+// Integer sums only (see jpeg_host.cc AdaptSums: the reference's double accumulators hold exactly
+// these integers); the regression and the choice of the step stay on the host.
+struct AdaptArgs {
+  const uint32_t* hist;             // [nframes][2][64][128]
+  long long* sums;                  // [nframes][2][64][25][2]: bits, distortion (INT64_MIN = not a candidate)
+  int* totlast;                     // [nframes][2][64][2]: population, highest occupied bin + 1
+  uint8_t quant[2][64], min_quant[2][64];
+};
+__global__ __launch_bounds__(32) void adapt_sums_kernel(const AdaptArgs a) {
+  const int pos = blockIdx.x, idx = blockIdx.y, frame = blockIdx.z, delta = threadIdx.x;
+  const uint32_t* const h = a.hist + ((static_cast<size_t>(frame) * 2 + idx) * 64 + pos) * 128;
+  int total = 0, last = 0;
+  for (int i = 0; i < 128; ++i) {
+    const uint32_t hi = h[i];
+    total += static_cast<int>(hi);
+    if (hi) last = i + 1;
+  }
+  const size_t cell = (static_cast<size_t>(frame) * 2 + idx) * 64 + pos;
+  if (delta == 0) { a.totlast[cell * 2] = total; a.totlast[cell * 2 + 1] = last; }
+  if (delta >= 25) return;
+  const int dq = static_cast<int>(a.quant[idx][pos]) + (delta - 12);
+  long long bsum = 0, dsum = 0;
+  if (dq < static_cast<int>(a.min_quant[idx][pos]) || dq > 255) {
+    dsum = static_cast<long long>(0x8000000000000000ull);
+  } else {
+    const uint32_t idq = static_cast<uint32_t>(((1 << 16) + dq - 1) / dq);
+    for (int i = 0; i < last; ++i) {
+      const uint32_t hi = h[i];
+      const uint32_t v = (static_cast<uint32_t>(i) << 2) + 2;
+      const uint32_t qv = (v * idq + (1u << 16 >> 1)) >> 16;
+      const uint32_t bits = 32u - __clz(qv);                        // 0 for qv == 0
+      const uint32_t d = v - qv * static_cast<uint32_t>(dq);
+      bsum += static_cast<int>(hi * bits);
+      dsum += static_cast<int>(hi * (d * d));
+    }
+  }
+  a.sums[(cell * 25 + delta) * 2] = bsum;
+  a.sums[(cell * 25 + delta) * 2 + 1] = dsum;
+}
+
+// ------------------------------------------------------------------------------------
 // K2: per frame, exclusive scan of segment bit lengths
 
 struct StitchArgs {
@@ -2231,6 +2274,22 @@ int sjpeg_hip_stitch_bands(sjpeg_hip_engine* e, int nbands, const uint32_t* d_wo
   uint32_t gx = 4096u;
   if (gx > max_chunks) gx = max_chunks;
   hipLaunchKernelGGL(stuff_chunks, dim3(gx, 1), dim3(kThreads), 0, st, s);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int sjpeg_hip_adapt_sums(const uint32_t* d_hist, int nframes, const uint8_t quant[2][64],
+                         const uint8_t* min_quant, int64_t* d_sums, int32_t* d_totlast, void* stream) {
+  if (d_hist == nullptr || quant == nullptr || d_sums == nullptr || d_totlast == nullptr || nframes <= 0 || nframes > 65535) {
+    return fail(SJPEG_HIP_EINVAL, "null argument or bad nframes");
+  }
+  AdaptArgs a;
+  a.hist = d_hist;
+  a.sums = reinterpret_cast<long long*>(d_sums);
+  a.totlast = d_totlast;
+  memcpy(a.quant, quant, sizeof(a.quant));
+  if (min_quant != nullptr) memcpy(a.min_quant, min_quant, sizeof(a.min_quant)); else memset(a.min_quant, 1, sizeof(a.min_quant));
+  hipLaunchKernelGGL(adapt_sums_kernel, dim3(64, 2, nframes), dim3(32), 0, static_cast<hipStream_t>(stream), a);
   HIP_TRY(hipGetLastError());
   return 0;
 }

@@ -577,3 +577,21 @@ def test_sharp_yuv_batch_and_bgra_planes(oracle):
                 np.array_equal(v[k].cpu().numpy(), wv), (w, h, k)
             assert np.array_equal(y4[k].cpu().numpy(), wy) and np.array_equal(u4[k].cpu().numpy(), wu) and \
                 np.array_equal(v4[k].cpu().numpy(), wv), (w, h, k, "bgra")
+
+
+def test_adaptive_analysis_on_device_equals_host(engine):
+    """AnalyseHisto's bin loops on the GPU (sjpeg_hip_adapt_sums) + the float half on the host ==
+    the all-host analysis (which the CPU tests pin against the oracle), incl. min-quant limits."""
+    rng = np.random.RandomState(91)
+    for (w, h, mode) in ((640, 360, 1), (333, 211, 3), (97, 61, 4), (1920, 1080, 1)):
+        img = synth.g_struct(w, h, 17) if w != 333 else rng.randint(0, 256, (h, w, 3)).astype(np.uint8)
+        hist_dev = engine.scan_histogram(dev(img), mode)[0]
+        hist = hist_dev.cpu().numpy().view(np.uint32)
+        for q in (20.0, 75.0, 95.0):
+            quant = sj.make_tables(quality=q)[1]
+            for mq in (None, np.maximum(quant, 4)):
+                for (dl, dc) in ((12, 1), (5, 7)):
+                    t_host, q_host = sj.adapt_quant(hist, mode, quant, mq, 0x78, dl, dc)
+                    t_dev, q_dev = sj.adapt_quant_device(hist_dev, mode, quant, mq, 0x78, dl, dc)
+                    assert np.array_equal(q_host, q_dev), (w, h, mode, q, dl, dc)
+                    assert bytes(t_host) == bytes(t_dev)
