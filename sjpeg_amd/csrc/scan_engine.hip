@@ -819,7 +819,13 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
     // 252 blocks), flushed as this workgroup's partial; reduce_partials() sums them.
     __syncthreads();                            // every thread holds its samples: slots are free
     uint32_t* const lh = reinterpret_cast<uint32_t*>(smem);
-    for (int i = tid; i < kHistoWords; i += kScanThreads) lh[i] = 0;
+    // Bins 0..3 (one word per position) take most of the hits and every lane of a wave hits the
+    // SAME word: an LDS atomic serialises those lanes.  Eight replicas of that word, picked by
+    // lane, cut the conflicts eight-fold; they are folded back before the flush.  (A position
+    // has at most 252 entries per workgroup: the 8-bit fields cannot overflow.)
+    constexpr int kReps = 8;
+    uint32_t* const rep = lh + kHistoWords;       // [2][64][kReps]
+    for (int i = tid; i < kHistoWords + 2 * 64 * kReps; i += kScanThreads) lh[i] = 0;
     __syncthreads();
     int acc[8];
     auto bump = [&](int row, const int* ac8) {
@@ -827,15 +833,11 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
       for (int i = 0; i < 8; ++i) {
         const int c = ac8[i] >> 16;
         const uint32_t bin = static_cast<uint32_t>(c < 0 ? -c : c) >> 2;
-        const bool ok = emits && bin < 128u;
-        // most coefficients fall in bin 0: count those lanes with one ballot per table
-        const unsigned long long z0 = __ballot(ok && bin == 0 && tbl == 0);
-        const unsigned long long z1 = __ballot(ok && bin == 0 && tbl == 1);
-        if ((tid & 63) == 0) {
-          if (z0) atomicAdd(&lh[(0 * 64 + row * 8 + i) * 32], static_cast<uint32_t>(__popcll(z0)));
-          if (z1) atomicAdd(&lh[(1 * 64 + row * 8 + i) * 32], static_cast<uint32_t>(__popcll(z1)));
+        if (emits && bin < 128u) {
+          const int pos = tbl * 64 + row * 8 + i;
+          uint32_t* const w = (bin < 4u) ? &rep[pos * kReps + (tid & (kReps - 1))] : &lh[pos * 32 + (bin >> 2)];
+          atomicAdd(w, 1u << (8 * (bin & 3)));
         }
-        if (ok && bin != 0) atomicAdd(&lh[(tbl * 64 + row * 8 + i) * 32 + (bin >> 2)], 1u << (8 * (bin & 3)));
       }
     };
     fdct_row8_pk<22725, 21407, 19266, 16384, 12873, 8867, 4520>(p[0], acc); bump(0, acc);
@@ -846,6 +848,13 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
     fdct_row8_pk<26722, 25172, 22654, 19266, 15137, 10426, 5315>(p[5], acc); bump(5, acc);
     fdct_row8_pk<29692, 27969, 25172, 21407, 16819, 11585, 5906>(p[6], acc); bump(6, acc);
     fdct_row8_pk<31521, 29692, 26722, 22725, 17855, 12299, 6270>(p[7], acc); bump(7, acc);
+    __syncthreads();
+    if (tid < 128) {                               // fold the replicas into word 0 of their position
+      uint32_t sum = 0;
+#pragma unroll
+      for (int r = 0; r < kReps; ++r) sum += rep[tid * kReps + r];
+      lh[tid * 32] += sum;
+    }
     __syncthreads();
     uint32_t* const dst = a.partial + (static_cast<size_t>(frame) * a.nseg + seg) * kHistoWords;
     for (int i = tid; i < kHistoWords; i += kScanThreads) dst[i] = lh[i];
@@ -1347,22 +1356,32 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
 template <bool BYTES>
 __global__ __launch_bounds__(kThreads) void reduce_partials(const uint32_t* part, int nseg, int words,
                                                            uint32_t* out) {
+  // blockIdx.z = slice of the segments: a thread adds up its slice (independent loads, unrolled)
+  // and the slices meet in the output with atomics (cleared by the caller).  One thread walking
+  // all ~800 partials of a 4K frame was a chain of loads: 0.15 ms of a 0.23 ms histogram pass.
   const int frame = blockIdx.y;
   const int w = blockIdx.x * kThreads + threadIdx.x;
   if (w >= words) return;
+  const int per = (nseg + gridDim.z - 1) / gridDim.z;
+  const int s0 = blockIdx.z * per, s1 = min(nseg, s0 + per);
   const uint32_t* src = part + static_cast<size_t>(frame) * nseg * words + w;
   if (BYTES) {
-    uint32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-    for (int s = 0; s < nseg; ++s) {
+    uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+#pragma unroll 8
+    for (int s = s0; s < s1; ++s) {
       const uint32_t v = src[static_cast<size_t>(s) * words];
-      s0 += v & 0xffu; s1 += (v >> 8) & 0xffu; s2 += (v >> 16) & 0xffu; s3 += v >> 24;
+      c0 += v & 0xffu; c1 += (v >> 8) & 0xffu; c2 += (v >> 16) & 0xffu; c3 += v >> 24;
     }
     uint32_t* dst = out + (static_cast<size_t>(frame) * words + w) * 4;
-    dst[0] = s0; dst[1] = s1; dst[2] = s2; dst[3] = s3;
+    if (c0) atomicAdd(&dst[0], c0);
+    if (c1) atomicAdd(&dst[1], c1);
+    if (c2) atomicAdd(&dst[2], c2);
+    if (c3) atomicAdd(&dst[3], c3);
   } else {
     uint32_t sum = 0;
-    for (int s = 0; s < nseg; ++s) sum += src[static_cast<size_t>(s) * words];
-    out[static_cast<size_t>(frame) * words + w] = sum;
+#pragma unroll 8
+    for (int s = s0; s < s1; ++s) sum += src[static_cast<size_t>(s) * words];
+    if (sum) atomicAdd(&out[static_cast<size_t>(frame) * words + w], sum);
   }
 }
 
@@ -2026,7 +2045,9 @@ static int scan_statistics(sjpeg_hip_engine* e, const sjpeg_hip_source* src, int
   else if (tables != nullptr && (tables->flags & SJPEG_HIP_QUANT_TRELLIS)) rc = launch_scan<kKindStatsTrellis>(yuv_mode, cls, dim3(g.nseg, nframes), st, a);
   else rc = launch_scan<kKindStats>(yuv_mode, cls, dim3(g.nseg, nframes), st, a);
   if (rc) return rc;
-  const dim3 grid((words + kThreads - 1) / kThreads, nframes);
+  const int slices = g.nseg >= 64 ? 32 : 1;
+  const dim3 grid((words + kThreads - 1) / kThreads, nframes, slices);
+  HIP_TRY(hipMemsetAsync(d_out, 0, static_cast<size_t>(nframes) * words * (histogram ? 4 : 1) * sizeof(uint32_t), st));
   if (histogram) {
     hipLaunchKernelGGL(reduce_partials<true>, grid, dim3(kThreads), 0, st, e->partial.p, g.nseg, words, d_out);
   } else {
