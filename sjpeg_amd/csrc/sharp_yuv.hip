@@ -215,6 +215,164 @@ __global__ __launch_bounds__(kSweepThreads) void sharp_sweeps(const SharpArgs a)
   }
 }
 
+// ---- the same sweeps for pictures up to 4096 pixels wide: nothing a step needs from global
+// memory is requested in that step.  The chroma rows `cur` and `next` of a row pair are last
+// sweep's values and the W / target rows do not depend on the neighbours, so they are loaded one
+// row pair AHEAD into registers; the one thing that does depend on the step before -- the row
+// above, just updated by the neighbours -- travels through a double-buffered LDS row.  One barrier
+// per row pair, and it does not wait for the loads in flight.
+constexpr int kFastCols = 2;                      // chroma columns per thread
+__global__ __launch_bounds__(kSweepThreads) void sharp_sweeps_fast(const SharpArgs a) {
+  __shared__ uint32_t g2l[kMaxY + 1];
+  __shared__ uint32_t l2g[kGammaTab + 2];
+  __shared__ unsigned long long red[kSweepThreads / 64];
+  __shared__ int stop;
+  __shared__ int16_t above[2][3][kFastCols * kSweepThreads];   // the updated row above, ping-pong
+  const int frame = blockIdx.x, tid = threadIdx.x;
+  for (int i = tid; i <= kMaxY; i += kSweepThreads) g2l[i] = a.tab->g2l[i];
+  if (tid < kGammaTab + 2) l2g[tid] = a.tab->l2g[tid];
+  uint16_t* const best_y = a.best_y + static_cast<size_t>(frame) * a.w * a.h;
+  const uint16_t* const target_y = a.target_y + static_cast<size_t>(frame) * a.w * a.h;
+  int16_t* const best_uv = a.best_uv + static_cast<size_t>(frame) * a.uv_h * 3 * a.uv_w;
+  const int16_t* const target_uv = a.target_uv + static_cast<size_t>(frame) * a.uv_h * 3 * a.uv_w;
+  const int w = a.w, h = a.h, uv_w = a.uv_w, uv_h = a.uv_h;
+  const unsigned long long threshold = static_cast<unsigned long long>(3.0 * w * h);
+  unsigned long long prev_diff = ~0ull;
+  // a barrier that orders LDS traffic only: global loads stay in flight across it
+  auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+
+  struct RowData {                                  // what one row pair needs from global memory, per column
+    int uv[3][3];                                   // chroma row: [channel][left, centre, right]
+    uint32_t wy[2], ty[2];                          // W and its target: two pixels per word, two rows
+    int tuv[3];                                     // chroma target
+  };
+  auto load_uv = [&](int row, int c, int (&dst)[3][3]) {
+    const int cl = c > 0 ? c - 1 : 0, cr = c < uv_w - 1 ? c + 1 : uv_w - 1;
+    const int16_t* r = best_uv + static_cast<size_t>(row) * 3 * uv_w;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { dst[k][0] = r[k * uv_w + cl]; dst[k][1] = r[k * uv_w + c]; dst[k][2] = r[k * uv_w + cr]; }
+  };
+  auto load_rest = [&](int ry, int c, RowData& d) {
+    const uint32_t* by0 = reinterpret_cast<const uint32_t*>(best_y + static_cast<size_t>(2 * ry) * w);
+    const uint32_t* by1 = reinterpret_cast<const uint32_t*>(best_y + static_cast<size_t>(2 * ry + 1) * w);
+    const uint32_t* ty0 = reinterpret_cast<const uint32_t*>(target_y + static_cast<size_t>(2 * ry) * w);
+    const uint32_t* ty1 = reinterpret_cast<const uint32_t*>(target_y + static_cast<size_t>(2 * ry + 1) * w);
+    d.wy[0] = by0[c]; d.wy[1] = by1[c]; d.ty[0] = ty0[c]; d.ty[1] = ty1[c];
+    const int16_t* t = target_uv + static_cast<size_t>(ry) * 3 * uv_w;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) d.tuv[k] = t[k * uv_w + c];
+  };
+  __syncthreads();
+  for (int iter = 0; iter < 4; ++iter) {
+    unsigned long long diff = 0;
+    RowData now[kFastCols], ahead[kFastCols];
+    int nxt[kFastCols][3][3];                       // chroma row ry + 1 (last sweep's values)
+#pragma unroll
+    for (int s = 0; s < kFastCols; ++s) {
+      const int c = tid + s * kSweepThreads;
+      if (c < uv_w) {
+        load_uv(0, c, now[s].uv);
+        load_rest(0, c, now[s]);
+        load_uv(uv_h > 1 ? 1 : 0, c, nxt[s]);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) above[0][k][c] = static_cast<int16_t>(now[s].uv[k][1]);   // row pair 0: "above" is the row itself
+      }
+    }
+    lds_barrier();
+    for (int ry = 0; ry < uv_h; ++ry) {
+      const int pp = ry & 1;
+      // request what the NEXT row pair needs
+#pragma unroll
+      for (int s = 0; s < kFastCols; ++s) {
+        const int c = tid + s * kSweepThreads;
+        if (c < uv_w && ry + 1 < uv_h) {
+          load_rest(ry + 1, c, ahead[s]);
+          load_uv(ry + 2 < uv_h ? ry + 2 : ry + 1, c, ahead[s].uv);     // becomes `nxt` of the next step
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < kFastCols; ++s) {
+        const int c = tid + s * kSweepThreads;
+        if (c < uv_w) {
+          const int cl = c > 0 ? c - 1 : 0, cr = c < uv_w - 1 ? c + 1 : uv_w - 1;
+          const int wy[2][2] = {{static_cast<int>(now[s].wy[0] & 0xffffu), static_cast<int>(now[s].wy[0] >> 16)},
+                                {static_cast<int>(now[s].wy[1] & 0xffffu), static_cast<int>(now[s].wy[1] >> 16)}};
+          const int ty[2][2] = {{static_cast<int>(now[s].ty[0] & 0xffffu), static_cast<int>(now[s].ty[0] >> 16)},
+                                {static_cast<int>(now[s].ty[1] & 0xffffu), static_cast<int>(now[s].ty[1] >> 16)}};
+          int px[2][2][3];
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            const int A = now[s].uv[k][1], Al = now[s].uv[k][0], Ar = now[s].uv[k][2];
+            const int P = above[pp][k][c], Pl = above[pp][k][cl], Pr = above[pp][k][cr];
+            const bool has_next = ry + 1 < uv_h;                   // last row pair: next == cur
+            const int N = has_next ? nxt[s][k][1] : A, Nl = has_next ? nxt[s][k][0] : Al, Nr = has_next ? nxt[s][k][2] : Ar;
+            int up0, up1, dn0, dn1;
+            if (c == 0) { up0 = (A * 3 + P + 2) >> 2; dn0 = (A * 3 + N + 2) >> 2; }
+            else { up0 = (A * 9 + Al * 3 + P * 3 + Pl + 8) >> 4; dn0 = (A * 9 + Al * 3 + N * 3 + Nl + 8) >> 4; }
+            if (c == uv_w - 1) { up1 = (A * 3 + P + 2) >> 2; dn1 = (A * 3 + N + 2) >> 2; }
+            else { up1 = (A * 9 + Ar * 3 + P * 3 + Pr + 8) >> 4; dn1 = (A * 9 + Ar * 3 + N * 3 + Nr + 8) >> 4; }
+            px[0][0][k] = clip_y(wy[0][0] + up0); px[0][1][k] = clip_y(wy[0][1] + up1);
+            px[1][0][k] = clip_y(wy[1][0] + dn0); px[1][1][k] = clip_y(wy[1][1] + dn1);
+          }
+          int wt[2][2], uv[3];
+          eval_group(g2l, l2g, px, wt, uv);
+          uint32_t newy[2];
+#pragma unroll
+          for (int r = 0; r < 2; ++r) {
+            int ny[2];
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc) {
+              const int d = ty[r][cc] - wt[r][cc];
+              ny[cc] = clip_y(wy[r][cc] + d);
+              diff += static_cast<unsigned long long>(d < 0 ? -d : d);
+            }
+            newy[r] = static_cast<uint32_t>(ny[0]) | (static_cast<uint32_t>(ny[1]) << 16);
+          }
+          reinterpret_cast<uint32_t*>(best_y + static_cast<size_t>(2 * ry) * w)[c] = newy[0];
+          reinterpret_cast<uint32_t*>(best_y + static_cast<size_t>(2 * ry + 1) * w)[c] = newy[1];
+          // SharpUpdateRGB: the row becomes this sweep's; the neighbours of the next row pair
+          // read it from the other LDS buffer
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            const int16_t nv = static_cast<int16_t>(now[s].uv[k][1] + (now[s].tuv[k] - uv[k]));
+            best_uv[static_cast<size_t>(ry) * 3 * uv_w + k * uv_w + c] = nv;
+            above[pp ^ 1][k][c] = nv;
+          }
+        }
+      }
+      lds_barrier();
+      // rotate: cur <- next (old values), next <- the row requested above
+#pragma unroll
+      for (int s = 0; s < kFastCols; ++s) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+#pragma unroll
+          for (int t = 0; t < 3; ++t) { now[s].uv[k][t] = nxt[s][k][t]; nxt[s][k][t] = ahead[s].uv[k][t]; }
+          now[s].tuv[k] = ahead[s].tuv[k];
+        }
+        now[s].wy[0] = ahead[s].wy[0]; now[s].wy[1] = ahead[s].wy[1];
+        now[s].ty[0] = ahead[s].ty[0]; now[s].ty[1] = ahead[s].ty[1];
+      }
+    }
+    // exit test (:660-666): sum of |dW| over the picture; full barriers: the next sweep reads
+    // what this one stored
+    for (int d = 32; d > 0; d >>= 1) diff += __shfl_down(diff, d, 64);
+    if ((tid & 63) == 0) red[tid >> 6] = diff;
+    __syncthreads();
+    if (tid == 0) {
+      unsigned long long sum = 0;
+      for (int i = 0; i < kSweepThreads / 64; ++i) sum += red[i];
+      stop = (iter > 0 && (sum < threshold || sum > prev_diff)) ? 1 : 0;
+      red[0] = sum;
+    }
+    __syncthreads();
+    prev_diff = red[0];
+    const int sflag = stop;
+    __syncthreads();
+    if (sflag) break;
+  }
+}
+
 // ---- back to 8-bit planes (:543-575; this file's own -11058 / -5328 constants)
 __global__ __launch_bounds__(256) void sharp_export(const SharpArgs a) {
   const int frame = blockIdx.z;
@@ -362,7 +520,8 @@ int sjpeg_hip_sharp_yuv(const sjpeg_hip_source* src, int width, int height, int 
   a.row_uv = reinterpret_cast<int16_t*>(p);
   const dim3 grid((a.uv_w + 255) / 256, a.uv_h, nframes);
   hipLaunchKernelGGL(sharp_import, grid, dim3(256), 0, st, a);
-  hipLaunchKernelGGL(sharp_sweeps, dim3(nframes), dim3(kSweepThreads), 0, st, a);
+  if (a.uv_w <= kFastCols * kSweepThreads) hipLaunchKernelGGL(sharp_sweeps_fast, dim3(nframes), dim3(kSweepThreads), 0, st, a);
+  else hipLaunchKernelGGL(sharp_sweeps, dim3(nframes), dim3(kSweepThreads), 0, st, a);
   hipLaunchKernelGGL(sharp_export, grid, dim3(256), 0, st, a);
   return hipGetLastError() == hipSuccess ? 0 : SJPEG_HIP_ERUNTIME;
 }
