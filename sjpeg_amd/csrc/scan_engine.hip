@@ -1314,20 +1314,22 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
   for (;;) {
     for (int i = tid; i < kWinWords / 4; i += kScanThreads) reinterpret_cast<uint4*>(win)[i] = make_uint4(0, 0, 0, 0);
     if (tid == 0) win[kWinWords] = 0;
-    if (tid == 0) misc[8] = total;
+    // the usual case -- the rest of the segment fits the window -- needs no vote
+    const bool all_fit = total <= base + kWinWords * 32u;            // uniform
+    if (!all_fit && tid == 0) misc[8] = total;
     __syncthreads();
     if (tid == 0 && carry != 0) atomicOr(&win[0], carry);
     uint32_t fits = 0;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       if (pending & (1u << r)) {
-        if (us_get(r) + (ur_get(r) >> 16) <= base + kWinWords * 32u) fits |= 1u << r;
+        if (all_fit || us_get(r) + (ur_get(r) >> 16) <= base + kWinWords * 32u) fits |= 1u << r;
         else atomicMin(&misc[8], us_get(r));
       }
     }
-    __syncthreads();
+    if (!all_fit) __syncthreads();
     // everything that starts before the first non-fitting part (stream order) is placed now
-    const uint32_t limit = misc[8];
+    const uint32_t limit = all_fit ? total : misc[8];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       if (r < n_rounds && (fits & (1u << r)) && us_get(r) < limit) {
