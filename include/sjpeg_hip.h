@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SJPEG_HIP_ABI_VERSION 7
+#define SJPEG_HIP_ABI_VERSION 8
 
 enum {
   SJPEG_HIP_OK = 0,
@@ -69,6 +69,15 @@ typedef struct sjpeg_hip_scan_tables {
  * (Encoder::TrellisQuantizeBlock, src/quantize.cc:325-457) instead of plain rounding.  Applies to
  * the encode and symbol-statistics passes. */
 #define SJPEG_HIP_QUANT_TRELLIS 1u
+/* Two-pass flows quantize every block twice (statistics pass, then encode pass with the tables
+ * compiled from it).  KEEP: the statistics pass leaves its quantized blocks in the engine (144 B per
+ * block); REPLAY: the encode pass entropy-codes those instead of converting, transforming and
+ * quantizing the pixels again -- what the reference's stored run/levels do (reuse_run_levels_,
+ * src/enc.cc:121-129).  REPLAY needs a KEEP statistics pass of the same geometry right before it on
+ * the same engine, and ignores iquant / bias / quant / trellis_len / the pixel source.  Worth it
+ * where quantization is expensive: the host API uses it for the trellis methods. */
+#define SJPEG_HIP_QUANT_KEEP 2u
+#define SJPEG_HIP_QUANT_REPLAY 4u
 
 /* Pixel sources.  Packed colour and gray use plane[0]; planar YUV uses Y, U, V; NV12/NV21 use
  * Y and the interleaved chroma plane in plane[1].  Chroma planes of the 4:2:0 layouts are

@@ -34,6 +34,8 @@ class ScanTables(C.Structure):
 
 
 QUANT_TRELLIS = 1
+QUANT_KEEP = 2
+QUANT_REPLAY = 4
 
 
 SRC_RGB, SRC_BGRA, SRC_RGBA, SRC_GRAY, SRC_YUV444, SRC_YUV420, SRC_NV12, SRC_NV21 = range(8)

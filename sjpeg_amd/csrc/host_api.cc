@@ -589,13 +589,16 @@ bool Encoder::Run() {
   const HuffSpec* dc[2] = {&sjpeg_host::DefaultHuff(0, 0), &sjpeg_host::DefaultHuff(0, 1)};
   const HuffSpec* ac[2] = {&sjpeg_host::DefaultHuff(1, 0), &sjpeg_host::DefaultHuff(1, 1)};
   HuffSpec opt[4];
+  bool replay = false;                              // trellis: the statistics pass keeps its blocks, the encode pass replays them
   if (final_tables_known) {
     for (int t = 0; t < ntables; ++t) { dc[t] = &pass_specs[t]; ac[t] = &pass_specs[2 + t]; }
   } else if (optimize) {
     // statistics half of SinglePassScanOptimized on the GPU (src/enc.cc:323-372),
     // CompileEntropyStats on the host (src/entropy.cc:432-444)
     uint32_t freq[2][272];
+    if (trellis) tables.flags |= SJPEG_HIP_QUANT_KEEP;
     if (!symbol_stats(freq)) return false;
+    if (trellis) { tables.flags &= ~SJPEG_HIP_QUANT_KEEP; replay = true; }
     for (int t = 0; t < ntables; ++t) {
       sjpeg_host::BuildOptimalSpec(freq[t] + 256, 12, &opt[t]);
       sjpeg_host::BuildOptimalSpec(freq[t], 256, &opt[2 + t]);
@@ -603,6 +606,7 @@ bool Encoder::Run() {
       ac[t] = &opt[2 + t];
     }
   }
+  if (replay) tables.flags |= SJPEG_HIP_QUANT_REPLAY;
   sjpeg_host::InstallCodes(dc, ac, ntables, &tables);
 
   // headers: SOI/APP0, metadata, DQT, SOF, DHT, SOS (src/enc.cc:415-443)

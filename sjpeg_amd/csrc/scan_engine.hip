@@ -89,6 +89,7 @@ struct ScanArgs {
   uint32_t slot_words;
   uint32_t* seg_nbits;     // [nframes*nseg]
   uint32_t* spill;         // [nframes*nseg][kScanThreads][kSpillWords]: words that cannot stay in the slot
+  uint32_t* replay;        // [nframes*nseg][kScanThreads][36]: quantized blocks kept by a statistics pass (or NULL)
   int16_t* coeffs;         // kKindTap: quantized coefficients
   uint32_t* partial;       // kKindHisto / kKindStats: per-workgroup partial statistics
   unsigned long long* stamps;  // profiling (env SJPEG_HIP_STAMPS): 8 cycle stamps per workgroup
@@ -535,14 +536,16 @@ __device__ __forceinline__ uint32_t wg_exclusive_scan(uint32_t x, uint32_t* scra
 // K1: colour + fDCT + quantize + entropy-code one segment
 
 enum { kKindEncode = 0, kKindTap = 1, kKindHisto = 2, kKindStats = 3, kKindError = 4,
-       kKindEncodeTrellis = 5, kKindStatsTrellis = 6 };   // the same two with trellis quantization
+       kKindEncodeTrellis = 5, kKindStatsTrellis = 6,     // the same two with trellis quantization
+       kKindEncodeReplay = 7 };   // entropy-code the coefficients a statistics pass left behind
 constexpr int kHistoWords = 2 * 64 * 32;          // per-workgroup partial: u8 counters [2][64][128]
 constexpr int kStatsWords = 2 * 272;              // per-workgroup partial: u32 [2][256 AC + 16 DC]
 
 template <int MODE, int KINDX, int SRC>
 __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) {
   constexpr bool TRELLIS = (KINDX == kKindEncodeTrellis || KINDX == kKindStatsTrellis);
-  constexpr int KIND = (KINDX == kKindEncodeTrellis) ? kKindEncode : (KINDX == kKindStatsTrellis) ? kKindStats : KINDX;
+  constexpr bool REPLAY = (KINDX == kKindEncodeReplay);
+  constexpr int KIND = (KINDX == kKindEncodeTrellis || KINDX == kKindEncodeReplay) ? kKindEncode : (KINDX == kKindStatsTrellis) ? kKindStats : KINDX;
   using G = Geo<MODE>;
   constexpr int BPM = G::kBpm;
   constexpr int PX = G::kMcuPx;
@@ -577,7 +580,8 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
 
   // ---- P1: colour conversion, strips of 8 pixels (x2 rows for 4:2:0) --------------------
   // local MCU index ml: 0 = halo, 1..n_coded = coded MCUs; block slot = ml*BPM + k
-  {
+  if (REPLAY) stage_tables();
+  if (!REPLAY) {
     const int ml_lo = 1 - halo;
     const int n_proc = n_coded + halo;
     constexpr int kRowsPerStrip = (MODE == SJPEG_HIP_YUV420) ? 2 : 1;
@@ -723,7 +727,19 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
   const bool emits = (ml >= 1) && (ml <= n_coded);
   const int tbl = (MODE == SJPEG_HIP_YUV420) ? (k >= 4) : (MODE == SJPEG_HIP_YUV444 ? (k >= 1) : 0);
   unsigned char* const slot = smem + tid * kSlotBytes;
-
+  uint32_t nzq[4] = {0, 0, 0, 0};                   // non-zero masks of the four zig-zag quarters
+  int dc_val = 0;
+  // what a statistics pass keeps for the replay kind: the slot as P2 leaves it + masks + DC value
+  uint4* const keep = (a.replay == nullptr) ? nullptr
+      : reinterpret_cast<uint4*>(a.replay) + ((static_cast<size_t>(frame) * a.nseg + seg) * kScanThreads + tid) * 9;
+  if (REPLAY) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) *reinterpret_cast<uint4*>(slot + 16 * r) = keep[r];
+    const uint4 t = keep[8];
+    nzq[0] = t.x & 0xffffu; nzq[1] = t.x >> 16; nzq[2] = t.y & 0xffffu; nzq[3] = t.y >> 16;
+    dc_val = static_cast<int>(t.z);
+  }
+  if (!REPLAY) {
   // rows as packed int16 pairs, straight from the slot: p[r][c] = (s[r][2c], s[r][2c+1])
   uint32_t p[8][4];
 #pragma unroll
@@ -860,7 +876,6 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
     for (int i = tid; i < kHistoWords; i += kScanThreads) dst[i] = lh[i];
     return;
   }
-  uint32_t nzq[4] = {0, 0, 0, 0};                   // non-zero masks of the four zig-zag quarters
   uint32_t ent[32];                             // natural order, 2 entries per dword
   {
     const uint4* qt = lq + tbl * 32;
@@ -894,7 +909,6 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
                                               kPairSel(kZig(i + 2), kZig(i + 3)));
     *reinterpret_cast<uint2*>(slot + 2 * i) = make_uint2(w0, w1);
   }
-  int dc_val;
   if (!TRELLIS) {
     const int dc_mag = static_cast<int>(ent[0] & 0x7fffu);
     dc_val = (ent[0] & 0x8000u) ? -dc_mag : dc_mag;
@@ -998,6 +1012,12 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
     nzq[2] = static_cast<uint32_t>(nzm >> 32) & 0xffffu; nzq[3] = static_cast<uint32_t>(nzm >> 48);
   }
   nzq[0] &= ~1u;                                // DC is coded separately
+  if (KIND == kKindStats && keep != nullptr) {   // leave the quantized block behind for the replay kind
+#pragma unroll
+    for (int r = 0; r < 8; ++r) keep[r] = *reinterpret_cast<const uint4*>(slot + 16 * r);
+    keep[8] = make_uint4(nzq[0] | (nzq[1] << 16), nzq[2] | (nzq[3] << 16), static_cast<uint32_t>(dc_val), 0u);
+  }
+  }   // !REPLAY
   const uint32_t nz_lo = nzq[0] | (nzq[1] << 16), nz_hi = nzq[2] | (nzq[3] << 16);
   if (KIND == kKindTap) {
     if (emits) {
@@ -1779,7 +1799,8 @@ struct sjpeg_hip_engine {
   int device = 0;
   DevBuf<DevTables> tables;
   DevBuf<uint8_t> header;
-  DevBuf<uint32_t> seg_words, seg_nbits, spill, ubuf, chunk_ff, partial;
+  DevBuf<uint32_t> seg_words, seg_nbits, spill, ubuf, chunk_ff, partial, replay;
+  int replay_w = 0, replay_h = 0, replay_mode = 0, replay_nframes = 0;   // what `replay` holds (0 = nothing)
   DevBuf<unsigned long long> seg_off, chunk_off, stamps;
   bool want_stamps = false;
   int last_nseg = 0, last_nframes = 0;   // geometry of the last encode call (entropy_bits)
@@ -1906,6 +1927,7 @@ int prepare_scan(sjpeg_hip_engine* e, const sjpeg_hip_source* src,
   a->tables = e->tables.p;
   a->seg_words = e->seg_words.p;
   a->spill = e->spill.p;
+  a->replay = nullptr;
   a->slot_words = g->slot_words;
   a->seg_nbits = e->seg_nbits.p;
   a->coeffs = nullptr;
@@ -1961,7 +1983,7 @@ int sjpeg_hip_engine_create(int device, sjpeg_hip_engine** engine) {
 void sjpeg_hip_engine_destroy(sjpeg_hip_engine* e) {
   if (e == nullptr) return;
   (void)hipSetDevice(e->device);
-  e->tables.release(); e->header.release(); e->seg_words.release(); e->seg_nbits.release(); e->spill.release();
+  e->tables.release(); e->header.release(); e->seg_words.release(); e->seg_nbits.release(); e->spill.release(); e->replay.release();
   e->ubuf.release(); e->chunk_ff.release(); e->partial.release(); e->seg_off.release(); e->chunk_off.release();
   for (auto& ev : e->ev) if (ev) (void)hipEventDestroy(ev);
   delete e;
@@ -2043,6 +2065,11 @@ static int scan_statistics(sjpeg_hip_engine* e, const sjpeg_hip_source* src, int
   const int words = histogram ? kHistoWords : kStatsWords;
   if ((rc = e->partial.ensure(static_cast<size_t>(nframes) * g.nseg * words))) return rc;
   a.partial = e->partial.p;
+  if (!histogram && (tables->flags & SJPEG_HIP_QUANT_KEEP)) {
+    if ((rc = e->replay.ensure(static_cast<size_t>(nframes) * g.nseg * kScanThreads * 36))) return rc;
+    a.replay = e->replay.p;
+    e->replay_w = width; e->replay_h = height; e->replay_mode = yuv_mode; e->replay_nframes = nframes;
+  }
   if (histogram) rc = launch_scan<kKindHisto>(yuv_mode, cls, dim3(g.nseg, nframes), st, a);
   else if (tables != nullptr && (tables->flags & SJPEG_HIP_QUANT_TRELLIS)) rc = launch_scan<kKindStatsTrellis>(yuv_mode, cls, dim3(g.nseg, nframes), st, a);
   else rc = launch_scan<kKindStats>(yuv_mode, cls, dim3(g.nseg, nframes), st, a);
@@ -2168,8 +2195,19 @@ int sjpeg_hip_encode_scan_src(sjpeg_hip_engine* e, const sjpeg_hip_source* src, 
   s.seg_nbits64 = nullptr; s.total_bits_out = nullptr; s.subs = 1;
 
   if (e->timing) HIP_TRY(hipEventRecord(e->ev[0], st));
-  if (tables->flags & SJPEG_HIP_QUANT_TRELLIS) rc = launch_scan<kKindEncodeTrellis>(yuv_mode, cls, dim3(g.nseg, nframes), st, a);
-  else rc = launch_scan<kKindEncode>(yuv_mode, cls, dim3(g.nseg, nframes), st, a);
+  if (tables->flags & SJPEG_HIP_QUANT_REPLAY) {
+    if (e->replay.p == nullptr || e->replay_w != width || e->replay_h != height || e->replay_mode != yuv_mode ||
+        e->replay_nframes != nframes) {
+      return fail(SJPEG_HIP_EINVAL, "SJPEG_HIP_QUANT_REPLAY: no kept coefficients of this geometry "
+                                    "(run the statistics pass with SJPEG_HIP_QUANT_KEEP first)");
+    }
+    a.replay = e->replay.p;
+    rc = launch_scan<kKindEncodeReplay>(yuv_mode, cls, dim3(g.nseg, nframes), st, a);
+  } else if (tables->flags & SJPEG_HIP_QUANT_TRELLIS) {
+    rc = launch_scan<kKindEncodeTrellis>(yuv_mode, cls, dim3(g.nseg, nframes), st, a);
+  } else {
+    rc = launch_scan<kKindEncode>(yuv_mode, cls, dim3(g.nseg, nframes), st, a);
+  }
   if (rc) return rc;
   if (e->timing) HIP_TRY(hipEventRecord(e->ev[1], st));
 

@@ -595,3 +595,35 @@ def test_adaptive_analysis_on_device_equals_host(engine):
                     t_dev, q_dev = sj.adapt_quant_device(hist_dev, mode, quant, mq, 0x78, dl, dc)
                     assert np.array_equal(q_host, q_dev), (w, h, mode, q, dl, dc)
                     assert bytes(t_host) == bytes(t_dev)
+
+
+def test_keep_and_replay_flags(oracle):
+    """SJPEG_HIP_QUANT_KEEP / REPLAY: the statistics pass leaves its quantized blocks behind and the
+    encode pass entropy-codes them without touching the pixels again (plain and trellis)."""
+    eng = sj.Engine(0)
+    for (w, h, mode, q) in ((333, 211, 1, 75.0), (640, 360, 3, 90.0), (97, 61, 4, 40.0)):
+        img = synth.g_struct(w, h, 4)
+        frames = dev(img)
+        for trellis in (False, True):
+            tables, quant = sj.make_tables(quality=q)
+            if trellis:
+                tables.flags = sj.QUANT_TRELLIS
+                for c in range(2):
+                    for i in range(256):
+                        tables.trellis_len[c][i] = tables.ac_codes[c][i] & 0xff
+            header = sj.make_header(w, h, mode, quant)
+            plain = eng.encode_frames(frames, tables, header, mode)
+            want = bytes(plain[0][0, :int(plain[1][0].item())].cpu().numpy())
+            if not trellis:
+                assert want == oracle.encode(img, q, mode)
+            tables.flags |= sj.QUANT_KEEP
+            eng.scan_symbol_stats(frames, tables, mode)
+            tables.flags = (tables.flags & ~sj.QUANT_KEEP) | sj.QUANT_REPLAY
+            out, sizes = eng.encode_frames(torch.zeros_like(frames), tables, header, mode)   # pixels are not read
+            assert bytes(out[0, :int(sizes[0].item())].cpu().numpy()) == want, (w, h, mode, trellis)
+    fresh = sj.Engine(0)
+    tables, quant = sj.make_tables(quality=75.0)
+    tables.flags = sj.QUANT_REPLAY
+    with pytest.raises(sj.SjpegError):
+        fresh.encode_frames(dev(synth.g_struct(32, 32, 1)), tables, b"", 1)
+    torch.cuda.synchronize()
