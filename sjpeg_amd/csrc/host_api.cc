@@ -480,8 +480,12 @@ bool Encoder::Run() {
         HuffSpec popt[4];
         uint32_t freq[2][272];
         if (optimize) {
-          if (trellis) memcpy(pass_rate, tables.trellis_len, sizeof(pass_rate));   // what this pass is priced with
+          if (trellis) {                             // what this pass is priced with; its blocks stay for a replay
+            memcpy(pass_rate, tables.trellis_len, sizeof(pass_rate));
+            tables.flags |= SJPEG_HIP_QUANT_KEEP;
+          }
           if (!symbol_stats(freq)) return false;
+          tables.flags &= ~SJPEG_HIP_QUANT_KEEP;
           for (int t = 0; t < ntables; ++t) {
             sjpeg_host::BuildOptimalSpec(freq[t] + 256, 12, &popt[t]);
             sjpeg_host::BuildOptimalSpec(freq[t], 256, &popt[2 + t]);
@@ -592,6 +596,7 @@ bool Encoder::Run() {
   bool replay = false;                              // trellis: the statistics pass keeps its blocks, the encode pass replays them
   if (final_tables_known) {
     for (int t = 0; t < ntables; ++t) { dc[t] = &pass_specs[t]; ac[t] = &pass_specs[2 + t]; }
+    replay = true;                                  // the last pass' blocks are still in the engine
   } else if (optimize) {
     // statistics half of SinglePassScanOptimized on the GPU (src/enc.cc:323-372),
     // CompileEntropyStats on the host (src/entropy.cc:432-444)
