@@ -627,3 +627,22 @@ def test_keep_and_replay_flags(oracle):
     with pytest.raises(sj.SjpegError):
         fresh.encode_frames(dev(synth.g_struct(32, 32, 1)), tables, b"", 1)
     torch.cuda.synchronize()
+
+
+def test_sharp_and_auto_with_padded_and_bottom_up_rows(oracle, risk_table):
+    """Row padding must not leak and a bottom-up picture equals the flipped one, also through the
+    sharp conversion and the riskiness stencil (reference tests/unit_test.cc:246-342 idea)."""
+    img = synth.g_struct(61, 45, 15)
+    lib = sj.lib()
+    for mode in (sj.YUV_SHARP, sj.YUV_AUTO):
+        want = sj.SjpegEncode(img, 80.0, 4, mode)
+        eff = 2 if mode == sj.YUV_SHARP else oracle.riskiness(img, risk_table)[0]
+        assert want == oracle.encode_method(img, 80.0, eff, 4)
+        padded = np.full((45, 61 * 3 + 13), 0x5C, np.uint8)
+        padded[:, :183] = img.reshape(45, 183)
+        out = C.POINTER(C.c_uint8)()
+        n = lib.SjpegEncode(padded.ctypes.data, 61, 45, padded.strides[0], C.byref(out), C.c_float(80.0), 4, mode)
+        assert C.string_at(out, n) == want
+        lib.SjpegFreeBuffer(out)
+        flipped = img[::-1].copy()
+        assert sj.SjpegEncode(flipped, 80.0, 4, mode, stride=-flipped.strides[0]) == want
