@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SJPEG_HIP_ABI_VERSION 8
+#define SJPEG_HIP_ABI_VERSION 9
 
 enum {
   SJPEG_HIP_OK = 0,
@@ -272,6 +272,23 @@ int sjpeg_hip_scan_symbol_stats_src(sjpeg_hip_engine* engine, const sjpeg_hip_so
                                     int width, int height, int yuv_mode, int nframes,
                                     const sjpeg_hip_scan_tables* tables, uint32_t* d_freq,
                                     void* stream);
+
+/* A batch whose frames each carry their OWN tables and header -- what a batch of the reference's
+ * default encodes is (method 4: per-image adapted quantizer and per-image optimised Huffman
+ * codes, src/enc.cc:801-812 + 323-372, one Encoder per image there, one launch here).
+ * tables[nframes] (host); headers = the frames' header bytes back to back (host), frame f owns
+ * [header_offsets[f], header_offsets[f+1]); flags must agree between the frames.  The rest as
+ * sjpeg_hip_encode_scan_src() / sjpeg_hip_scan_symbol_stats_src(). */
+int sjpeg_hip_encode_scan_multi(sjpeg_hip_engine* engine, const sjpeg_hip_source* src,
+                                int width, int height, int yuv_mode, int nframes,
+                                const sjpeg_hip_scan_tables* tables /*[nframes]*/,
+                                const void* headers, const size_t* header_offsets /*[nframes+1]*/,
+                                int append_eoi, void* d_out, size_t out_stride, uint64_t* d_sizes,
+                                void* stream);
+int sjpeg_hip_scan_symbol_stats_multi(sjpeg_hip_engine* engine, const sjpeg_hip_source* src,
+                                      int width, int height, int yuv_mode, int nframes,
+                                      const sjpeg_hip_scan_tables* tables /*[nframes]*/,
+                                      uint32_t* d_freq, void* stream);
 
 /* ---- host-side helpers (tiny CPU work, no device needed) -----------------------------
  * They produce exactly what the reference's host code would hand to its hot loop, so that

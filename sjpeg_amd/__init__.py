@@ -182,6 +182,19 @@ def lib() -> C.CDLL:
                                             C.POINTER(ScanTables), C.c_void_p, C.c_void_p]
     L.sjpeg_hip_scan_histogram_src.argtypes = [C.c_void_p, srcp, C.c_int, C.c_int, C.c_int, C.c_int,
                                                C.c_void_p, C.c_void_p]
+    L.sjpeg_hip_adapt_sums.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_void_p]
+    L.sjpeg_hip_adapt_sums.restype = C.c_int
+    L.sjpeg_hip_adapt_quant_sums.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                             C.c_int, C.c_int, C.c_void_p]
+    L.sjpeg_hip_adapt_quant_sums.restype = None
+    L.sjpeg_hip_encode_scan_multi.argtypes = [C.c_void_p, srcp, C.c_int, C.c_int, C.c_int, C.c_int,
+                                              C.c_void_p, C.c_char_p, C.POINTER(C.c_size_t), C.c_int,
+                                              C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    L.sjpeg_hip_encode_scan_multi.restype = C.c_int
+    L.sjpeg_hip_scan_symbol_stats_multi.argtypes = [C.c_void_p, srcp, C.c_int, C.c_int, C.c_int, C.c_int,
+                                                    C.c_void_p, C.c_void_p, C.c_void_p]
+    L.sjpeg_hip_scan_symbol_stats_multi.restype = C.c_int
     L.sjpeg_hip_scan_symbol_stats_src.argtypes = [C.c_void_p, srcp, C.c_int, C.c_int, C.c_int, C.c_int,
                                                   C.POINTER(ScanTables), C.c_void_p, C.c_void_p]
     L.sjpeg_hip_scan_quant_error_src.argtypes = [C.c_void_p, srcp, C.c_int, C.c_int, C.c_int, C.c_int,
@@ -223,6 +236,7 @@ EXPORTED_C_SYMBOLS = [
     "sjpeg_hip_adapt_sums", "sjpeg_hip_adapt_quant_sums",
     "sjpeg_hip_encode_scan_src", "sjpeg_hip_scan_coeffs_src", "sjpeg_hip_scan_histogram_src",
     "sjpeg_hip_scan_symbol_stats_src", "sjpeg_hip_scan_quant_error_src", "sjpeg_hip_engine_entropy_bits",
+    "sjpeg_hip_encode_scan_multi", "sjpeg_hip_scan_symbol_stats_multi",
     "sjpeg_hip_optimize_huffman", "sjpeg_hip_make_header_ex", "sjpeg_hip_make_header_meta",
     "sjpeg_hip_sharp_workspace", "sjpeg_hip_sharp_yuv",
     "sjpeg_hip_set_riskiness_table", "sjpeg_hip_has_riskiness_table", "sjpeg_hip_riskiness_sums",
@@ -330,32 +344,41 @@ def adapt_quant(hist: np.ndarray, yuv_mode, quant, min_quant=None, q_bias=0x78, 
     return t, q
 
 
-def adapt_quant_device(hist_dev, yuv_mode, quant, min_quant=None, q_bias=0x78, dmax_luma=12, dmax_chroma=1):
-    """The same with the bin loops on the GPU: hist_dev = CUDA int32 tensor [2, 64, 128] of ONE frame
-    (Engine.scan_histogram()[f]); sums come back (52 KB), the float half runs on the host."""
+def adapt_quant_device_batch(hists_dev, yuv_mode, quant, min_quant=None, q_bias=0x78, dmax_luma=12,
+                             dmax_chroma=1):
+    """AnalyseHisto for a batch with the bin loops on the GPU: hists_dev = CUDA int32 tensor
+    [F, 2, 64, 128] (Engine.scan_histogram()); ONE launch, the sums come back (52 KB per frame),
+    the float half runs on the host per frame.  Returns [(ScanTables, quant[2][64])] * F."""
     import torch
-    q = np.ascontiguousarray(quant, np.uint8).reshape(2, 64).copy()
+    q0 = np.ascontiguousarray(quant, np.uint8).reshape(2, 64).copy()
     mq = None if min_quant is None else np.ascontiguousarray(min_quant, np.uint8).reshape(2, 64)
-    sums = torch.zeros((2, 64, 25, 2), dtype=torch.int64, device=hist_dev.device)
-    totlast = torch.zeros((2, 64, 2), dtype=torch.int32, device=hist_dev.device)
+    mqp = mq.ctypes.data if mq is not None else None
+    f = hists_dev.shape[0]
+    sums = torch.zeros((f, 2, 64, 25, 2), dtype=torch.int64, device=hists_dev.device)
+    totlast = torch.zeros((f, 2, 64, 2), dtype=torch.int32, device=hists_dev.device)
     L = lib()
-    L.sjpeg_hip_adapt_sums.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
-    rc = L.sjpeg_hip_adapt_sums(hist_dev.contiguous().data_ptr(), 1, q.ctypes.data,
-                                mq.ctypes.data if mq is not None else None, sums.data_ptr(), totlast.data_ptr(),
-                                torch.cuda.current_stream().cuda_stream)
+    rc = L.sjpeg_hip_adapt_sums(hists_dev.contiguous().data_ptr(), f, q0.ctypes.data, mqp, sums.data_ptr(),
+                                totlast.data_ptr(), torch.cuda.current_stream().cuda_stream)
     if rc != 0:
         raise SjpegError("sjpeg_hip_adapt_sums: " + L.sjpeg_hip_last_error().decode())
     s_host = np.ascontiguousarray(sums.cpu().numpy())
     t_host = np.ascontiguousarray(totlast.cpu().numpy())
-    t = ScanTables()
-    L.sjpeg_hip_finalize_quant(q.ctypes.data, mq.ctypes.data if mq is not None else None, q_bias, C.byref(t))
-    L.sjpeg_hip_adapt_quant_sums.restype = None
-    L.sjpeg_hip_adapt_quant_sums.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
-                                             C.c_int, C.c_void_p]
-    L.sjpeg_hip_adapt_quant_sums(s_host.ctypes.data, t_host.ctypes.data, yuv_mode, q.ctypes.data,
-                                 mq.ctypes.data if mq is not None else None, q_bias, dmax_luma, dmax_chroma, C.byref(t))
-    L.sjpeg_hip_default_huffman(C.byref(t))
-    return t, q
+    res = []
+    for k in range(f):
+        q = q0.copy()
+        t = ScanTables()
+        L.sjpeg_hip_finalize_quant(q.ctypes.data, mqp, q_bias, C.byref(t))
+        L.sjpeg_hip_adapt_quant_sums(s_host[k].ctypes.data, t_host[k].ctypes.data, yuv_mode, q.ctypes.data, mqp,
+                                     q_bias, dmax_luma, dmax_chroma, C.byref(t))
+        L.sjpeg_hip_default_huffman(C.byref(t))
+        res.append((t, q))
+    return res
+
+
+def adapt_quant_device(hist_dev, yuv_mode, quant, min_quant=None, q_bias=0x78, dmax_luma=12, dmax_chroma=1):
+    """One frame of adapt_quant_device_batch(): hist_dev = CUDA int32 tensor [2, 64, 128]."""
+    return adapt_quant_device_batch(hist_dev.unsqueeze(0), yuv_mode, quant, min_quant, q_bias, dmax_luma,
+                                    dmax_chroma)[0]
 
 
 def optimize_huffman(freq: np.ndarray, yuv_mode, tables: ScanTables):
@@ -497,6 +520,38 @@ class Engine:
                   "sjpeg_hip_scan_symbol_stats_src")
         return out
 
+    def encode_source_multi(self, src: Source, nframes, w, h, tables_list, headers, yuv_mode,
+                            out_stride=None, append_eoi=True, device="cuda"):
+        """Frame f is coded with tables_list[f] and gets headers[f] in front (one launch)."""
+        import torch
+        assert len(tables_list) == nframes and len(headers) == nframes
+        arr = (ScanTables * nframes)(*tables_list)
+        offs = (C.c_size_t * (nframes + 1))()
+        for i, hd in enumerate(headers):
+            offs[i + 1] = offs[i] + len(hd)
+        blob = b"".join(headers)
+        if out_stride is None:
+            out_stride = frame_bound(w, h, yuv_mode, max(len(hd) for hd in headers))
+        out = torch.empty((nframes, out_stride), dtype=torch.uint8, device=device)
+        sizes = torch.zeros(nframes, dtype=torch.int64, device=device)
+        self._chk(lib().sjpeg_hip_encode_scan_multi(self._h, C.byref(src), w, h, yuv_mode, nframes,
+                                                    C.cast(arr, C.c_void_p), blob, offs, int(append_eoi),
+                                                    out.data_ptr(), out_stride, sizes.data_ptr(),
+                                                    self._stream()),
+                  "sjpeg_hip_encode_scan_multi")
+        return out, sizes
+
+    def scan_symbol_stats_multi(self, src: Source, nframes, w, h, tables_list, yuv_mode, device="cuda"):
+        import torch
+        assert len(tables_list) == nframes
+        arr = (ScanTables * nframes)(*tables_list)
+        out = torch.zeros((nframes, 2, 272), dtype=torch.int32, device=device)
+        self._chk(lib().sjpeg_hip_scan_symbol_stats_multi(self._h, C.byref(src), w, h, yuv_mode, nframes,
+                                                          C.cast(arr, C.c_void_p), out.data_ptr(),
+                                                          self._stream()),
+                  "sjpeg_hip_scan_symbol_stats_multi")
+        return out
+
     def scan_quant_error_source(self, src: Source, nframes, w, h, tables, yuv_mode, device="cuda"):
         import torch
         out = torch.zeros(nframes, dtype=torch.int64, device=device)
@@ -585,32 +640,51 @@ class Engine:
 
 def encode_device_method(frames, quality=75.0, yuv_mode=YUV_420, method=4, engine=None, quant=None,
                          min_quant=None, q_bias=0x78, dmax_luma=12, dmax_chroma=1):
-    """Per-frame adaptive quantization / optimised Huffman tables (reference methods 0..6) for
-    device-resident frames, driven through the C-ABI exactly like the C++ host API does:
-    GPU statistics passes + host analysis + GPU encode.  Returns a list of JPEG byte strings."""
+    """Per-frame adaptive quantization / optimised Huffman tables (reference methods 0..6) for a
+    batch of device-resident frames, driven through the C-ABI: every device pass is ONE launch
+    over the whole batch (histograms; symbol statistics and encode with per-frame tables and
+    headers), the per-frame analysis between them is the reference's host code.  Returns a list
+    of JPEG byte strings."""
     import torch
     eng = engine or Engine(frames.device.index or 0)
     method = max(0, min(int(method), 8))
     if method >= 7:
-        raise SjpegError("trellis methods are not available")
+        raise SjpegError("trellis methods: use the host API (SjpegEncode / sjpeg::Encode)")
     adaptive, optimize = method >= 3, method not in (0, 3)
     f, h, w, _ = frames.shape
-    out_frames = []
-    hists = eng.scan_histogram(frames, yuv_mode).cpu().numpy().view(np.uint32) if adaptive else None
-    for k in range(f):
-        one = frames[k:k + 1]
-        tables, q = make_tables(quality=quality, quant=quant, min_quant=min_quant, q_bias=q_bias)
-        if adaptive:
-            tables, q = adapt_quant(hists[k], yuv_mode, q, min_quant, q_bias, dmax_luma, dmax_chroma)
-        specs = None
-        if optimize:
-            freq = eng.scan_symbol_stats(one, tables, yuv_mode).cpu().numpy().view(np.uint32)[0]
-            specs = optimize_huffman(freq, yuv_mode, tables)
-        header = make_header_ex(w, h, yuv_mode, q, specs)
-        out, sizes = eng.encode_frames(one, tables, header, yuv_mode)
-        torch.cuda.synchronize()
-        out_frames.append(bytes(out[0, :int(sizes[0])].cpu().numpy()))
-    return out_frames
+    assert frames.stride(3) == 1 and frames.stride(2) == 3
+    rows = frames.as_strided((f, h, w * 3), (frames.stride(0), frames.stride(1), 1))
+    src, _ = make_source(SRC_RGB, [rows])
+    base, q0 = make_tables(quality=quality, quant=quant, min_quant=min_quant, q_bias=q_bias)
+    tabs, quants = [base] * f, [q0] * f
+    if adaptive:
+        pairs = adapt_quant_device_batch(eng.scan_histogram(frames, yuv_mode), yuv_mode, q0, min_quant, q_bias,
+                                         dmax_luma, dmax_chroma)
+        tabs, quants = [p[0] for p in pairs], [p[1] for p in pairs]
+    specs = [None] * f
+    if optimize:
+        freq = eng.scan_symbol_stats_multi(src, f, w, h, tabs, yuv_mode,
+                                           device=frames.device).cpu().numpy().view(np.uint32)
+        if tabs[0] is base:                       # optimize_huffman writes the codes into its tables
+            tabs = [ScanTables.from_buffer_copy(base) for _ in range(f)]
+        specs = [optimize_huffman(freq[k], yuv_mode, tabs[k]) for k in range(f)]
+    headers = [make_header_ex(w, h, yuv_mode, quants[k], specs[k]) for k in range(f)]
+    out, sizes = eng.encode_source_multi(src, f, w, h, tabs, headers, yuv_mode, device=frames.device)
+    return _fetch_frames(out, sizes)
+
+
+def _fetch_frames(out, sizes):
+    """The batch's JPEGs as byte strings: the used part of every slot, one pinned staging buffer,
+    one synchronisation."""
+    import torch
+    sz = sizes.cpu().numpy()
+    offs = np.concatenate([[0], np.cumsum(sz)]).astype(np.int64)
+    stage = torch.empty(int(offs[-1]), dtype=torch.uint8, pin_memory=True)
+    for k in range(len(sz)):
+        stage[int(offs[k]):int(offs[k + 1])].copy_(out[k, :int(sz[k])], non_blocking=True)
+    torch.cuda.synchronize()
+    host = stage.numpy()
+    return [host[int(offs[k]):int(offs[k + 1])].tobytes() for k in range(len(sz))]
 
 
 def encode_source_method(fmt, planes, w, h, quality=75.0, yuv_mode=YUV_420, method=0, engine=None,
@@ -646,6 +720,4 @@ def encode_device(frames, quality=75.0, yuv_mode=YUV_420, engine=None, quant=Non
     f, h, w, _ = frames.shape
     header = make_header(w, h, yuv_mode, q)
     out, sizes = eng.encode_frames(frames, tables, header, yuv_mode)
-    torch.cuda.synchronize()
-    sz = sizes.cpu().numpy()
-    return [bytes(out[i, :int(sz[i])].cpu().numpy()) for i in range(f)]
+    return _fetch_frames(out, sizes)

@@ -38,6 +38,7 @@
 
 #include <new>
 #include <string>
+#include <vector>
 
 #include "sjpeg_hip.h"
 
@@ -85,6 +86,7 @@ struct ScanArgs {
   int W, H, mb_w, n_mcus, nseg, has_clip;
   int seg_first;                // band mode: frame-level index of this launch's segment 0
   const DevTables* tables;
+  int tables_stride;            // 0: every frame uses tables[0]; 1: frame f uses tables[f]
   uint32_t* seg_words;     // [nframes*nseg][slot_words]
   uint32_t slot_words;
   uint32_t* seg_nbits;     // [nframes*nseg]
@@ -571,7 +573,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
 
   // tables -> LDS; issued once the first pixel loads are in flight (see P1)
   auto stage_tables = [&]() {
-    const DevTables* t = a.tables;
+    const DevTables* t = a.tables + frame * a.tables_stride;
     if (tid < 64) lq[tid] = (&t->q[0][0])[tid];
     for (int i = tid; i < 512; i += kScanThreads) lac[i] = (&t->ac[0][0])[i];
     if (tid < 24) ldc[tid] = (&t->dc[0][0])[tid];
@@ -1478,6 +1480,7 @@ struct StitchArgs {
   uint32_t max_chunks;
   const uint8_t* header;
   uint32_t header_size;
+  const uint32_t* hdr_off;           // per-frame headers: frame f owns header[hdr_off[f] .. hdr_off[f+1]) (else NULL: one for all)
   int append_eoi;
   uint8_t* out;
   size_t out_stride;
@@ -1655,19 +1658,21 @@ __global__ __launch_bounds__(kThreads) void scan_chunk_offsets(const StitchArgs 
   }
   // a frame that does not fit the caller's slot reports size 0 and is not written
   const unsigned long long body = U + running;
-  const unsigned long long size = a.header_size + body + (a.append_eoi ? 2 : 0);
+  const uint32_t hoff = a.hdr_off ? a.hdr_off[frame] : 0u;
+  const uint32_t hsize = a.hdr_off ? a.hdr_off[frame + 1] - hoff : a.header_size;
+  const unsigned long long size = hsize + body + (a.append_eoi ? 2 : 0);
   const bool fits = size <= a.out_stride;
   uint8_t* dst = a.out + static_cast<size_t>(frame) * a.out_stride;
   if (threadIdx.x == 0) {
     if (fits && a.append_eoi) {
-      dst[a.header_size + body] = 0xff;
-      dst[a.header_size + body + 1] = 0xd9;
+      dst[hsize + body] = 0xff;
+      dst[hsize + body + 1] = 0xd9;
     }
     a.sizes[frame] = fits ? size : 0ull;
   }
   // header bytes in front of the entropy segment
   if (fits) {
-    for (uint32_t i = threadIdx.x; i < a.header_size; i += kThreads) dst[i] = a.header[i];
+    for (uint32_t i = threadIdx.x; i < hsize; i += kThreads) dst[i] = a.header[hoff + i];
   }
 }
 
@@ -1685,7 +1690,8 @@ __global__ __launch_bounds__(kThreads) void stuff_chunks(const StitchArgs a) {
   const uint32_t nchunks = static_cast<uint32_t>((U + kChunkBytes - 1) / kChunkBytes);
   const uint32_t* ub = a.ubuf + static_cast<size_t>(frame) * a.ubuf_words;
   const unsigned long long* co = a.chunk_off + static_cast<size_t>(frame) * a.max_chunks;
-  uint8_t* const dst0 = a.out + static_cast<size_t>(frame) * a.out_stride + a.header_size;
+  const uint32_t hsize = a.hdr_off ? a.hdr_off[frame + 1] - a.hdr_off[frame] : a.header_size;
+  uint8_t* const dst0 = a.out + static_cast<size_t>(frame) * a.out_stride + hsize;
   if (a.sizes[frame] == 0) return;                          // did not fit (see K4)
   for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
     const unsigned long long w0 = static_cast<unsigned long long>(chunk) * kChunkWords + threadIdx.x * 4;
@@ -1802,6 +1808,7 @@ struct sjpeg_hip_engine {
   DevBuf<uint32_t> seg_words, seg_nbits, spill, ubuf, chunk_ff, partial, replay;
   int replay_w = 0, replay_h = 0, replay_mode = 0, replay_nframes = 0;   // what `replay` holds (0 = nothing)
   DevBuf<unsigned long long> seg_off, chunk_off, stamps;
+  DevBuf<uint32_t> hdr_off;
   bool want_stamps = false;
   int last_nseg = 0, last_nframes = 0;   // geometry of the last encode call (entropy_bits)
   size_t stamps_n = 0;
@@ -1865,7 +1872,7 @@ sjpeg_hip_source rgb_source(const void* d_rgb, int64_t row_stride, int64_t frame
 
 int prepare_scan(sjpeg_hip_engine* e, const sjpeg_hip_source* src,
                  int W, int H, int mode, int nframes, const sjpeg_hip_scan_tables* tables,
-                 hipStream_t st, FrameGeo* g, ScanArgs* a, int* src_class) {
+                 hipStream_t st, FrameGeo* g, ScanArgs* a, int* src_class, bool per_frame_tables = false) {
   if (e == nullptr || src == nullptr || src->plane[0] == nullptr || tables == nullptr || nframes <= 0) {
     return fail(SJPEG_HIP_EINVAL, "null argument or nframes <= 0");
   }
@@ -1913,18 +1920,23 @@ int prepare_scan(sjpeg_hip_engine* e, const sjpeg_hip_source* src,
   if (nframes > 65535) return fail(SJPEG_HIP_EINVAL, "nframes > 65535");
   HIP_TRY(hipSetDevice(e->device));
   int rc;
-  if ((rc = e->tables.ensure(1))) return rc;
+  const int ntab = per_frame_tables ? nframes : 1;
+  if ((rc = e->tables.ensure(ntab))) return rc;
   const size_t total_segs = static_cast<size_t>(nframes) * g->nseg;
   if ((rc = e->seg_words.ensure(total_segs * g->slot_words))) return rc;
   if ((rc = e->seg_nbits.ensure(total_segs))) return rc;
   if ((rc = e->spill.ensure(total_segs * kScanThreads * kSpillWords))) return rc;
-  DevTables host_tables;
-  digest_tables(tables, &host_tables);
-  HIP_TRY(hipMemcpyAsync(e->tables.p, &host_tables, sizeof(DevTables), hipMemcpyHostToDevice, st));
+  {
+    // (pageable source: the copy has left the host buffer when the call returns)
+    std::vector<DevTables> host_tables(ntab);
+    for (int i = 0; i < ntab; ++i) digest_tables(tables + i, &host_tables[i]);
+    HIP_TRY(hipMemcpyAsync(e->tables.p, host_tables.data(), sizeof(DevTables) * ntab, hipMemcpyHostToDevice, st));
+  }
   a->W = W; a->H = H; a->mb_w = g->mb_w; a->n_mcus = g->n_mcus; a->nseg = g->nseg;
   a->seg_first = 0;
   a->has_clip = (W % g->px != 0) || (H % g->px != 0);
   a->tables = e->tables.p;
+  a->tables_stride = per_frame_tables ? 1 : 0;
   a->seg_words = e->seg_words.p;
   a->spill = e->spill.p;
   a->replay = nullptr;
@@ -1984,7 +1996,7 @@ void sjpeg_hip_engine_destroy(sjpeg_hip_engine* e) {
   if (e == nullptr) return;
   (void)hipSetDevice(e->device);
   e->tables.release(); e->header.release(); e->seg_words.release(); e->seg_nbits.release(); e->spill.release(); e->replay.release();
-  e->ubuf.release(); e->chunk_ff.release(); e->partial.release(); e->seg_off.release(); e->chunk_off.release();
+  e->ubuf.release(); e->chunk_ff.release(); e->partial.release(); e->seg_off.release(); e->chunk_off.release(); e->hdr_off.release();
   for (auto& ev : e->ev) if (ev) (void)hipEventDestroy(ev);
   delete e;
 }
@@ -2049,7 +2061,7 @@ int sjpeg_hip_scan_coeffs(sjpeg_hip_engine* e, const void* d_rgb, int64_t row_st
 
 static int scan_statistics(sjpeg_hip_engine* e, const sjpeg_hip_source* src, int width, int height,
                            int yuv_mode, int nframes, const sjpeg_hip_scan_tables* tables,
-                           bool histogram, uint32_t* d_out, void* stream) {
+                           bool histogram, uint32_t* d_out, void* stream, bool per_frame_tables = false) {
   if (d_out == nullptr) return fail(SJPEG_HIP_EINVAL, "output pointer == NULL");
   hipStream_t st = static_cast<hipStream_t>(stream);
   sjpeg_hip_scan_tables dummy;
@@ -2060,7 +2072,7 @@ static int scan_statistics(sjpeg_hip_engine* e, const sjpeg_hip_source* src, int
   FrameGeo g;
   ScanArgs a;
   int cls = 0;
-  int rc = prepare_scan(e, src, width, height, yuv_mode, nframes, tables, st, &g, &a, &cls);
+  int rc = prepare_scan(e, src, width, height, yuv_mode, nframes, tables, st, &g, &a, &cls, per_frame_tables);
   if (rc) return rc;
   const int words = histogram ? kHistoWords : kStatsWords;
   if ((rc = e->partial.ensure(static_cast<size_t>(nframes) * g.nseg * words))) return rc;
@@ -2155,19 +2167,40 @@ int sjpeg_hip_encode_scan(sjpeg_hip_engine* e, const void* d_rgb, int64_t row_st
                                    append_eoi, d_out, out_stride, d_sizes, stream);
 }
 
-int sjpeg_hip_encode_scan_src(sjpeg_hip_engine* e, const sjpeg_hip_source* src, int width, int height,
-                              int yuv_mode, int nframes, const sjpeg_hip_scan_tables* tables,
-                              const void* header, size_t header_size, int append_eoi, void* d_out,
-                              size_t out_stride, uint64_t* d_sizes, void* stream) {
+// header_offsets == NULL: one header (and one set of tables) for every frame; else per frame
+static int encode_scan_impl(sjpeg_hip_engine* e, const sjpeg_hip_source* src, int width, int height,
+                            int yuv_mode, int nframes, const sjpeg_hip_scan_tables* tables,
+                            const void* header, size_t header_size, const size_t* header_offsets,
+                            int append_eoi, void* d_out, size_t out_stride, uint64_t* d_sizes,
+                            void* stream) {
   if (d_out == nullptr || d_sizes == nullptr) return fail(SJPEG_HIP_EINVAL, "d_out/d_sizes == NULL");
   if (header == nullptr) header_size = 0;
+  const bool multi = header_offsets != nullptr;
   hipStream_t st = static_cast<hipStream_t>(stream);
   FrameGeo g;
   ScanArgs a;
   int cls = 0;
-  int rc = prepare_scan(e, src, width, height, yuv_mode, nframes, tables, st, &g, &a, &cls);
+  int rc = prepare_scan(e, src, width, height, yuv_mode, nframes, tables, st, &g, &a, &cls, multi);
   if (rc) return rc;
-  if (out_stride < header_size + 2 + 64) {
+  size_t largest_header = header_size;
+  if (multi) {
+    if (tables->flags & SJPEG_HIP_QUANT_REPLAY) {
+      for (int f = 1; f < nframes; ++f) if (!(tables[f].flags & SJPEG_HIP_QUANT_REPLAY)) return fail(SJPEG_HIP_EINVAL, "flags must agree between the frames' tables");
+    }
+    largest_header = 0;
+    std::vector<uint32_t> offs(static_cast<size_t>(nframes) + 1);
+    for (int f = 0; f <= nframes; ++f) {
+      if (header_offsets[f] > header_size || (f > 0 && header_offsets[f] < header_offsets[f - 1])) {
+        return fail(SJPEG_HIP_EINVAL, "header_offsets must ascend inside the header blob");
+      }
+      offs[f] = static_cast<uint32_t>(header_offsets[f]);
+      if (f > 0 && header_offsets[f] - header_offsets[f - 1] > largest_header) largest_header = header_offsets[f] - header_offsets[f - 1];
+    }
+    if ((rc = e->hdr_off.ensure(static_cast<size_t>(nframes) + 1))) return rc;
+    HIP_TRY(hipMemcpyAsync(e->hdr_off.p, offs.data(), offs.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+  }
+  header_size = header == nullptr ? 0 : header_size;
+  if (out_stride < largest_header + 2 + 64) {
     return fail(SJPEG_HIP_ECAPACITY, "out_stride " + std::to_string(out_stride) + " too small");
   }
   const size_t ubuf_words = (static_cast<size_t>(g.nseg) * g.slot_words + kChunkWords + 3) & ~size_t(3);
@@ -2193,6 +2226,7 @@ int sjpeg_hip_encode_scan_src(sjpeg_hip_engine* e, const sjpeg_hip_source* src, 
   s.out = static_cast<uint8_t*>(d_out); s.out_stride = out_stride;
   s.sizes = reinterpret_cast<unsigned long long*>(d_sizes);
   s.seg_nbits64 = nullptr; s.total_bits_out = nullptr; s.subs = 1;
+  s.hdr_off = multi ? e->hdr_off.p : nullptr;
 
   if (e->timing) HIP_TRY(hipEventRecord(e->ev[0], st));
   if (tables->flags & SJPEG_HIP_QUANT_REPLAY) {
@@ -2228,6 +2262,32 @@ int sjpeg_hip_encode_scan_src(sjpeg_hip_engine* e, const sjpeg_hip_source* src, 
     e->ev_valid = true;
   }
   return 0;
+}
+
+int sjpeg_hip_encode_scan_src(sjpeg_hip_engine* e, const sjpeg_hip_source* src, int width, int height,
+                              int yuv_mode, int nframes, const sjpeg_hip_scan_tables* tables,
+                              const void* header, size_t header_size, int append_eoi, void* d_out,
+                              size_t out_stride, uint64_t* d_sizes, void* stream) {
+  return encode_scan_impl(e, src, width, height, yuv_mode, nframes, tables, header, header_size, nullptr,
+                          append_eoi, d_out, out_stride, d_sizes, stream);
+}
+
+int sjpeg_hip_encode_scan_multi(sjpeg_hip_engine* e, const sjpeg_hip_source* src, int width, int height,
+                                int yuv_mode, int nframes, const sjpeg_hip_scan_tables* tables,
+                                const void* headers, const size_t* header_offsets, int append_eoi,
+                                void* d_out, size_t out_stride, uint64_t* d_sizes, void* stream) {
+  if (tables == nullptr || headers == nullptr || header_offsets == nullptr || nframes <= 0) {
+    return fail(SJPEG_HIP_EINVAL, "null argument or nframes <= 0");
+  }
+  return encode_scan_impl(e, src, width, height, yuv_mode, nframes, tables, headers, header_offsets[nframes],
+                          header_offsets, append_eoi, d_out, out_stride, d_sizes, stream);
+}
+
+int sjpeg_hip_scan_symbol_stats_multi(sjpeg_hip_engine* e, const sjpeg_hip_source* src, int width, int height,
+                                      int yuv_mode, int nframes, const sjpeg_hip_scan_tables* tables,
+                                      uint32_t* d_freq, void* stream) {
+  if (tables == nullptr) return fail(SJPEG_HIP_EINVAL, "tables == NULL");
+  return scan_statistics(e, src, width, height, yuv_mode, nframes, tables, false, d_freq, stream, true);
 }
 
 // ---- one frame over several GPUs: bands of consecutive segments ----------

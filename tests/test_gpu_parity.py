@@ -237,6 +237,43 @@ def test_methods_full_size_digests(engine, digests):
     assert hashlib.md5(host).hexdigest() == digests["struct4k|420|q75|m4"]["md5"]
 
 
+def test_methods_batched_per_frame_tables(engine, oracle):
+    """One launch per pass over a batch whose frames each get their own adapted quantizer,
+    optimised Huffman codes and header (sjpeg_hip_*_multi): every frame equals the reference's
+    single-image encode."""
+    rng = np.random.RandomState(4242)
+    for (w, h, mode) in ((321, 203, 1), (160, 96, 3), (75, 131, 4), (1, 1, 1)):
+        imgs = []
+        for k in range(7):                      # very different content => different tables per frame
+            if k % 3 == 0:
+                imgs.append(rng.randint(0, 256, (h, w, 3)).astype(np.uint8))
+            elif k % 3 == 1:
+                imgs.append(synth.g_struct(w, h, 1000 + k))
+            else:
+                imgs.append(np.full((h, w, 3), 37 * k, np.uint8))
+        frames = torch.from_numpy(np.stack(imgs)).cuda()
+        for m, q in ((1, 60.0), (3, 85.0), (4, 75.0), (6, 30.0), (0, 75.0)):
+            got = sj.encode_device_method(frames, q, mode, m, engine=engine)
+            for k in range(7):
+                assert got[k] == oracle.encode_method(imgs[k], q, mode, m), (w, h, mode, m, k)
+
+
+def test_multi_rejects_bad_header_offsets(engine):
+    import ctypes as C
+    frames = dev(synth.g_struct(64, 48))
+    rows = frames.view(1, 48, 64 * 3)
+    src, _ = sj.make_source(sj.SRC_RGB, [rows])
+    t, q = sj.make_tables(quality=75.0)
+    hdr = sj.make_header(64, 48, 1, q)
+    arr = (sj.ScanTables * 1)(t)
+    out = torch.empty((1, 65536), dtype=torch.uint8, device="cuda")
+    sizes = torch.zeros(1, dtype=torch.int64, device="cuda")
+    offs = (C.c_size_t * 2)(len(hdr), 0)        # descending
+    rc = sj.lib().sjpeg_hip_encode_scan_multi(engine._h, C.byref(src), 64, 48, 1, 1, C.cast(arr, C.c_void_p), hdr,
+                                             offs, 1, out.data_ptr(), 65536, sizes.data_ptr(), None)
+    assert rc != 0 and "header_offsets" in sj.lib().sjpeg_hip_last_error().decode()
+
+
 def test_c5_recompress_default_params(engine, digests):
     d = digests["recompress|r90|default"]
     src = np.array(digests["recompress|r90|m0"]["source_quant"], np.uint8).reshape(2, 64)
