@@ -1045,6 +1045,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
   // (sort bookkeeping that aliases nothing still in use is cleared under the same barrier)
   if (KIND == kKindEncode) {
     if (tid < 32) win[kSortHist + tid] = 0;
+    if (tid == 32) misc[10] = 0;                   // the queue of part groups (P3)
     *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(win + 64 + 512) + 4 * tid) = make_uint2(0u, 0u);
   }
   __syncthreads();
@@ -1150,7 +1151,6 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
   }
   stamp(3);
   const uint32_t n_units = misc[9];
-  const int n_rounds = static_cast<int>((n_units + kScanThreads - 1) / kScanThreads);   // <= 4
 
   // the walk reads 16-bit entries and writes 32-bit words in the same slot: no type-based reordering
   typedef uint16_t __attribute__((may_alias)) u16_alias;
@@ -1253,8 +1253,16 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
   // (four registers picked by the round counter: one copy of the walk for all rounds)
   uint32_t ur0 = 0xffffffffu, ur1 = 0xffffffffu, ur2 = 0xffffffffu, ur3 = 0xffffffffu;
   auto ur_get = [&](int r) { return r == 0 ? ur0 : r == 1 ? ur1 : r == 2 ? ur2 : ur3; };
-  for (int r = 0; r < n_rounds; ++r) {
-    const uint32_t idx = static_cast<uint32_t>(r) * kScanThreads + tid;
+  // The list is sorted: handed out in order, wave 0's 64 parts would be the heaviest of every
+  // round and its SIMD the busiest of the CU.  The waves draw groups of 64 parts from a queue
+  // instead (heaviest first, at most four each: 4 x 4 covers the 16 groups of a full segment).
+  const uint32_t n_groups = (n_units + 63u) >> 6;
+  for (int r = 0; r < 4; ++r) {
+    uint32_t grp = 0;
+    if ((tid & 63) == 0) grp = atomicAdd(&misc[10], 1u);
+    grp = __builtin_amdgcn_readfirstlane(grp);
+    if (grp >= n_groups) break;
+    const uint32_t idx = grp * 64u + (tid & 63u);
     if (idx < n_units) {
       const uint32_t unit = ulist[idx];
       uint32_t len, wsp;
@@ -1354,7 +1362,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
     const uint32_t limit = all_fit ? total : misc[8];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      if (r < n_rounds && (fits & (1u << r)) && us_get(r) < limit) {
+      if ((fits & (1u << r)) && us_get(r) < limit) {
         place(ur_get(r), us_get(r));
         pending &= ~(1u << r);
       }
