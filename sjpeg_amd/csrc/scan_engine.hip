@@ -44,1709 +44,10 @@
 
 namespace {
 
-// ------------------------------------------------------------------------------------
-// geometry
-
-constexpr int kThreads = 256;        // stitch kernels (K2..K5): 4 waves
-constexpr int kScanThreads = 256;    // K1: 4 waves = 41 coded MCUs + 1 halo MCU in 4:2:0
-constexpr int kSlotBytes = 144;      // 64 int16 + 16 B pad: conflict-free ds_read_b128 per lane
-constexpr int kWinWords = 2048;       // LDS bit window, 32-bit MSB-first words (8 KiB)
-constexpr int kSpillWords = 64;      // per block: 16 words for each of the four parts (<= 496 bits)
-constexpr int kMaxBlockBits = 1728;  // 22 (DC) + 63*27 (AC) rounded up; reference bound enc.cc:206-209
-constexpr int kChunkWords = 1024;    // K3/K5 chunk: 4 KiB of un-stuffed stream
-constexpr int kChunkBytes = kChunkWords * 4;
-
-template <int MODE> struct Geo;
-template <> struct Geo<SJPEG_HIP_YUV420> {
-  static constexpr int kBpm = 6, kMcuPx = 16, kSegMcus = 41;    // (41 + 1 halo) * 6 = 252 threads
-};
-template <> struct Geo<SJPEG_HIP_YUV444> {
-  static constexpr int kBpm = 3, kMcuPx = 8, kSegMcus = 84;     // 85 * 3 = 255
-};
-template <> struct Geo<SJPEG_HIP_YUV400> {
-  static constexpr int kBpm = 1, kMcuPx = 8, kSegMcus = 255;    // 256
-};
-
-// device copy of sjpeg_hip_scan_tables, pre-digested
-struct DevTables {
-  uint4 q[2][32];          // per natural-order PAIR (2j, 2j+1): {iq0 | iq1<<16, bias0*iq0, bias1*iq1, q0 | q1<<16}
-  uint32_t dc[2][12];
-  uint32_t ac[2][256];
-  uint8_t tlen[2][256];    // trellis quantization: AC code lengths the rate is priced with
-};
-
-// source classes the colour phase is specialised for
-enum { kSrcRgb24 = 0, kSrcRgbx32 = 1, kSrcPlanes = 2 };
-
-struct ScanArgs {
-  const uint8_t* plane[3];      // packed colour / gray: [0]; planar YUV: Y, U, V; NV12/NV21: Y, UV
-  long long row_stride[3], frame_stride[3];
-  int rsh, bsh;                 // kSrcRgbx32: bit position of R and B inside a pixel dword (0 / 16)
-  int cstep, uoff, voff;        // kSrcPlanes: bytes per chroma sample (2 = interleaved) and U/V offsets
-  int W, H, mb_w, n_mcus, nseg, has_clip;
-  int seg_first;                // band mode: frame-level index of this launch's segment 0
-  const DevTables* tables;
-  int tables_stride;            // 0: every frame uses tables[0]; 1: frame f uses tables[f]
-  uint32_t* seg_words;     // [nframes*nseg][slot_words]
-  uint32_t slot_words;
-  uint32_t* seg_nbits;     // [nframes*nseg]
-  uint32_t* spill;         // [nframes*nseg][kScanThreads][kSpillWords]: words that cannot stay in the slot
-  uint32_t* replay;        // [nframes*nseg][kScanThreads][36]: quantized blocks kept by a statistics pass (or NULL)
-  int16_t* coeffs;         // kKindTap: quantized coefficients
-  uint32_t* partial;       // kKindHisto / kKindStats: per-workgroup partial statistics
-  unsigned long long* stamps;  // profiling (env SJPEG_HIP_STAMPS): 8 cycle stamps per workgroup
-  int ablate;              // profiling knob (env SJPEG_HIP_ABLATE): stop after phase 1/2/3; 0 = full
-};
-
-// LDS carve (bytes), all offsets multiples of 16
-constexpr int kSamplesBytes = kScanThreads * kSlotBytes;        // 36864
-constexpr int kOffWin = kSamplesBytes;
-// The quantizer table (1 KiB) and the DC codes are only read before the bit window is first
-// touched (P2 / DC coding), so they live INSIDE the window region.
-constexpr int kOffQ = kOffWin;                                  // uint4[64]
-constexpr int kOffDc = kOffWin + 1024;                          // uint32[24]
-constexpr int kOffTlen = kOffWin + 1152;                        // uint8[2][256], trellis kinds only
-constexpr int kSortHist = 1100;                                 // window word of the sort's bins: beyond everything P2 reads
-constexpr int kOffAc = kOffWin + kWinWords * 4 + 16;            // +1 spare word (16 B keeps alignment)
-constexpr int kOffMisc = kOffAc + 2 * 256 * 4;                  // scan scratch
-constexpr int kLdsBytes = kOffMisc + 64;                        // 47184: three workgroups per CU
-constexpr int kOffStats = kLdsBytes;                            // kKindStats only: u32[2][272]
-constexpr int kLdsBytesStats = kOffStats + 2 * 272 * 4;
-static_assert(kWinWords * 4 >= 1152 + 512 && kWinWords >= 64 + 512 + 512, "window region too small");
-static_assert(3 * kLdsBytes <= 160 * 1024, "three workgroups per CU");
-
-// ------------------------------------------------------------------------------------
-// small device helpers
-
-__device__ __forceinline__ int mul24(int a, int b) { return __mul24(a, b); }
-
-// (a*b) >> 16 with 24-bit operands: the column pass' 16-bit fixed-point multiply
-__device__ __forceinline__ int mulhi16(int a, int b) { return __mul24(a, b) >> 16; }
-
-// In-place 8-point column transform on 8 registers; operation order of
-// src/fdct.cc:67-144 (plain-C macro set :148-157).  Outputs land in natural frequency order.
-__device__ __forceinline__ void fdct_col8(int& x0, int& x1, int& x2, int& x3,
-                                          int& x4, int& x5, int& x6, int& x7) {
-  int d07 = x0 - x7, s07 = x0 + x7;
-  int d25 = x2 - x5, s25 = x2 + x5;
-  int d34 = x3 - x4, s34 = x3 + x4;
-  int d16 = x1 - x6, s16 = x1 + x6;
-  int ed = s07 - s34, es = s07 + s34;
-  int fd = s16 - s25, fs = s16 + s25;
-  const int a = es << 3, b = fs << 3;
-  x0 = a + b;
-  x4 = a - b;
-  ed <<= 3; fd <<= 3; d34 <<= 3; d07 <<= 3;
-  x2 = mulhi16(27146, fd) + ed;
-  x6 = mulhi16(27146, ed) - fd;
-  d25 <<= 4; d16 <<= 4;
-  const int od = mulhi16(d16 - d25, 23170);
-  const int os = mulhi16(d16 + d25, 23170);
-  const int p3 = d34 - od, p1 = d34 + od;
-  const int p0 = d07 - os, p2 = d07 + os;
-  const int t3 = mulhi16(p3, -21746) + p3 + 1;
-  const int t1 = mulhi16(p1, 13036) + p2 + 1;
-  const int t4 = mulhi16(-21746, p0) + p0;
-  const int t5 = mulhi16(13036, p2);
-  x1 = t1;
-  x3 = p0 - t3;
-  x5 = p3 + t4;
-  x7 = t5 - p1;
-}
-
-// Row transform with compile-time table (src/fdct.cc:174-209); products are 24x16 bit.
-template <int C1, int C2, int C3, int C4, int C5, int C6, int C7>
-__device__ __forceinline__ void fdct_row8(int* r) {
-  const int a0 = r[0] + r[7], b0 = r[0] - r[7];
-  const int a1 = r[1] + r[6], b1 = r[1] - r[6];
-  const int a2 = r[2] + r[5], b2 = r[2] - r[5];
-  const int a3 = r[3] + r[4], b3 = r[3] - r[4];
-  const int c0 = a0 + a3, c1 = a0 - a3, c2 = a1 + a2, c3 = a1 - a2;
-  r[0] = mul24(C4, c0 + c2) >> 16;
-  r[4] = mul24(C4, c0 - c2) >> 16;
-  r[2] = (mul24(C2, c1) + mul24(C6, c3)) >> 16;
-  r[6] = (mul24(C6, c1) - mul24(C2, c3)) >> 16;
-  r[1] = (mul24(C1, b0) + mul24(C3, b1) + mul24(C5, b2) + mul24(C7, b3)) >> 16;
-  r[3] = (mul24(C3, b0) - mul24(C7, b1) - mul24(C1, b2) - mul24(C5, b3)) >> 16;
-  r[5] = (mul24(C5, b0) - mul24(C1, b1) + mul24(C7, b2) + mul24(C3, b3)) >> 16;
-  r[7] = (mul24(C7, b0) - mul24(C5, b1) + mul24(C3, b2) - mul24(C1, b3)) >> 16;
-}
-
-// 64 samples (row-major, registers) -> 64 coefficients, x16 scaled (src/fdct.cc:596-609)
-__device__ __forceinline__ void fdct_block(int* v) {
-#pragma unroll
-  for (int x = 0; x < 8; ++x) {
-    fdct_col8(v[x], v[8 + x], v[16 + x], v[24 + x], v[32 + x], v[40 + x], v[48 + x], v[56 + x]);
-  }
-  // cos(k*pi/16)/sqrt(2) tables, rows 1/7, 2/6, 3/5 pre-scaled (src/fdct.cc:28-35)
-  fdct_row8<22725, 21407, 19266, 16384, 12873, 8867, 4520>(v + 0);
-  fdct_row8<31521, 29692, 26722, 22725, 17855, 12299, 6270>(v + 8);
-  fdct_row8<29692, 27969, 25172, 21407, 16819, 11585, 5906>(v + 16);
-  fdct_row8<26722, 25172, 22654, 19266, 15137, 10426, 5315>(v + 24);
-  fdct_row8<22725, 21407, 19266, 16384, 12873, 8867, 4520>(v + 32);
-  fdct_row8<26722, 25172, 22654, 19266, 15137, 10426, 5315>(v + 40);
-  fdct_row8<29692, 27969, 25172, 21407, 16819, 11585, 5906>(v + 48);
-  fdct_row8<31521, 29692, 26722, 22725, 17855, 12299, 6270>(v + 56);
-}
-
-
-// ---- packed int16 arithmetic (two columns per register), the 16-bit-lane formulation the
-// reference's own SIMD paths use and prove bit-identical to the plain-C one (src/fdct.cc:147).
-typedef short s16x2 __attribute__((ext_vector_type(2)));
-typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t as_u32(s16x2 v) { return __builtin_bit_cast(uint32_t, v); }
-__device__ __forceinline__ s16x2 as_pk(uint32_t v) { return __builtin_bit_cast(s16x2, v); }
-
-// per-lane (a*K) >> 16 on both halves: two 24-bit multiplies + one byte permute
-__device__ __forceinline__ s16x2 pk_mulhi(s16x2 a, int K) {
-  const int lo = __mul24(static_cast<int>(a.x), K), hi = __mul24(static_cast<int>(a.y), K);
-  return as_pk(__builtin_amdgcn_perm(static_cast<uint32_t>(hi), static_cast<uint32_t>(lo), 0x07060302u));
-}
-__device__ __forceinline__ s16x2 pk_swap(s16x2 a) {
-  return as_pk(__builtin_amdgcn_alignbit(as_u32(a), as_u32(a), 16));
-}
-__device__ __forceinline__ s16x2 pk_const(int lo, int hi) {
-  return as_pk((static_cast<uint32_t>(lo) & 0xffffu) | (static_cast<uint32_t>(hi) << 16));
-}
-
-// Column transform of TWO adjacent columns at once; operation order of src/fdct.cc:67-144.
-// All intermediates stay inside int16 (|value| <= 8216).
-__device__ __forceinline__ void fdct_col8_pk(uint32_t& r0, uint32_t& r1, uint32_t& r2, uint32_t& r3,
-                                             uint32_t& r4, uint32_t& r5, uint32_t& r6, uint32_t& r7) {
-  const s16x2 x0 = as_pk(r0), x1 = as_pk(r1), x2 = as_pk(r2), x3 = as_pk(r3);
-  const s16x2 x4 = as_pk(r4), x5 = as_pk(r5), x6 = as_pk(r6), x7 = as_pk(r7);
-  s16x2 d07 = x0 - x7, s07 = x0 + x7;
-  s16x2 d25 = x2 - x5, s25 = x2 + x5;
-  s16x2 d34 = x3 - x4, s34 = x3 + x4;
-  s16x2 d16 = x1 - x6, s16 = x1 + x6;
-  s16x2 ed = s07 - s34, es = s07 + s34;
-  s16x2 fd = s16 - s25, fs = s16 + s25;
-  const s16x2 a = es << 3, b = fs << 3;
-  r0 = as_u32(a + b);
-  r4 = as_u32(a - b);
-  ed = ed << 3; fd = fd << 3; d34 = d34 << 3; d07 = d07 << 3;
-  r2 = as_u32(pk_mulhi(fd, 27146) + ed);
-  r6 = as_u32(pk_mulhi(ed, 27146) - fd);
-  d25 = d25 << 4; d16 = d16 << 4;
-  const s16x2 od = pk_mulhi(d16 - d25, 23170);
-  const s16x2 os = pk_mulhi(d16 + d25, 23170);
-  const s16x2 p3 = d34 - od, p1 = d34 + od;
-  const s16x2 p0 = d07 - os, p2 = d07 + os;
-  const s16x2 one = pk_const(1, 1);
-  const s16x2 t3 = pk_mulhi(p3, -21746) + p3 + one;
-  const s16x2 t1 = pk_mulhi(p1, 13036) + p2 + one;
-  const s16x2 t4 = pk_mulhi(p0, -21746) + p0;
-  const s16x2 t5 = pk_mulhi(p2, 13036);
-  r1 = as_u32(t1);
-  r3 = as_u32(p0 - t3);
-  r5 = as_u32(p3 + t4);
-  r7 = as_u32(t5 - p1);
-}
-
-__device__ __forceinline__ int dot2(s16x2 a, int klo, int khi, int acc) {
-  return __builtin_amdgcn_sdot2(a, pk_const(klo, khi), acc, false);
-}
-// the same with a zero accumulator: the three-operand encoding takes the 0 inline (the
-// accumulate-in-place form the compiler picks would need a v_mov first)
-__device__ __forceinline__ int dot2z(s16x2 a, int klo, int khi) {
-  int d;
-  asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(d) : "v"(as_u32(a)), "s"(as_u32(pk_const(klo, khi))));
-  return d;
-}
-
-// Row transform of one row held as 4 packed pairs; 32-bit wrap-around accumulation like
-// src/fdct.cc:174-209 (and pmaddwd in its SSE2 twin).  acc[i] >> 16 is coefficient i of the row.
-template <int C1, int C2, int C3, int C4, int C5, int C6, int C7>
-__device__ __forceinline__ void fdct_row8_pk(const uint32_t* row, int* acc) {
-  const s16x2 p0 = as_pk(row[0]), p1 = as_pk(row[1]);
-  const s16x2 r3 = pk_swap(as_pk(row[3])), r2 = pk_swap(as_pk(row[2]));
-  const s16x2 A01 = p0 + r3, B01 = p0 - r3;       // (a0,a1), (b0,b1)
-  const s16x2 A23 = p1 + r2, B23 = p1 - r2;       // (a2,a3), (b2,b3)
-  acc[0] = dot2(A23, C4, C4, dot2z(A01, C4, C4));
-  acc[4] = dot2(A23, -C4, C4, dot2z(A01, C4, -C4));
-  acc[2] = dot2(A23, -C6, -C2, dot2z(A01, C2, C6));
-  acc[6] = dot2(A23, C2, -C6, dot2z(A01, C6, -C2));
-  acc[1] = dot2(B23, C5, C7, dot2z(B01, C1, C3));
-  acc[3] = dot2(B23, -C1, -C5, dot2z(B01, C3, -C7));
-  acc[5] = dot2(B23, C7, C3, dot2z(B01, C5, -C1));
-  acc[7] = dot2(B23, C3, -C1, dot2z(B01, C7, -C5));
-}
-
-// D = a.u16[half] * b.u16[half] + c   (one VOP3 op on packed operands)
-__device__ __forceinline__ uint32_t mad_u16_lo(uint32_t a, uint32_t b, uint32_t c) {
-  uint32_t d;
-  asm("v_mad_u32_u16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-  return d;
-}
-__device__ __forceinline__ uint32_t mad_u16_hi(uint32_t a, uint32_t b, uint32_t c) {
-  uint32_t d;
-  asm("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[1,1,0,0]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-  return d;
-}
-// D = a.u16[0 or 1] * k + c with a uniform 16-bit multiplier k (scalar operand)
-__device__ __forceinline__ uint32_t mad_u16_lo_k(uint32_t a, uint32_t k, uint32_t c) {
-  uint32_t d;
-  asm("v_mad_u32_u16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(k), "v"(c));
-  return d;
-}
-__device__ __forceinline__ uint32_t mad_u16_hi_k(uint32_t a, uint32_t k, uint32_t c) {
-  uint32_t d;
-  asm("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(d) : "v"(a), "s"(k), "v"(c));
-  return d;
-}
-// D = a.u16[1] * b.u16[0] + c
-__device__ __forceinline__ uint32_t mad_u16_hl(uint32_t a, uint32_t b, uint32_t c) {
-  uint32_t d;
-  asm("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-  return d;
-}
-// a.u16[0] * b.u16[0] + a.u16[1] * b.u16[1] + c, modulo 2^32
-__device__ __forceinline__ uint32_t udot2(uint32_t a, uint32_t b, uint32_t c) {
-  return __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b), c, false);
-}
-__device__ __forceinline__ uint32_t sdot2u(uint32_t a, int klo, int khi, uint32_t c) {
-  return static_cast<uint32_t>(__builtin_amdgcn_sdot2(as_pk(a), pk_const(klo, khi), static_cast<int>(c), false));
-}
-// (x1 >> 16) << 16 | (x0 >> 16) & 0xffff: the upper halves of two 32-bit sums as an int16 pair
-__device__ __forceinline__ uint32_t pk_top(uint32_t x0, uint32_t x1) {
-  return __builtin_amdgcn_perm(x1, x0, 0x07060302u);
-}
-
-// natural index -> zig-zag position
-__device__ constexpr int kInvZig(int j) {
-  constexpr int z[64] = {0,  1,  5,  6,  14, 15, 27, 28, 2,  4,  7,  13, 16, 26, 29, 42,
-                         3,  8,  12, 17, 25, 30, 41, 43, 9,  11, 18, 24, 31, 40, 44, 53,
-                         10, 19, 23, 32, 39, 45, 52, 54, 20, 22, 33, 38, 46, 51, 55, 60,
-                         21, 34, 37, 47, 50, 56, 59, 61, 35, 36, 48, 49, 57, 58, 62, 63};
-  return z[j];
-}
-
-// One row: transform, quantize, pack.  Produces 4 dwords of sign-magnitude entries
-// (bit 15 = negative, bits 0..14 = level) for natural positions 8*ROW .. 8*ROW+7 and ORs the
-// non-zero flags into the zig-zag-ordered 64-bit mask.
-//   level = ((|c| + bias) * iquant) >> 20 == (|c|*iquant + bias*iquant) >> 20
-// The reference's qthresh test is implied: |c| >= qthresh <=> level > 0 (quantize.cc:144-145).
-template <int ROW, int C1, int C2, int C3, int C4, int C5, int C6, int C7>
-__device__ __forceinline__ void row_quant(const uint32_t* row, const uint4* qt, uint32_t* ent, uint32_t* nzq) {
-  int acc[8];
-  fdct_row8_pk<C1, C2, C3, C4, C5, C6, C7>(row, acc);
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const uint32_t cp = __builtin_amdgcn_perm(static_cast<uint32_t>(acc[2 * k + 1]),
-                                              static_cast<uint32_t>(acc[2 * k]), 0x07060302u);
-    const s16x2 c = as_pk(cp);
-    const uint32_t ap = as_u32(__builtin_elementwise_max(c, pk_const(0, 0) - c));
-    const uint4 t = qt[4 * ROW + k];
-    const uint32_t l0 = mad_u16_lo(ap, t.x, t.y) >> 20;
-    const uint32_t l1 = mad_u16_hi(ap, t.x, t.z) >> 20;
-    const uint32_t lv = l0 | (l1 << 16);
-    ent[k] = (cp & 0x80008000u) | lv;
-    // non-zero flags: both at once (packed min), each dropped at its zig-zag position of the
-    // 16-bit mask of its quarter by one multiply-add (every position is written exactly once)
-    uint32_t f;                                   // (min(l0, 1), min(l1, 1))
-    asm("v_pk_min_u16 %0, %1, %2" : "=v"(f) : "v"(lv), "v"(0x00010001u));
-    const int z0 = kInvZig(8 * ROW + 2 * k), z1 = kInvZig(8 * ROW + 2 * k + 1);   // folds after unroll
-    nzq[z0 >> 4] = mad_u16_lo_k(f, 1u << (z0 & 15), nzq[z0 >> 4]);
-    nzq[z1 >> 4] = mad_u16_hi_k(f, 1u << (z1 & 15), nzq[z1 >> 4]);
-  }
-}
-
-// One row, transform only: the raw coefficients (int16 pairs, natural order) for the trellis.
-template <int C1, int C2, int C3, int C4, int C5, int C6, int C7>
-__device__ __forceinline__ void row_raw(const uint32_t* row, uint32_t* ent) {
-  int acc[8];
-  fdct_row8_pk<C1, C2, C3, C4, C5, C6, C7>(row, acc);
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    ent[k] = __builtin_amdgcn_perm(static_cast<uint32_t>(acc[2 * k + 1]), static_cast<uint32_t>(acc[2 * k]), 0x07060302u);
-  }
-}
-
-// zig-zag position -> natural index, as data (the trellis walks positions in a run-time loop)
-__device__ const unsigned char kZigTab[64] = {
-    0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
-    41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
-    30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
-
-// byte-permute selector that builds (E16[a], E16[b]) from the dwords holding them
-__device__ constexpr uint32_t kPairSel(int a, int b) {
-  const uint32_t lo = (a & 1) ? 0x0302u : 0x0100u;       // from S1 (second operand)
-  const uint32_t hi = (b & 1) ? 0x0706u : 0x0504u;       // from S0 (first operand)
-  return lo | (hi << 16);
-}
-
-// zig-zag position -> natural index (JPEG Figure A.6)
-__device__ constexpr int kZig(int i) {
-  constexpr int z[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,
-                         12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6,  7,  14, 21, 28,
-                         35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51,
-                         58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
-  return z[i];
-}
-
-__device__ __forceinline__ uint32_t pack16(int lo, int hi) {
-  return (static_cast<uint32_t>(lo) & 0xffffu) | (static_cast<uint32_t>(hi) << 16);
-}
-
-__device__ __forceinline__ int byte_of(const uint32_t* w, int i) {
-  return static_cast<int>((w[i >> 2] >> (8 * (i & 3))) & 0xffu);
-}
-
-// 24 bytes (8 pixels) of one row; coordinates clamp to the picture (edge replication)
-__device__ __forceinline__ void load_row8(const uint8_t* frame, long long row_stride, int W, int H,
-                                          int x0, int y, bool inside, uint32_t* w) {
-  if (inside) {
-    const uint8_t* p = frame + y * row_stride + 3ll * x0;
-    __builtin_memcpy(w, p, 24);
-  } else {
-    const int yy = y < H ? y : H - 1;
-    const uint8_t* row = frame + yy * row_stride;
-#pragma unroll
-    for (int k = 0; k < 6; ++k) w[k] = 0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int xx = (x0 + i) < W ? (x0 + i) : W - 1;
-      const uint8_t* p = row + 3ll * xx;
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const int bi = 3 * i + c;
-        w[bi >> 2] |= static_cast<uint32_t>(p[c]) << (8 * (bi & 3));
-      }
-    }
-  }
-}
-
-// Raw dwords of 8 consecutive pixels of row y (coordinates clamp to the picture): 6 dwords for
-// packed RGB, 8 for the 4-byte layouts.
-template <int SRC>
-__device__ __forceinline__ void load_px8(const ScanArgs& a, const uint8_t* frame_px, int x0, int y,
-                                         bool inside, uint32_t* w) {
-  if (SRC == kSrcRgb24) {
-    load_row8(frame_px, a.row_stride[0], a.W, a.H, x0, y, inside, w);
-  } else {
-    // 4 bytes per pixel (BGRA / RGBA, alpha ignored: src/colors_rgb.cc:882-1025)
-    if (inside) {
-      __builtin_memcpy(w, frame_px + y * a.row_stride[0] + 4ll * x0, 32);
-    } else {
-      const int yy = y < a.H ? y : a.H - 1;
-      const uint8_t* row = frame_px + yy * a.row_stride[0];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int xx = (x0 + i) < a.W ? (x0 + i) : a.W - 1;
-        __builtin_memcpy(&w[i], row + 4ll * xx, 4);
-      }
-    }
-  }
-}
-
-// The same 8 pixels as packed 16-bit operands: rg[i] = r_i | g_i << 16 (i = 0..7),
-// bb[j] = b_2j | b_(2j+1) << 16 (j = 0..3).  One byte-permute per register.
-template <int SRC>
-__device__ __forceinline__ void unpack_px8(const ScanArgs& a, const uint32_t* w, uint32_t* rg, uint32_t* bb) {
-  if (SRC == kSrcRgb24) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int o = 3 * i, d = o >> 2, sl = o & 3;                  // r at byte o, g at o + 1
-      const uint32_t sel = sl | 0x0c00u | (static_cast<uint32_t>(sl + 1) << 16) | 0x0c000000u;
-      rg[i] = __builtin_amdgcn_perm(w[d + 1 < 6 ? d + 1 : 5], w[d], sel);
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int o = 6 * j + 2, d = o >> 2, sl = o & 3;              // b at bytes o and o + 3
-      const uint32_t sel = sl | 0x0c00u | (static_cast<uint32_t>(sl + 3) << 16) | 0x0c000000u;
-      bb[j] = __builtin_amdgcn_perm(w[d + 1 < 6 ? d + 1 : 5], w[d], sel);
-    }
-  } else {
-    const uint32_t rs = static_cast<uint32_t>(a.rsh) >> 3, bs = static_cast<uint32_t>(a.bsh) >> 3;
-    const uint32_t sel_rg = rs | 0x0c00u | 0x00010000u | 0x0c000000u;
-    const uint32_t sel_bb = bs | 0x0c00u | ((4u + bs) << 16) | 0x0c000000u;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) rg[i] = __builtin_amdgcn_perm(0u, w[i], sel_rg);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) bb[j] = __builtin_amdgcn_perm(w[2 * j + 1], w[2 * j], sel_bb);
-  }
-}
-
-// BT.601 full-range 16.16 fixed point (src/colors_rgb.cc:17-19,31-32,785-828) on packed operands.
-// All sums are the reference's, modulo 2^32; the int16 results are read off the upper halves.
-constexpr uint32_t kLumaRG = 19595u | (38469u << 16);
-constexpr uint32_t kLumaRound = static_cast<uint32_t>(32768 - (128 << 16));
-// luma of pixels 2j and 2j + 1 as an int16 pair
-__device__ __forceinline__ uint32_t luma_pair(uint32_t rg0, uint32_t rg1, uint32_t bbj, uint32_t k7471,
-                                              uint32_t rnd) {
-  const uint32_t y0 = udot2(rg0, kLumaRG, mad_u16_lo(bbj, k7471, rnd));
-  const uint32_t y1 = udot2(rg1, kLumaRG, mad_u16_hl(bbj, k7471, rnd));
-  return pk_top(y0, y1);
-}
-// 32-bit Cb / Cr sums (before the final shift) of one (R | G << 16, B) triple; rnd = rounding term
-__device__ __forceinline__ uint32_t cb_sum(uint32_t RG, uint32_t B, uint32_t rnd) {
-  return sdot2u(RG, -11059, -21709, (B << 15) + rnd);
-}
-__device__ __forceinline__ uint32_t cr_sum(uint32_t RG, uint32_t B, uint32_t k32768, uint32_t rnd) {
-  const uint32_t GB = __builtin_amdgcn_perm(B, RG, 0x05040302u);     // G | B << 16
-  return sdot2u(GB, -27439, -5329, mad_u16_lo(RG, k32768, rnd));
-}
-
-// 8 level-shifted samples of an 8-bit plane (sample pitch `step` bytes), clamped coordinates:
-// what Convert8To16b[Clipped] / Replicate8b produce (src/colors_rgb.cc:1212-1260)
-__device__ __forceinline__ void fetch_plane(const uint8_t* plane, long long stride, int step, int pw,
-                                            int ph, int x0, int y, int n, int* out) {
-  const int yy = y < ph ? y : ph - 1;
-  const uint8_t* row = plane + yy * stride;
-  if (step == 1 && n == 8 && x0 + 8 <= pw) {
-    uint32_t w[2];
-    __builtin_memcpy(w, row + x0, 8);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) out[i] = byte_of(w, i) - 128;
-  } else {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      if (i < n) {
-        const int xx = (x0 + i) < pw ? (x0 + i) : pw - 1;
-        out[i] = static_cast<int>(row[static_cast<long long>(xx) * step]) - 128;
-      }
-    }
-  }
-}
-
-// workgroup exclusive scan of one uint32 per thread; returns exclusive prefix, *total = sum
-template <int NT>
-__device__ __forceinline__ uint32_t wg_exclusive_scan(uint32_t x, uint32_t* scratch /*>=8 u32*/,
-                                                      uint32_t* total) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  uint32_t incl = x;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const uint32_t y = __shfl_up(incl, d, 64);
-    if (lane >= d) incl += y;
-  }
-  if (lane == 63) scratch[wave] = incl;
-  __syncthreads();
-  uint32_t base = 0, sum = 0;
-#pragma unroll
-  for (int w = 0; w < NT / 64; ++w) {
-    const uint32_t s = scratch[w];
-    if (w < wave) base += s;
-    sum += s;
-  }
-  __syncthreads();
-  *total = sum;
-  return base + incl - x;
-}
-
-// ------------------------------------------------------------------------------------
-// K1: colour + fDCT + quantize + entropy-code one segment
-
-enum { kKindEncode = 0, kKindTap = 1, kKindHisto = 2, kKindStats = 3, kKindError = 4,
-       kKindEncodeTrellis = 5, kKindStatsTrellis = 6,     // the same two with trellis quantization
-       kKindEncodeReplay = 7 };   // entropy-code the coefficients a statistics pass left behind
-constexpr int kHistoWords = 2 * 64 * 32;          // per-workgroup partial: u8 counters [2][64][128]
-constexpr int kStatsWords = 2 * 272;              // per-workgroup partial: u32 [2][256 AC + 16 DC]
-
-template <int MODE, int KINDX, int SRC>
-__global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) {
-  constexpr bool TRELLIS = (KINDX == kKindEncodeTrellis || KINDX == kKindStatsTrellis);
-  constexpr bool REPLAY = (KINDX == kKindEncodeReplay);
-  constexpr int KIND = (KINDX == kKindEncodeTrellis || KINDX == kKindEncodeReplay) ? kKindEncode : (KINDX == kKindStatsTrellis) ? kKindStats : KINDX;
-  using G = Geo<MODE>;
-  constexpr int BPM = G::kBpm;
-  constexpr int PX = G::kMcuPx;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  uint32_t* const win = reinterpret_cast<uint32_t*>(smem + kOffWin);
-  uint4* const lq = reinterpret_cast<uint4*>(smem + kOffQ);
-  uint32_t* const lac = reinterpret_cast<uint32_t*>(smem + kOffAc);
-  uint32_t* const ldc = reinterpret_cast<uint32_t*>(smem + kOffDc);
-  uint32_t* const misc = reinterpret_cast<uint32_t*>(smem + kOffMisc);
-
-  const int tid = threadIdx.x;
-  const int seg = blockIdx.x, frame = blockIdx.y;
-  auto stamp = [&](int k) {
-    if (a.stamps != nullptr && tid == 0) {
-      a.stamps[(static_cast<size_t>(frame) * a.nseg + seg) * 8 + k] = __builtin_readcyclecounter();
-    }
-  };
-  stamp(0);
-  const int m_first = (seg + a.seg_first) * G::kSegMcus;       // first coded MCU of the segment
-  const int n_coded = min(G::kSegMcus, a.n_mcus - m_first);
-  const int halo = m_first > 0 ? 1 : 0;                        // previous MCU: DC predictors only
-  const uint8_t* const frame_px = a.plane[0] + frame * a.frame_stride[0];
-
-  // tables -> LDS; issued once the first pixel loads are in flight (see P1)
-  auto stage_tables = [&]() {
-    const DevTables* t = a.tables + frame * a.tables_stride;
-    if (tid < 64) lq[tid] = (&t->q[0][0])[tid];
-    for (int i = tid; i < 512; i += kScanThreads) lac[i] = (&t->ac[0][0])[i];
-    if (tid < 24) ldc[tid] = (&t->dc[0][0])[tid];
-    if (TRELLIS && tid < 128) reinterpret_cast<uint32_t*>(smem + kOffTlen)[tid] = reinterpret_cast<const uint32_t*>(&t->tlen[0][0])[tid];
-  };
-
-  // ---- P1: colour conversion, strips of 8 pixels (x2 rows for 4:2:0) --------------------
-  // local MCU index ml: 0 = halo, 1..n_coded = coded MCUs; block slot = ml*BPM + k
-  if (REPLAY) stage_tables();
-  if (!REPLAY) {
-    const int ml_lo = 1 - halo;
-    const int n_proc = n_coded + halo;
-    constexpr int kRowsPerStrip = (MODE == SJPEG_HIP_YUV420) ? 2 : 1;
-    constexpr int kStripsX = PX / 8;                           // strips per MCU row
-    const int per_row = kStripsX * n_proc;
-    // A thread keeps ONE strip column (one MCU, one x-half) and walks down its row pairs
-    // yp0, yp0 + ngroups, ...: the index arithmetic (two integer divisions by run-time
-    // values) is done once per thread instead of once per strip, and consecutive lanes still
-    // read consecutive 24-byte pieces of a picture row.
-    const int ngroups = kScanThreads / per_row;                 // 3 for a full 4:2:0 segment
-    const int yp0 = tid / per_row;
-    const int rem = tid - yp0 * per_row;
-    const int ml = ml_lo + rem / kStripsX;
-    const int xs = rem % kStripsX;
-    const int mcu = m_first - 1 + ml;
-    const int mb_y = mcu / a.mb_w;
-    const int mb_x = mcu - mb_y * a.mb_w;
-    const int x0 = mb_x * PX + xs * 8;
-    const uint32_t k7471 = 7471u, k32768 = 32768u;             // multiplier operands (low halves)
-    constexpr int kNW = (SRC == kSrcRgb24) ? 6 : 8;             // dwords per 8 pixels
-    constexpr int kBatch = 3;                                   // row pairs in flight per thread
-    bool tables_staged = false;
-    for (int ypb = yp0; ypb < 8 && yp0 < ngroups; ypb += kBatch * ngroups) {
-    // all global loads of the batch are issued before the first one is consumed
-    uint32_t raw[kBatch][kRowsPerStrip][kNW];
-    if (SRC != kSrcPlanes) {
-#pragma unroll
-      for (int it = 0; it < kBatch; ++it) {
-        const int yp = ypb + it * ngroups;
-        if (yp < 8) {
-          const int y0 = mb_y * PX + yp * kRowsPerStrip;
-          const bool inside = (x0 + 8 <= a.W) && (y0 + kRowsPerStrip <= a.H);
-#pragma unroll
-          for (int r = 0; r < kRowsPerStrip; ++r) load_px8<SRC>(a, frame_px, x0, y0 + r, inside, raw[it][r]);
-        }
-      }
-    }
-    if (!tables_staged) { stage_tables(); tables_staged = true; }
-#pragma unroll
-    for (int it = 0; it < kBatch; ++it) {
-      const int yp = ypb + it * ngroups;
-      if (yp >= 8) break;
-      const int y0 = mb_y * PX + yp * kRowsPerStrip;
-      if (SRC == kSrcPlanes) {
-        // 8-bit planes are used as they are, minus 128 (src/encoders.cc:256-490)
-        int ya[8];
-        fetch_plane(frame_px, a.row_stride[0], 1, a.W, a.H, x0, y0, 8, ya);
-        if (MODE == SJPEG_HIP_YUV420) {
-          int yb[8], U[8], V[8];
-          fetch_plane(frame_px, a.row_stride[0], 1, a.W, a.H, x0, y0 + 1, 8, yb);
-          const int cw = (a.W + 1) >> 1, ch = (a.H + 1) >> 1;
-          const uint8_t* pu = a.plane[1] + frame * a.frame_stride[1] + a.uoff;
-          const uint8_t* pv = a.plane[2] + frame * a.frame_stride[2] + a.voff;
-          fetch_plane(pu, a.row_stride[1], a.cstep, cw, ch, mb_x * 8 + xs * 4, mb_y * 8 + yp, 4, U);
-          fetch_plane(pv, a.row_stride[2], a.cstep, cw, ch, mb_x * 8 + xs * 4, mb_y * 8 + yp, 4, V);
-          const int k = (yp >> 2) * 2 + xs;
-          const int row = (yp & 3) * 2;
-          unsigned char* ys = smem + (ml * BPM + k) * kSlotBytes + row * 16;
-          *reinterpret_cast<uint4*>(ys) =
-              make_uint4(pack16(ya[0], ya[1]), pack16(ya[2], ya[3]), pack16(ya[4], ya[5]), pack16(ya[6], ya[7]));
-          *reinterpret_cast<uint4*>(ys + 16) =
-              make_uint4(pack16(yb[0], yb[1]), pack16(yb[2], yb[3]), pack16(yb[4], yb[5]), pack16(yb[6], yb[7]));
-          unsigned char* us = smem + (ml * BPM + 4) * kSlotBytes + yp * 16 + xs * 8;
-          *reinterpret_cast<uint2*>(us) = make_uint2(pack16(U[0], U[1]), pack16(U[2], U[3]));
-          *reinterpret_cast<uint2*>(us + kSlotBytes) = make_uint2(pack16(V[0], V[1]), pack16(V[2], V[3]));
-        } else {
-          unsigned char* ys = smem + (ml * BPM) * kSlotBytes + yp * 16;
-          *reinterpret_cast<uint4*>(ys) =
-              make_uint4(pack16(ya[0], ya[1]), pack16(ya[2], ya[3]), pack16(ya[4], ya[5]), pack16(ya[6], ya[7]));
-          if (MODE == SJPEG_HIP_YUV444) {
-            int uv[8], vv[8];
-            fetch_plane(a.plane[1] + frame * a.frame_stride[1], a.row_stride[1], 1, a.W, a.H, x0, y0, 8, uv);
-            fetch_plane(a.plane[2] + frame * a.frame_stride[2], a.row_stride[2], 1, a.W, a.H, x0, y0, 8, vv);
-            *reinterpret_cast<uint4*>(ys + kSlotBytes) =
-                make_uint4(pack16(uv[0], uv[1]), pack16(uv[2], uv[3]), pack16(uv[4], uv[5]), pack16(uv[6], uv[7]));
-            *reinterpret_cast<uint4*>(ys + 2 * kSlotBytes) =
-                make_uint4(pack16(vv[0], vv[1]), pack16(vv[2], vv[3]), pack16(vv[4], vv[5]), pack16(vv[6], vv[7]));
-          }
-        }
-        continue;
-      }
-      uint32_t rg0[8], bb0[4];
-      unpack_px8<SRC>(a, raw[it][0], rg0, bb0);
-      if (MODE == SJPEG_HIP_YUV420) {
-        uint32_t rg1[8], bb1[4];
-        unpack_px8<SRC>(a, raw[it][kRowsPerStrip - 1], rg1, bb1);
-        uint32_t ya[4], yb[4], us32[4], vs32[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          ya[c] = luma_pair(rg0[2 * c], rg0[2 * c + 1], bb0[c], k7471, kLumaRound);
-          yb[c] = luma_pair(rg1[2 * c], rg1[2 * c + 1], bb1[c], k7471, kLumaRound);
-          // 2x2 sums: halves stay below 1021, plain 32-bit adds never carry across
-          const uint32_t RG = (rg0[2 * c] + rg0[2 * c + 1]) + (rg1[2 * c] + rg1[2 * c + 1]);
-          const uint32_t BB = bb0[c] + bb1[c];
-          const uint32_t B = (BB & 0xffffu) + (BB >> 16);
-          us32[c] = cb_sum(RG, B, 32768u << 2);
-          vs32[c] = cr_sum(RG, B, k32768, 32768u << 2);
-        }
-        // (sum >> 16) >> 2 == sum >> 18 (floor of floor)
-        const s16x2 two = pk_const(2, 2);
-        const uint32_t u01 = as_u32(as_pk(pk_top(us32[0], us32[1])) >> two);
-        const uint32_t u23 = as_u32(as_pk(pk_top(us32[2], us32[3])) >> two);
-        const uint32_t v01 = as_u32(as_pk(pk_top(vs32[0], vs32[1])) >> two);
-        const uint32_t v23 = as_u32(as_pk(pk_top(vs32[2], vs32[3])) >> two);
-        const int k = (yp >> 2) * 2 + xs;
-        const int row = (yp & 3) * 2;
-        unsigned char* ys = smem + (ml * BPM + k) * kSlotBytes + row * 16;
-        *reinterpret_cast<uint4*>(ys) = make_uint4(ya[0], ya[1], ya[2], ya[3]);
-        *reinterpret_cast<uint4*>(ys + 16) = make_uint4(yb[0], yb[1], yb[2], yb[3]);
-        unsigned char* us = smem + (ml * BPM + 4) * kSlotBytes + yp * 16 + xs * 8;
-        *reinterpret_cast<uint2*>(us) = make_uint2(u01, u23);
-        *reinterpret_cast<uint2*>(us + kSlotBytes) = make_uint2(v01, v23);
-      } else {
-        uint32_t yv[4], uv[4], vv[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          yv[c] = luma_pair(rg0[2 * c], rg0[2 * c + 1], bb0[c], k7471, kLumaRound);
-          if (MODE == SJPEG_HIP_YUV444) {
-            const uint32_t b0 = bb0[c] & 0xffffu, b1 = bb0[c] >> 16;
-            uv[c] = pk_top(cb_sum(rg0[2 * c], b0, 32768u), cb_sum(rg0[2 * c + 1], b1, 32768u));
-            vv[c] = pk_top(cr_sum(rg0[2 * c], b0, k32768, 32768u), cr_sum(rg0[2 * c + 1], b1, k32768, 32768u));
-          }
-        }
-        unsigned char* ys = smem + (ml * BPM) * kSlotBytes + yp * 16;
-        *reinterpret_cast<uint4*>(ys) = make_uint4(yv[0], yv[1], yv[2], yv[3]);
-        if (MODE == SJPEG_HIP_YUV444) {
-          *reinterpret_cast<uint4*>(ys + kSlotBytes) = make_uint4(uv[0], uv[1], uv[2], uv[3]);
-          *reinterpret_cast<uint4*>(ys + 2 * kSlotBytes) = make_uint4(vv[0], vv[1], vv[2], vv[3]);
-        }
-      }
-    }
-    }
-    if (!tables_staged) stage_tables();
-  }
-  __syncthreads();
-  stamp(1);
-  if (a.ablate == 1) return;
-
-  // ---- P2: one thread per block: fix-up, fDCT, quantize ---------------------------------
-  const int ml = tid / BPM;                    // local MCU (0 = halo)
-  const int k = tid - ml * BPM;                // block inside the MCU
-  const bool has_block = (ml <= n_coded) && (ml >= 1 || halo);
-  const bool emits = (ml >= 1) && (ml <= n_coded);
-  const int tbl = (MODE == SJPEG_HIP_YUV420) ? (k >= 4) : (MODE == SJPEG_HIP_YUV444 ? (k >= 1) : 0);
-  unsigned char* const slot = smem + tid * kSlotBytes;
-  uint32_t nzq[4] = {0, 0, 0, 0};                   // non-zero masks of the four zig-zag quarters
-  int dc_val = 0;
-  // what a statistics pass keeps for the replay kind: the slot as P2 leaves it + masks + DC value
-  uint4* const keep = (a.replay == nullptr) ? nullptr
-      : reinterpret_cast<uint4*>(a.replay) + ((static_cast<size_t>(frame) * a.nseg + seg) * kScanThreads + tid) * 9;
-  if (REPLAY) {
-#pragma unroll
-    for (int r = 0; r < 8; ++r) *reinterpret_cast<uint4*>(slot + 16 * r) = keep[r];
-    const uint4 t = keep[8];
-    nzq[0] = t.x & 0xffffu; nzq[1] = t.x >> 16; nzq[2] = t.y & 0xffffu; nzq[3] = t.y >> 16;
-    dc_val = static_cast<int>(t.z);
-  }
-  if (!REPLAY) {
-  // rows as packed int16 pairs, straight from the slot: p[r][c] = (s[r][2c], s[r][2c+1])
-  uint32_t p[8][4];
-#pragma unroll
-  for (int r = 0; r < 8; ++r) {
-    uint4 q = make_uint4(0, 0, 0, 0);
-    if (has_block) q = *reinterpret_cast<const uint4*>(slot + 16 * r);
-    p[r][0] = q.x; p[r][1] = q.y; p[r][2] = q.z; p[r][3] = q.w;
-  }
-
-  if (MODE == SJPEG_HIP_YUV420 && a.has_clip) {
-    // AverageExtraLuma (src/encoders.cc:107-125): luma blocks wholly outside the picture
-    // become flat at (sum + 32) >> 6 of a neighbouring real block.
-    int sum = 0;
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-#pragma unroll
-      for (int c = 0; c < 4; ++c) sum = dot2(as_pk(p[r][c]), 1, 1, sum);
-    }
-    reinterpret_cast<int*>(slot + 128)[3] = sum;
-    __syncthreads();
-    if (has_block && k >= 1 && k <= 3) {
-      const int mcu = m_first - 1 + ml;
-      const int mb_y = mcu / a.mb_w;
-      const int mb_x = mcu - mb_y * a.mb_w;
-      const int sub_w = a.W - mb_x * 16, sub_h = a.H - mb_y * 16;
-      int src = -1;
-      if (k == 1) {
-        if (sub_w <= 8) src = 0;
-      } else if (sub_h <= 8) {
-        src = (sub_w > 8) ? 1 : 0;
-      } else if (k == 3 && sub_w <= 8) {
-        src = 2;
-      }
-      if (src >= 0) {
-        const int flat = (reinterpret_cast<const int*>(smem + (ml * BPM + src) * kSlotBytes + 128)[3] + 32) >> 6;
-        const uint32_t ff = pack16(flat, flat);
-#pragma unroll
-        for (int r = 0; r < 8; ++r) { p[r][0] = ff; p[r][1] = ff; p[r][2] = ff; p[r][3] = ff; }
-      }
-    }
-    __syncthreads();
-  }
-
-  // forward DCT: two columns per op, then row by row fused with quantization
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    fdct_col8_pk(p[0][c], p[1][c], p[2][c], p[3][c], p[4][c], p[5][c], p[6][c], p[7][c]);
-  }
-  if (KIND == kKindError) {
-    // Quantization error of the picture (reference QuantizeError, src/quantize.cc:553-565):
-    // sum of ((|c| >> 4) - quant * level)^2, per block in 32-bit wrap-around, 64 bits overall.
-    const uint4* qt = lq + tbl * 32;
-    uint32_t err = 0;
-    int acc[8];
-    auto add_row = [&](int row, const int* ac8) {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int c = ac8[i] >> 16;
-        const uint32_t mag = static_cast<uint32_t>(c < 0 ? -c : c);
-        const uint4 t = qt[row * 4 + (i >> 1)];
-        const uint32_t iq = (i & 1) ? (t.x >> 16) : (t.x & 0xffffu);
-        const uint32_t biq = (i & 1) ? t.z : t.y;
-        const uint32_t qv = (i & 1) ? (t.w >> 16) : (t.w & 0xffffu);
-        const uint32_t v = qv * ((mag * iq + biq) >> 20);
-        const uint32_t d = (mag >> 4) - v;
-        err += d * d;
-      }
-    };
-    fdct_row8_pk<22725, 21407, 19266, 16384, 12873, 8867, 4520>(p[0], acc); add_row(0, acc);
-    fdct_row8_pk<31521, 29692, 26722, 22725, 17855, 12299, 6270>(p[1], acc); add_row(1, acc);
-    fdct_row8_pk<29692, 27969, 25172, 21407, 16819, 11585, 5906>(p[2], acc); add_row(2, acc);
-    fdct_row8_pk<26722, 25172, 22654, 19266, 15137, 10426, 5315>(p[3], acc); add_row(3, acc);
-    fdct_row8_pk<22725, 21407, 19266, 16384, 12873, 8867, 4520>(p[4], acc); add_row(4, acc);
-    fdct_row8_pk<26722, 25172, 22654, 19266, 15137, 10426, 5315>(p[5], acc); add_row(5, acc);
-    fdct_row8_pk<29692, 27969, 25172, 21407, 16819, 11585, 5906>(p[6], acc); add_row(6, acc);
-    fdct_row8_pk<31521, 29692, 26722, 22725, 17855, 12299, 6270>(p[7], acc); add_row(7, acc);
-    unsigned long long e64 = emits ? err : 0u;
-    for (int d = 32; d > 0; d >>= 1) e64 += __shfl_xor(e64, d, 64);
-    unsigned long long* const we = reinterpret_cast<unsigned long long*>(misc);
-    if ((tid & 63) == 0) we[tid >> 6] = e64;
-    __syncthreads();
-    if (tid == 0) {
-      unsigned long long sum = 0;
-      for (int w = 0; w < kScanThreads / 64; ++w) sum += we[w];
-      reinterpret_cast<unsigned long long*>(a.partial)[static_cast<size_t>(frame) * a.nseg + seg] = sum;
-    }
-    return;
-  }
-  if (KIND == kKindHisto) {
-    // Adaptive-quantization statistics (reference StoreHisto, src/histogram.cc:56-108): for every
-    // natural position, histogram of |coefficient| >> 2 (bins < 128), one histogram per
-    // quantizer table.  8-bit counters packed four to a word in LDS (a workgroup has at most
-    // 252 blocks), flushed as this workgroup's partial; reduce_partials() sums them.
-    __syncthreads();                            // every thread holds its samples: slots are free
-    uint32_t* const lh = reinterpret_cast<uint32_t*>(smem);
-    // Bins 0..3 (one word per position) take most of the hits and every lane of a wave hits the
-    // SAME word: an LDS atomic serialises those lanes.  Eight replicas of that word, picked by
-    // lane, cut the conflicts eight-fold; they are folded back before the flush.  (A position
-    // has at most 252 entries per workgroup: the 8-bit fields cannot overflow.)
-    constexpr int kReps = 8;
-    uint32_t* const rep = lh + kHistoWords;       // [2][64][kReps]
-    for (int i = tid; i < kHistoWords + 2 * 64 * kReps; i += kScanThreads) lh[i] = 0;
-    __syncthreads();
-    int acc[8];
-    auto bump = [&](int row, const int* ac8) {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int c = ac8[i] >> 16;
-        const uint32_t bin = static_cast<uint32_t>(c < 0 ? -c : c) >> 2;
-        if (emits && bin < 128u) {
-          const int pos = tbl * 64 + row * 8 + i;
-          uint32_t* const w = (bin < 4u) ? &rep[pos * kReps + (tid & (kReps - 1))] : &lh[pos * 32 + (bin >> 2)];
-          atomicAdd(w, 1u << (8 * (bin & 3)));
-        }
-      }
-    };
-    fdct_row8_pk<22725, 21407, 19266, 16384, 12873, 8867, 4520>(p[0], acc); bump(0, acc);
-    fdct_row8_pk<31521, 29692, 26722, 22725, 17855, 12299, 6270>(p[1], acc); bump(1, acc);
-    fdct_row8_pk<29692, 27969, 25172, 21407, 16819, 11585, 5906>(p[2], acc); bump(2, acc);
-    fdct_row8_pk<26722, 25172, 22654, 19266, 15137, 10426, 5315>(p[3], acc); bump(3, acc);
-    fdct_row8_pk<22725, 21407, 19266, 16384, 12873, 8867, 4520>(p[4], acc); bump(4, acc);
-    fdct_row8_pk<26722, 25172, 22654, 19266, 15137, 10426, 5315>(p[5], acc); bump(5, acc);
-    fdct_row8_pk<29692, 27969, 25172, 21407, 16819, 11585, 5906>(p[6], acc); bump(6, acc);
-    fdct_row8_pk<31521, 29692, 26722, 22725, 17855, 12299, 6270>(p[7], acc); bump(7, acc);
-    __syncthreads();
-    if (tid < 128) {                               // fold the replicas into word 0 of their position
-      uint32_t sum = 0;
-#pragma unroll
-      for (int r = 0; r < kReps; ++r) sum += rep[tid * kReps + r];
-      lh[tid * 32] += sum;
-    }
-    __syncthreads();
-    uint32_t* const dst = a.partial + (static_cast<size_t>(frame) * a.nseg + seg) * kHistoWords;
-    for (int i = tid; i < kHistoWords; i += kScanThreads) dst[i] = lh[i];
-    return;
-  }
-  uint32_t ent[32];                             // natural order, 2 entries per dword
-  {
-    const uint4* qt = lq + tbl * 32;
-    // cos(k*pi/16)/sqrt(2) tables, rows 1/7, 2/6, 3/5 pre-scaled (src/fdct.cc:28-35,599-606)
-    if (!TRELLIS) {
-      row_quant<0, 22725, 21407, 19266, 16384, 12873, 8867, 4520>(p[0], qt, ent + 0, nzq);
-      row_quant<1, 31521, 29692, 26722, 22725, 17855, 12299, 6270>(p[1], qt, ent + 4, nzq);
-      row_quant<2, 29692, 27969, 25172, 21407, 16819, 11585, 5906>(p[2], qt, ent + 8, nzq);
-      row_quant<3, 26722, 25172, 22654, 19266, 15137, 10426, 5315>(p[3], qt, ent + 12, nzq);
-      row_quant<4, 22725, 21407, 19266, 16384, 12873, 8867, 4520>(p[4], qt, ent + 16, nzq);
-      row_quant<5, 26722, 25172, 22654, 19266, 15137, 10426, 5315>(p[5], qt, ent + 20, nzq);
-      row_quant<6, 29692, 27969, 25172, 21407, 16819, 11585, 5906>(p[6], qt, ent + 24, nzq);
-      row_quant<7, 31521, 29692, 26722, 22725, 17855, 12299, 6270>(p[7], qt, ent + 28, nzq);
-    } else {
-      row_raw<22725, 21407, 19266, 16384, 12873, 8867, 4520>(p[0], ent + 0);
-      row_raw<31521, 29692, 26722, 22725, 17855, 12299, 6270>(p[1], ent + 4);
-      row_raw<29692, 27969, 25172, 21407, 16819, 11585, 5906>(p[2], ent + 8);
-      row_raw<26722, 25172, 22654, 19266, 15137, 10426, 5315>(p[3], ent + 12);
-      row_raw<22725, 21407, 19266, 16384, 12873, 8867, 4520>(p[4], ent + 16);
-      row_raw<26722, 25172, 22654, 19266, 15137, 10426, 5315>(p[5], ent + 20);
-      row_raw<29692, 27969, 25172, 21407, 16819, 11585, 5906>(p[6], ent + 24);
-      row_raw<31521, 29692, 26722, 22725, 17855, 12299, 6270>(p[7], ent + 28);
-    }
-  }
-  // zig-zag reorder with byte permutes, 4 entries per ds_write_b64
-#pragma unroll
-  for (int i = 0; i < 64; i += 4) {
-    const uint32_t w0 = __builtin_amdgcn_perm(ent[kZig(i + 1) >> 1], ent[kZig(i) >> 1],
-                                              kPairSel(kZig(i), kZig(i + 1)));
-    const uint32_t w1 = __builtin_amdgcn_perm(ent[kZig(i + 3) >> 1], ent[kZig(i + 2) >> 1],
-                                              kPairSel(kZig(i + 2), kZig(i + 3)));
-    *reinterpret_cast<uint2*>(slot + 2 * i) = make_uint2(w0, w1);
-  }
-  if (!TRELLIS) {
-    const int dc_mag = static_cast<int>(ent[0] & 0x7fffu);
-    dc_val = (ent[0] & 0x8000u) ? -dc_mag : dc_mag;
-  } else {
-    // Trellis quantization (reference Encoder::TrellisQuantizeBlock + SearchBestPrev,
-    // src/quantize.cc:325-457): the slot holds the RAW coefficients in zig-zag order.  For every
-    // coefficient that does not quantize to zero, two candidate levels become nodes of a graph;
-    // an edge costs distortion + lambda * bits (bits priced with the AC code lengths in `tl`).
-    // One thread per block, nodes in private memory: a correct, not a fast, path.
-    typedef int16_t __attribute__((may_alias)) i16_alias;
-    typedef uint16_t __attribute__((may_alias)) u16_alias2;
-    const i16_alias* const raw = reinterpret_cast<const i16_alias*>(slot);
-    const uint4* const qt = lq + tbl * 32;
-    const uint8_t* const tl = smem + kOffTlen + tbl * 256;
-    {
-      const int d = raw[0];
-      const uint4 t0 = qt[0];
-      const uint32_t ad = static_cast<uint32_t>(d < 0 ? -d : d);
-      const int lv = static_cast<int>((ad * (t0.x & 0xffffu) + t0.y) >> 20);
-      dc_val = d < 0 ? -lv : lv;
-    }
-    unsigned long long nzm = 0;
-    if (emits) {
-      constexpr int kNodes = 1 + 2 * 63;
-      uint32_t n_score[kNodes];
-      uint32_t n_info[kNodes];                     // level | neg << 11 | pos << 12 | rank << 18 | prev << 25
-      uint32_t disto0[64];
-      n_score[0] = 0; n_info[0] = 0;
-      disto0[0] = 0;
-      int count = 1;                               // node 0 = the sink
-      const uint32_t zrl_len = tl[0xf0];
-      for (int i = 1; i < 64; ++i) {
-        const int j = kZigTab[i];
-        const uint4 t = qt[j >> 1];
-        const uint32_t iq = (j & 1) ? (t.x >> 16) : (t.x & 0xffffu);
-        const uint32_t biq = (j & 1) ? t.z : t.y;
-        const uint32_t qq = ((j & 1) ? (t.w >> 16) : (t.w & 0xffffu)) << 4;
-        const uint32_t lambda = qq * qq / 32u;
-        const int rv = raw[i];
-        const uint32_t neg = rv < 0 ? 1u : 0u;
-        const int V = rv < 0 ? -rv : rv;
-        disto0[i] = static_cast<uint32_t>(V * V) + disto0[i - 1];
-        int v = static_cast<int>((static_cast<uint32_t>(V) * iq + biq) >> 20);
-        if (v == 0) continue;
-        int nbits = 32 - __clz(v);
-        for (int kk = 0; kk < 2; ++kk) {
-          const int err = V - v * static_cast<int>(qq);
-          const int me = count;
-          uint32_t my_score = 0xffffffffu, my_prev = 0, my_rank = 0;
-          bool found = false;
-          const uint32_t base_disto = static_cast<uint32_t>(err * err) + disto0[i - 1];
-          for (int c = me - 1; c >= 0; --c) {
-            const uint32_t ci = n_info[c];
-            const int cpos = static_cast<int>((ci >> 12) & 63u);
-            const int run = i - 1 - cpos;
-            if (run < 0) continue;
-            uint32_t bits = static_cast<uint32_t>(nbits) + static_cast<uint32_t>(run >> 4) * zrl_len;
-            const uint32_t disto = base_disto - disto0[cpos];
-            if (disto + lambda * bits >= my_score) break;
-            bits += tl[((run & 15) << 4) | nbits];
-            const uint32_t score = disto + lambda * bits + n_score[c];
-            if (score < my_score) {
-              my_score = score; my_prev = static_cast<uint32_t>(c); my_rank = ((ci >> 18) & 127u) + 1u;
-              found = true;
-            }
-          }
-          if (found) {
-            n_score[me] = my_score;
-            n_info[me] = static_cast<uint32_t>(v) | (neg << 11) | (static_cast<uint32_t>(i) << 12) | (my_rank << 18) | (my_prev << 25);
-            ++count;
-          }
-          --nbits;
-          if (nbits <= 0) break;
-          v = (1 << nbits) - 1;
-        }
-      }
-      // best entry point, searched backwards (the EOB cost is the same for all but position 63)
-      int best = 0;
-      if (count > 1) {
-        uint32_t best_score = 0xffffffffu;
-        for (int c = count - 1; c >= 0; --c) {
-          const uint32_t sc = n_score[c] + (disto0[63] - disto0[(n_info[c] >> 12) & 63u]);
-          if (sc < best_score) { best = c; best_score = sc; }
-        }
-      }
-      // the slot becomes the usual sign-magnitude entries: zeros but for the chosen chain
-#pragma unroll
-      for (int r = 0; r < 8; ++r) *reinterpret_cast<uint4*>(slot + 16 * r) = make_uint4(0, 0, 0, 0);
-      u16_alias2* const zzw = reinterpret_cast<u16_alias2*>(slot);
-      for (int c = best; c > 0; c = static_cast<int>(n_info[c] >> 25)) {
-        const uint32_t ci = n_info[c];
-        const uint32_t pos = (ci >> 12) & 63u;
-        zzw[pos] = static_cast<uint16_t>((ci & 0x7ffu) | (((ci >> 11) & 1u) << 15));
-        nzm |= 1ull << pos;
-      }
-    } else {
-#pragma unroll
-      for (int r = 0; r < 8; ++r) *reinterpret_cast<uint4*>(slot + 16 * r) = make_uint4(0, 0, 0, 0);
-    }
-    nzq[0] = static_cast<uint32_t>(nzm) & 0xffffu; nzq[1] = static_cast<uint32_t>(nzm >> 16) & 0xffffu;
-    nzq[2] = static_cast<uint32_t>(nzm >> 32) & 0xffffu; nzq[3] = static_cast<uint32_t>(nzm >> 48);
-  }
-  nzq[0] &= ~1u;                                // DC is coded separately
-  if (KIND == kKindStats && keep != nullptr) {   // leave the quantized block behind for the replay kind
-#pragma unroll
-    for (int r = 0; r < 8; ++r) keep[r] = *reinterpret_cast<const uint4*>(slot + 16 * r);
-    keep[8] = make_uint4(nzq[0] | (nzq[1] << 16), nzq[2] | (nzq[3] << 16), static_cast<uint32_t>(dc_val), 0u);
-  }
-  }   // !REPLAY
-  const uint32_t nz_lo = nzq[0] | (nzq[1] << 16), nz_hi = nzq[2] | (nzq[3] << 16);
-  if (KIND == kKindTap) {
-    if (emits) {
-      const long long nblk_frame = static_cast<long long>(a.n_mcus) * BPM;
-      const long long blk = frame * nblk_frame + static_cast<long long>(m_first - 1 + ml) * BPM + k;
-      const uint16_t* src = reinterpret_cast<const uint16_t*>(slot);
-      int16_t* dst = a.coeffs + blk * 64;
-      for (int i = 0; i < 64; ++i) {
-        const int e = src[i], mag = e & 0x7fff;
-        dst[i] = static_cast<int16_t>((e & 0x8000) ? -mag : mag);
-      }
-    }
-    return;                                        // the tap ends here: no entropy coding
-  }
-
-  if (a.ablate == 2) { if (nz_lo + nz_hi + dc_val == 0x7fffffff) a.seg_nbits[0] = 1; return; }
-
-  stamp(2);
-  // ---- P3: entropy coding ----------------------------------------------------------------
-  // DC prediction (src/entropy.cc:133-150) through the 16 spare bytes of each slot.
-  uint32_t* const tail = reinterpret_cast<uint32_t*>(slot + 128);
-  tail[3] = static_cast<uint32_t>(dc_val);
-  // (sort bookkeeping that aliases nothing still in use is cleared under the same barrier)
-  if (KIND == kKindEncode) {
-    if (tid < 32) win[kSortHist + tid] = 0;
-    if (tid == 32) misc[10] = 0;                   // the queue of part groups (P3)
-    *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(win + 64 + 512) + 4 * tid) = make_uint2(0u, 0u);
-  }
-  __syncthreads();
-  int pred = 0;
-  {
-    int prev;   // slot holding the previous block of the same component, stream order
-    if (MODE == SJPEG_HIP_YUV420) prev = (k == 0) ? tid - 3 : (k <= 3 ? tid - 1 : tid - 6);
-    else prev = tid - BPM;
-    const bool prev_in_halo = prev < BPM;
-    if (emits && !(prev_in_halo && !halo)) {
-      pred = static_cast<int>(reinterpret_cast<const uint32_t*>(smem + prev * kSlotBytes + 128)[3]);
-    }
-  }
-  uint32_t dc_word = 0;                            // dc_len << 24 | dc_bits (<= 22); 0 = emits nothing
-  if (emits) {
-    const int diff = dc_val - pred;
-    const int ad = diff < 0 ? -diff : diff;
-    const int n = 32 - __clz(ad);                 // 0 for diff == 0 (clz(0) == 32)
-    const uint32_t suffix = static_cast<uint32_t>(diff < 0 ? diff - 1 : diff) & ((1u << n) - 1u);
-    const uint32_t code = ldc[tbl * 12 + n];
-    dc_word = (((code & 0xffu) + n) << 24) | ((code >> 16) << n) | suffix;
-  }
-  tail[0] = nz_lo; tail[1] = nz_hi; tail[2] = dc_word;   // (the predictors live in tail[3])
-
-  if (KIND == kKindStats) {
-    // Symbol statistics for optimised Huffman tables (reference AddEntropyStats,
-    // src/entropy.cc:208-227): per table, counts of AC symbols (run << 4 | size, ZRL, EOB) and
-    // of DC size categories.  LDS counters, flushed as this workgroup's partial.
-    uint32_t* const lf = reinterpret_cast<uint32_t*>(smem + kOffStats);   // [2][272]: 256 AC then 16 DC
-    for (int i = tid; i < kStatsWords; i += kScanThreads) lf[i] = 0;
-    __syncthreads();
-    if (emits) {
-      uint32_t* const f = lf + tbl * 272;
-      {
-        const int diff = dc_val - pred;
-        const int ad = diff < 0 ? -diff : diff;
-        atomicAdd(&f[256 + (32 - __clz(ad))], 1u);
-      }
-      const uint16_t* const zz = reinterpret_cast<const uint16_t*>(slot);
-      unsigned long long m = (static_cast<unsigned long long>(nz_hi) << 32) | nz_lo;
-      int prev = 1;
-      while (m) {
-        const int i = __builtin_ctzll(m);
-        m &= m - 1;
-        const uint32_t mag = zz[i] & 0x7fffu;
-        const int run = i - prev;
-        prev = i + 1;
-        if (run >> 4) atomicAdd(&f[0xf0], static_cast<uint32_t>(run >> 4));
-        atomicAdd(&f[((run & 15) << 4) | (32 - __clz(mag))], 1u);
-      }
-      if (prev <= 63) atomicAdd(&f[0x00], 1u);
-    }
-    __syncthreads();
-    uint32_t* const dst = a.partial + (static_cast<size_t>(frame) * a.nseg + seg) * kStatsWords;
-    for (int i = tid; i < kStatsWords; i += kScanThreads) dst[i] = lf[i];
-    return;
-  }
-
-  // The run/size coding of a block (src/entropy.cc:161-198) is a serial walk over its non-zero
-  // coefficients, and a structured 4K picture averages 13 non-zeros per block but 45 for the
-  // worst block of a segment: one thread per block leaves the whole workgroup waiting for that
-  // one walk.  So a block is coded as up to four independent PARTS, one per quarter of the
-  // zig-zag scan (positions 1-15 with the DC, 16-31, 32-47, 48-63; empty quarters make no part).
-  // A part needs only the block's non-zero mask to know the run in front of its first symbol and
-  // whether it carries the EOB, and its bits are stitched at bit granularity like the blocks
-  // themselves.  Parts are handed to threads sorted by their number of non-zeros (counting sort,
-  // descending), 256 per round: walks of at most 16 symbols with similar trip counts per wave.
-  // The unit list and the part lengths live in the bit window, idle until the stitch.
-  uint32_t* const hist = win + kSortHist;          // [32], bins 0..16 (cleared before the DC barrier)
-  uint32_t* const bin_start = win + kSortHist + 32;   // [32]
-  uint16_t* const ulist = reinterpret_cast<uint16_t*>(win + 64);          // [1024] block | quarter << 8
-  uint16_t* const ulen = reinterpret_cast<uint16_t*>(win + 64 + 512);     // [256][4] bits per part
-  {
-    uint32_t c[4] = {static_cast<uint32_t>(__popc(nzq[0])), static_cast<uint32_t>(__popc(nzq[1])),
-                     static_cast<uint32_t>(__popc(nzq[2])), static_cast<uint32_t>(__popc(nzq[3]))};
-    uint32_t rank[4] = {0, 0, 0, 0};
-    if (emits) {
-      rank[0] = atomicAdd(&hist[c[0]], 1u);        // quarter 0 always makes a part (DC, EOB)
-#pragma unroll
-      for (int q = 1; q < 4; ++q) if (c[q] != 0u) rank[q] = atomicAdd(&hist[c[q]], 1u);
-    }
-    __syncthreads();
-    if (tid < 64) {                                // wave 0: exclusive scan over bins 16, 15, ... 0
-      const uint32_t h = tid <= 16 ? hist[16 - tid] : 0u;
-      uint32_t incl = h;
-#pragma unroll
-      for (int d = 1; d < 32; d <<= 1) {
-        const uint32_t y = __shfl_up(incl, d, 64);
-        if (tid >= d) incl += y;
-      }
-      if (tid <= 16) bin_start[16 - tid] = incl - h;
-      if (tid == 16) misc[9] = incl;               // number of parts
-    }
-    __syncthreads();
-    if (emits) {
-      ulist[bin_start[c[0]] + rank[0]] = static_cast<uint16_t>(tid);
-#pragma unroll
-      for (int q = 1; q < 4; ++q) {
-        if (c[q] != 0u) ulist[bin_start[c[q]] + rank[q]] = static_cast<uint16_t>(tid | (q << 8));
-      }
-    }
-    __syncthreads();
-  }
-  stamp(3);
-  const uint32_t n_units = misc[9];
-
-  // the walk reads 16-bit entries and writes 32-bit words in the same slot: no type-based reordering
-  typedef uint16_t __attribute__((may_alias)) u16_alias;
-  typedef uint32_t __attribute__((may_alias)) u32_alias;
-  constexpr int kEnd = 69;                         // "no more non-zeros": reads as a loaded frontier
-  constexpr uint32_t kNoSpill = 0xffffu;
-  uint32_t* const spill_wg = a.spill + (static_cast<size_t>(frame) * a.nseg + seg) * kScanThreads * kSpillWords;
-
-  // ONE walk codes a part.  The bits go, MSB-first, into the part's OWN quarter of the slot (8
-  // words over its 16 entries), over coefficients that were already consumed: word w replaces
-  // entries 2w and 2w + 1 and is only written once every entry up to 2w + 1 has been loaded.
-  // The rare word that would overtake the reader, or leave the quarter, goes to a global spill
-  // row instead, and so does everything after it.  The walk is software-pipelined by hand: the
-  // entry of the NEXT non-zero position and the Huffman word of the CURRENT one are in flight
-  // while the previous symbol is appended; unrolled by two with swapped roles so that an
-  // in-flight LDS value is never copied (a copy forces a wait).
-  auto walk = [&](uint32_t unit, uint32_t& len_out, uint32_t& spill_out) {
-    const int blk = static_cast<int>(unit & 255u), q = static_cast<int>(unit >> 8);
-    unsigned char* const bslot = smem + blk * kSlotBytes;
-    const uint32_t* const btail = reinterpret_cast<const uint32_t*>(bslot + 128);
-    const unsigned long long m_all = (static_cast<unsigned long long>(btail[1]) << 32) | btail[0];
-    const uint32_t b_dc = btail[2];
-    const int b_k = blk % BPM;
-    const int b_tbl = (MODE == SJPEG_HIP_YUV420) ? (b_k >= 4) : (MODE == SJPEG_HIP_YUV444 ? (b_k >= 1) : 0);
-    const uint32_t* const ac = lac + b_tbl * 256;
-    const u16_alias* const zz = reinterpret_cast<const u16_alias*>(bslot);   // bit 15 = negative, 14..0 = level
-    u32_alias* const bw = reinterpret_cast<u32_alias*>(bslot) + 8 * q;
-    uint32_t* const spill = spill_wg + blk * kSpillWords + 16 * q;
-    const uint32_t zrl = ac[0xf0], eob = ac[0x00];
-    const uint32_t zl = zrl & 0xffu;
-    const int sh = 16 * q;
-    uint32_t m = static_cast<uint32_t>(m_all >> sh) & 0xffffu;   // the part's own 16 positions
-    const unsigned long long below = m_all & ((1ull << sh) - 1ull);
-    const bool is_last = (q == 3) || ((m_all >> (sh + 16)) == 0ull);
-    int prev = below ? 64 - __builtin_clzll(below) : 1;       // position after the previous non-zero
-    unsigned long long acc = 0;                    // pending bits, right-aligned (upper bits stale)
-    uint32_t nacc = 0, wr = 0;                     // pending bit count (< 32), words produced
-    uint32_t wr_lim = 8;                           // words [0, wr_lim) may stay in the slot
-    const uint32_t wabs = 16u * static_cast<uint32_t>(q) + 1u;   // entry 2 * (8q + wr) + 1
-    auto next_pos = [&]() -> int { if (!m) return kEnd; const int i = __builtin_ctz(m); m &= m - 1; return sh + i; };
-    // branch-free but for the two predicated stores: most appends of a wave complete a word in
-    // some lane anyway
-    auto append = [&](uint32_t bits, uint32_t nb, int frontier) {   // 1 <= nb <= 31
-      acc = (acc << nb) | bits;
-      nacc += nb;
-      const bool full = nacc >= 32u;
-      nacc &= 31u;
-      const uint32_t word = static_cast<uint32_t>(acc >> nacc);
-      const bool in_place = (wr < wr_lim) & (2u * wr + wabs <= static_cast<uint32_t>(frontier));
-      if (full) {
-        if (in_place) bw[wr] = word; else spill[wr] = word;
-      }
-      wr_lim = (full & !in_place) ? (wr < wr_lim ? wr : wr_lim) : wr_lim;
-      wr += full ? 1u : 0u;
-    };
-    // stage A of entry (iC, eC): indices + issue the table read (codeOut); fetch next entry;
-    // stage B of the symbol before it (sIn = n | zr << 8 | suffix << 16, codeIn in flight).
-    auto step = [&](int iC, uint32_t eC, int& iN, uint32_t& eN,
-                    uint32_t codeIn, uint32_t sIn, bool vIn, uint32_t& codeOut, uint32_t& sOut) {
-      iN = next_pos();
-      eN = zz[iN];
-      const uint32_t mag = eC & 0x7fffu;
-      const int run = iC - prev;
-      prev = iC + 1;
-      const uint32_t n = 32u - __clz(mag);
-      const uint32_t ones = (1u << n) - 1u;
-      const uint32_t suffix = (eC & 0x8000u) ? (mag ^ ones) : mag;      // negative: ~mag on n bits
-      codeOut = ac[((run & 15) << 4) | n];
-      sOut = n | ((static_cast<uint32_t>(run) >> 4) << 8) | (suffix << 16);
-      if (vIn) {
-        const uint32_t pn = sIn & 0xffu;
-        for (uint32_t z = (sIn >> 8) & 0xffu; z > 0; --z) append(zrl >> 16, zl, iN);
-        append(((codeIn >> 16) << pn) | (sIn >> 16), (codeIn & 0xffu) + pn, iN);
-      }
-    };
-    int iA = next_pos(), iB = kEnd;
-    uint32_t eA = zz[iA], eB = 0, cA = 0, cB = 0, sA = 0, sB = 0;
-    if (q == 0) append(b_dc & 0xffffffu, b_dc >> 24, iA);
-    bool pend = false;                             // a symbol waits for stage B (in cA/sA)
-    while (iA != kEnd) {
-      step(iA, eA, iB, eB, cA, sA, pend, cB, sB);
-      if (iB == kEnd) { cA = cB; sA = sB; pend = true; break; }
-      step(iB, eB, iA, eA, cB, sB, true, cA, sA);
-      pend = true;
-    }
-    if (pend) {
-      const uint32_t pn = sA & 0xffu;
-      for (uint32_t z = (sA >> 8) & 0xffu; z > 0; --z) append(zrl >> 16, zl, kEnd);
-      append(((cA >> 16) << pn) | (sA >> 16), (cA & 0xffu) + pn, kEnd);
-    }
-    if (is_last && prev <= 63) append(eob >> 16, eob & 0xffu, kEnd);   // last non-zero index < 63
-    const uint32_t len = 32u * wr + nacc;
-    if (nacc != 0u) append(0u, 32u - nacc, kEnd);                        // left-align the last word
-    ulen[4 * blk + q] = static_cast<uint16_t>(len);
-    len_out = len;
-    spill_out = wr > wr_lim ? wr_lim : kNoSpill;
-  };
-
-  // what this thread coded in each round: unit | spill << 10 | len << 16, 0xffffffff = nothing.
-  // (four registers picked by the round counter: one copy of the walk for all rounds)
-  uint32_t ur0 = 0xffffffffu, ur1 = 0xffffffffu, ur2 = 0xffffffffu, ur3 = 0xffffffffu;
-  auto ur_get = [&](int r) { return r == 0 ? ur0 : r == 1 ? ur1 : r == 2 ? ur2 : ur3; };
-  // The list is sorted: handed out in order, wave 0's 64 parts would be the heaviest of every
-  // round and its SIMD the busiest of the CU.  The waves draw groups of 64 parts from a queue
-  // instead (heaviest first, at most four each: 4 x 4 covers the 16 groups of a full segment).
-  const uint32_t n_groups = (n_units + 63u) >> 6;
-  for (int r = 0; r < 4; ++r) {
-    uint32_t grp = 0;
-    if ((tid & 63) == 0) grp = atomicAdd(&misc[10], 1u);
-    grp = __builtin_amdgcn_readfirstlane(grp);
-    if (grp >= n_groups) break;
-    const uint32_t idx = grp * 64u + (tid & 63u);
-    if (idx < n_units) {
-      const uint32_t unit = ulist[idx];
-      uint32_t len, wsp;
-      walk(unit, len, wsp);
-      const uint32_t rec = unit | ((wsp & 31u) << 10) | (len << 16);   // spill index 0..15, 31 = none
-      if (r == 0) ur0 = rec; else if (r == 1) ur1 = rec; else if (r == 2) ur2 = rec; else ur3 = rec;
-    }
-  }
-  __syncthreads();
-  stamp(4);
-  // offsets are a prefix sum in STREAM order (thread tid owns block tid here); the lengths of
-  // the first three parts stay with the block so that every part can find its own offset
-  uint32_t total;
-  {
-    const uint2 L = *reinterpret_cast<const uint2*>(ulen + 4 * tid);
-    const uint32_t l0 = L.x & 0xffffu, l1 = L.x >> 16, l2 = L.y & 0xffffu, l3 = L.y >> 16;
-    tail[2] = l0 | (l1 << 10) | (l2 << 20);
-    const uint32_t my_start = wg_exclusive_scan<kScanThreads>(l0 + l1 + l2 + l3, misc, &total);
-    tail[3] = my_start;
-  }
-  if (a.ablate == 3) { if (tid == 0) a.seg_nbits[static_cast<size_t>(frame) * a.nseg + seg] = total; return; }
-  __syncthreads();
-  uint32_t us0 = 0, us1 = 0, us2 = 0, us3 = 0;     // bit offset of each of them in the segment
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const uint32_t rec = ur_get(r);
-    if (rec != 0xffffffffu) {
-      const uint32_t* const btail = reinterpret_cast<const uint32_t*>(smem + (rec & 255u) * kSlotBytes + 128);
-      const uint32_t pk = btail[2], q = (rec >> 8) & 3u;
-      const uint32_t l0 = pk & 1023u, l1 = (pk >> 10) & 1023u, l2 = (pk >> 20) & 1023u;
-      const uint32_t st = btail[3] + (q >= 1u ? l0 : 0u) + (q >= 2u ? l1 : 0u) + (q >= 3u ? l2 : 0u);
-      if (r == 0) us0 = st; else if (r == 1) us1 = st; else if (r == 2) us2 = st; else us3 = st;
-    }
-  }
-  auto us_get = [&](int r) { return r == 0 ? us0 : r == 1 ? us1 : r == 2 ? us2 : us3; };
-
-  stamp(5);
-  // Stitch: every part's words are shifted to its bit offset and ORed into the LDS window,
-  // round by round (one round unless the segment overflows the window); the window is flushed
-  // coalesced to the segment's slot.
-  uint32_t* const out_words = a.seg_words + (static_cast<size_t>(frame) * a.nseg + seg) * a.slot_words;
-  uint32_t base = 0;                               // bit position of window word 0, multiple of 32
-  uint32_t carry = 0;
-  auto place = [&](uint32_t rec, uint32_t start) {
-    const uint32_t blk = rec & 255u, q = (rec >> 8) & 3u, len = rec >> 16;
-    const uint32_t wr_spill = ((rec >> 10) & 31u) == 31u ? kNoSpill : ((rec >> 10) & 31u);
-    const u32_alias* const bw = reinterpret_cast<const u32_alias*>(smem + blk * kSlotBytes) + 8 * q;
-    const uint32_t* const spill = spill_wg + blk * kSpillWords + 16 * q;
-    const uint32_t nw = (len + 31u) >> 5;
-    const uint32_t pos = start - base;
-    const uint32_t o = pos & 31u;
-    uint32_t* const dst = win + (pos >> 5);
-    uint32_t before = 0;                           // source word j - 1
-    if (wr_spill == kNoSpill) {                    // nw <= 8, all inside the quarter
-      for (uint32_t j0 = 0; j0 < nw; j0 += 4) {
-        const uint4 v4 = *reinterpret_cast<const uint4*>(bw + j0);
-        uint32_t v[4] = {v4.x, v4.y, v4.z, v4.w};
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const uint32_t j = j0 + u;
-          if (j >= nw) v[u] = 0;
-          if (j <= nw) atomicOr(dst + j, __builtin_amdgcn_alignbit(before, v[u], o));   // (before:v) >> o
-          before = v[u];
-        }
-      }
-    } else {
-      for (uint32_t j = 0; j < ((nw + 3u) & ~3u); ++j) {                // same schedule, word by word
-        uint32_t v = 0;
-        if (j < nw) v = (j < wr_spill) ? bw[j] : spill[j];
-        if (j <= nw) atomicOr(dst + j, __builtin_amdgcn_alignbit(before, v, o));
-        before = v;
-      }
-    }
-    if ((nw & 3u) == 0u && o != 0u) atomicOr(dst + nw, before << (32u - o));
-  };
-  uint32_t pending = 0;                            // bit r: part of round r still has to be placed
-#pragma unroll
-  for (int r = 0; r < 4; ++r) if (ur_get(r) != 0xffffffffu) pending |= 1u << r;
-  for (;;) {
-    for (int i = tid; i < kWinWords / 4; i += kScanThreads) reinterpret_cast<uint4*>(win)[i] = make_uint4(0, 0, 0, 0);
-    if (tid == 0) win[kWinWords] = 0;
-    // the usual case -- the rest of the segment fits the window -- needs no vote
-    const bool all_fit = total <= base + kWinWords * 32u;            // uniform
-    if (!all_fit && tid == 0) misc[8] = total;
-    __syncthreads();
-    if (tid == 0 && carry != 0) atomicOr(&win[0], carry);
-    uint32_t fits = 0;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      if (pending & (1u << r)) {
-        if (all_fit || us_get(r) + (ur_get(r) >> 16) <= base + kWinWords * 32u) fits |= 1u << r;
-        else atomicMin(&misc[8], us_get(r));
-      }
-    }
-    if (!all_fit) __syncthreads();
-    // everything that starts before the first non-fitting part (stream order) is placed now
-    const uint32_t limit = all_fit ? total : misc[8];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      if ((fits & (1u << r)) && us_get(r) < limit) {
-        place(ur_get(r), us_get(r));
-        pending &= ~(1u << r);
-      }
-    }
-    __syncthreads();
-    stamp(6);
-    const uint32_t filled = limit - base;          // bits valid in the window
-    const bool last = (limit == total);
-    const uint32_t nfull = last ? (filled + 31) >> 5 : filled >> 5;
-    for (uint32_t i = tid; i < nfull; i += kScanThreads) out_words[(base >> 5) + i] = win[i];
-    if (last) break;
-    carry = win[filled >> 5];                      // partial word carried into the next window
-    base += filled & ~31u;
-    __syncthreads();
-  }
-  if (tid == 0) a.seg_nbits[static_cast<size_t>(frame) * a.nseg + seg] = total;
-  stamp(7);
-}
-
-// ------------------------------------------------------------------------------------
-// Sums the per-workgroup partial statistics of one frame: out[frame][i] = sum over segments.
-// BYTES: partial words hold four 8-bit counters (histogram) -> four u32 outputs per word.
-template <bool BYTES>
-__global__ __launch_bounds__(kThreads) void reduce_partials(const uint32_t* part, int nseg, int words,
-                                                           uint32_t* out) {
-  // blockIdx.z = slice of the segments: a thread adds up its slice (independent loads, unrolled)
-  // and the slices meet in the output with atomics (cleared by the caller).  One thread walking
-  // all ~800 partials of a 4K frame was a chain of loads: 0.15 ms of a 0.23 ms histogram pass.
-  const int frame = blockIdx.y;
-  const int w = blockIdx.x * kThreads + threadIdx.x;
-  if (w >= words) return;
-  const int per = (nseg + gridDim.z - 1) / gridDim.z;
-  const int s0 = blockIdx.z * per, s1 = min(nseg, s0 + per);
-  const uint32_t* src = part + static_cast<size_t>(frame) * nseg * words + w;
-  if (BYTES) {
-    uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;
-#pragma unroll 8
-    for (int s = s0; s < s1; ++s) {
-      const uint32_t v = src[static_cast<size_t>(s) * words];
-      c0 += v & 0xffu; c1 += (v >> 8) & 0xffu; c2 += (v >> 16) & 0xffu; c3 += v >> 24;
-    }
-    uint32_t* dst = out + (static_cast<size_t>(frame) * words + w) * 4;
-    if (c0) atomicAdd(&dst[0], c0);
-    if (c1) atomicAdd(&dst[1], c1);
-    if (c2) atomicAdd(&dst[2], c2);
-    if (c3) atomicAdd(&dst[3], c3);
-  } else {
-    uint32_t sum = 0;
-#pragma unroll 8
-    for (int s = s0; s < s1; ++s) sum += src[static_cast<size_t>(s) * words];
-    if (sum) atomicAdd(&out[static_cast<size_t>(frame) * words + w], sum);
-  }
-}
-
-__global__ __launch_bounds__(kThreads) void reduce_error(const unsigned long long* part, int nseg,
-                                                        unsigned long long* out) {
-  __shared__ unsigned long long red[kThreads / 64];
-  const int frame = blockIdx.x;
-  unsigned long long sum = 0;
-  for (int s = threadIdx.x; s < nseg; s += kThreads) sum += part[static_cast<size_t>(frame) * nseg + s];
-  for (int d = 32; d > 0; d >>= 1) sum += __shfl_xor(sum, d, 64);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sum;
-  __syncthreads();
-  if (threadIdx.x == 0) out[frame] = red[0] + red[1] + red[2] + red[3];
-}
-
-// ------------------------------------------------------------------------------------
-// The bin loops of AnalyseHisto (reference src/histogram.cc:150-205) on the device-resident
-// histogram: one small workgroup per (frame, table, position), one thread per candidate step.
-// Integer sums only (see jpeg_host.cc AdaptSums: the reference's double accumulators hold exactly
-// these integers); the regression and the choice of the step stay on the host.
-struct AdaptArgs {
-  const uint32_t* hist;             // [nframes][2][64][128]
-  long long* sums;                  // [nframes][2][64][25][2]: bits, distortion (INT64_MIN = not a candidate)
-  int* totlast;                     // [nframes][2][64][2]: population, highest occupied bin + 1
-  uint8_t quant[2][64], min_quant[2][64];
-};
-__global__ __launch_bounds__(32) void adapt_sums_kernel(const AdaptArgs a) {
-  const int pos = blockIdx.x, idx = blockIdx.y, frame = blockIdx.z, delta = threadIdx.x;
-  const uint32_t* const h = a.hist + ((static_cast<size_t>(frame) * 2 + idx) * 64 + pos) * 128;
-  int total = 0, last = 0;
-  for (int i = 0; i < 128; ++i) {
-    const uint32_t hi = h[i];
-    total += static_cast<int>(hi);
-    if (hi) last = i + 1;
-  }
-  const size_t cell = (static_cast<size_t>(frame) * 2 + idx) * 64 + pos;
-  if (delta == 0) { a.totlast[cell * 2] = total; a.totlast[cell * 2 + 1] = last; }
-  if (delta >= 25) return;
-  const int dq = static_cast<int>(a.quant[idx][pos]) + (delta - 12);
-  long long bsum = 0, dsum = 0;
-  if (dq < static_cast<int>(a.min_quant[idx][pos]) || dq > 255) {
-    dsum = static_cast<long long>(0x8000000000000000ull);
-  } else {
-    const uint32_t idq = static_cast<uint32_t>(((1 << 16) + dq - 1) / dq);
-    for (int i = 0; i < last; ++i) {
-      const uint32_t hi = h[i];
-      const uint32_t v = (static_cast<uint32_t>(i) << 2) + 2;
-      const uint32_t qv = (v * idq + (1u << 16 >> 1)) >> 16;
-      const uint32_t bits = 32u - __clz(qv);                        // 0 for qv == 0
-      const uint32_t d = v - qv * static_cast<uint32_t>(dq);
-      bsum += static_cast<int>(hi * bits);
-      dsum += static_cast<int>(hi * (d * d));
-    }
-  }
-  a.sums[(cell * 25 + delta) * 2] = bsum;
-  a.sums[(cell * 25 + delta) * 2 + 1] = dsum;
-}
-
-// ------------------------------------------------------------------------------------
-// K2: per frame, exclusive scan of segment bit lengths
-
-struct StitchArgs {
-  int nseg, nframes;
-  const uint32_t* seg_nbits;
-  unsigned long long* seg_off;       // [nframes][nseg+1]
-  const uint32_t* seg_words;
-  uint32_t slot_words;
-  uint32_t* ubuf;                    // [nframes][ubuf_words] un-stuffed stream, MSB-first words
-  size_t ubuf_words;
-  uint32_t* chunk_ff;                // [nframes][max_chunks]
-  unsigned long long* chunk_off;     // [nframes][max_chunks]
-  uint32_t max_chunks;
-  const uint8_t* header;
-  uint32_t header_size;
-  const uint32_t* hdr_off;           // per-frame headers: frame f owns header[hdr_off[f] .. hdr_off[f+1]) (else NULL: one for all)
-  int append_eoi;
-  uint8_t* out;
-  size_t out_stride;
-  unsigned long long* sizes;
-  const unsigned long long* seg_nbits64;   // band stitch: lengths as uint64 (else NULL)
-  unsigned long long* total_bits_out;      // band encode: where the bit count of the band goes (else NULL)
-  uint32_t subs;                           // K3: waves per segment (1 unless segments are whole bands)
-};
-
-__global__ __launch_bounds__(kThreads) void scan_seg_offsets(const StitchArgs a) {
-  __shared__ uint32_t scratch[16];
-  const int frame = blockIdx.x;
-  const uint32_t* nb = a.seg_nbits + static_cast<size_t>(frame) * a.nseg;
-  unsigned long long* off = a.seg_off + static_cast<size_t>(frame) * (a.nseg + 1);
-  unsigned long long running = 0;
-  for (int base = 0; base < a.nseg; base += kThreads) {
-    const int i = base + threadIdx.x;
-    // (a band is shorter than 2^32 bits: sjpeg_hip_stitch_bands checks its capacity)
-    const uint32_t x = i >= a.nseg ? 0u
-                     : a.seg_nbits64 != nullptr ? static_cast<uint32_t>(a.seg_nbits64[static_cast<size_t>(frame) * a.nseg + i])
-                                                : nb[i];
-    uint32_t total;
-    const uint32_t ex = wg_exclusive_scan<kThreads>(x, scratch, &total);
-    if (i < a.nseg) off[i] = running + ex;
-    running += total;
-  }
-  if (threadIdx.x == 0) {
-    off[a.nseg] = running;
-    if (a.total_bits_out != nullptr) a.total_bits_out[frame] = running;
-  }
-  // K3 accumulates the 0xFF counts of the chunks with atomics: clear the ones this frame uses
-  const unsigned long long U = (running + 7) >> 3;
-  const uint32_t nchunks = static_cast<uint32_t>((U + kChunkBytes - 1) / kChunkBytes);
-  uint32_t* ff = a.chunk_ff + static_cast<size_t>(frame) * a.max_chunks;
-  for (uint32_t i = threadIdx.x; i < nchunks; i += kThreads) ff[i] = 0;
-}
-
-// ------------------------------------------------------------------------------------
-// K3: place every segment in the continuous bit stream, and count 0xFF bytes per 4 KiB chunk
-
-__device__ __forceinline__ uint32_t count_ff(uint32_t w, int nbytes /*valid leading bytes, MSB first*/) {
-  uint32_t n = 0;
-#pragma unroll
-  for (int b = 0; b < 4; ++b) {
-    if (b < nbytes && ((w >> (24 - 8 * b)) & 0xffu) == 0xffu) ++n;
-  }
-  return n;
-}
-
-// One WAVE per SEGMENT (scatter form): a segment knows where its bits go (seg_off); its
-// words are read coalesced, funnel-shifted to the destination alignment, and every word of the
-// continuous stream whose FIRST bit lies inside the segment is written.  Only the last of those
-// words needs bits of the following segment(s), or the final 1-bit padding
-// (src/bit_writer.cc:107-116).  0xFF bytes are counted per 4 KiB chunk of the stream (atomics;
-// cleared by K2).
-// The kernel is latency-bound by construction (a few KB per workgroup), so the dependent chain
-// is cut to ONE round trip: destination word i always needs source words i and i + 1 whatever
-// the offset (only the shift depends on it), so the first kSpec batches of source words are
-// requested before the offsets have arrived.  Earlier forms (a workgroup per 4 KiB chunk with a
-// search; per group of segments) spent 35-50 us in chains of 3-5 dependent loads.
-constexpr int kSpec = 12;                                   // speculative batches of 64 words: segments up to 3 KiB
-constexpr int kPlaceLanes = 64;                             // one WAVE per segment, four segments per workgroup
-__global__ __launch_bounds__(kThreads) void place_segments(const StitchArgs a) {
-  const int frame = blockIdx.y;
-  // a wave takes words [sub * kSpec * 64, ...) of one segment; normal segments have one wave
-  // (subs == 1, the loop below takes the rare longer rest), whole bands are cut into many
-  const uint32_t unit = blockIdx.x * (kThreads / kPlaceLanes) + (threadIdx.x >> 6);
-  const int sc0 = static_cast<int>(unit / a.subs);
-  const uint32_t ibase = (unit % a.subs) * (kSpec * kPlaceLanes);
-  if (sc0 >= a.nseg) return;
-  const unsigned long long* off = a.seg_off + static_cast<size_t>(frame) * (a.nseg + 1);
-  const uint32_t* segw = a.seg_words + static_cast<size_t>(frame) * a.nseg * a.slot_words;
-  const uint32_t* src = segw + static_cast<size_t>(sc0) * a.slot_words;
-  uint32_t spec[kSpec][2];
-#pragma unroll
-  for (int k = 0; k < kSpec; ++k) {                          // inside the slot whatever the length
-    const uint32_t i = min(ibase + k * kPlaceLanes + (threadIdx.x & 63), a.slot_words - 2u);
-    spec[k][0] = src[i];
-    spec[k][1] = src[i + 1];
-  }
-  const unsigned long long b0 = off[sc0], b1 = off[sc0 + 1];
-  const unsigned long long T = off[a.nseg];                 // total bits
-  const unsigned long long U = (T + 7) >> 3;                // bytes incl. 1-bit padding
-  uint32_t* ub = a.ubuf + static_cast<size_t>(frame) * a.ubuf_words;
-  uint32_t* cff = a.chunk_ff + static_cast<size_t>(frame) * a.max_chunks;
-  const int lane = threadIdx.x & 63;
-  const unsigned long long wbeg = (b0 + 31) >> 5;
-  const unsigned long long wend = (sc0 == a.nseg - 1) ? ((U + 3) >> 2) : ((b1 + 31) >> 5);
-  const uint32_t nwords = static_cast<uint32_t>(wend - wbeg);
-  const uint32_t lead = static_cast<uint32_t>(wbeg * 32 - b0);           // bits of the segment in front of word wbeg (< 32)
-  const uint32_t len = static_cast<uint32_t>(b1 - b0);
-  uint32_t* dst = ub + wbeg;
-  const uint32_t wbase = static_cast<uint32_t>(wbeg);                     // < 2^32 words per frame
-  uint32_t ff_acc = 0;                                      // 0xFF bytes seen by this lane in chunk ff_chunk
-  uint32_t ff_chunk = 0xffffffffu;                          // wave-uniform
-  auto ff_flush = [&]() {
-    uint32_t sum = ff_acc;
-    for (int d = 32; d > 0; d >>= 1) sum += __shfl_down(sum, d, 64);
-    if (lane == 0 && sum != 0u) atomicAdd(&cff[ff_chunk], sum);
-    ff_acc = 0;
-  };
-  auto one = [&](uint32_t i, uint32_t v0, uint32_t v1) {
-    uint32_t ffs = 0;
-    if (i < nwords) {
-      const uint32_t r = lead + 32u * i;                                  // first source bit of this word
-      uint32_t outw;
-      if (r + 32u <= len) {
-        outw = lead ? __builtin_amdgcn_alignbit(v0, v1, 32u - lead) : v0;   // (v0:v1) >> (32 - lead)
-      } else {
-        // the word that runs over the end of the segment: finish it from the next ones
-        outw = 0;
-        int need = 32, sc = sc0;
-        unsigned long long p = (wbeg + i) * 32, c_beg = b0, c_end = b1;
-        while (need > 0 && p < T) {
-          while (p >= c_end) { ++sc; c_beg = c_end; c_end = off[sc + 1]; }
-          const unsigned long long avail = c_end - p;
-          const int take = avail < static_cast<unsigned long long>(need) ? static_cast<int>(avail) : need;
-          const uint32_t rr = static_cast<uint32_t>(p - c_beg);
-          const uint32_t* q = segw + static_cast<size_t>(sc) * a.slot_words + (rr >> 5);
-          const unsigned long long two = (static_cast<unsigned long long>(q[0]) << 32) | q[1];
-          const uint32_t bits = static_cast<uint32_t>((two << (rr & 31)) >> (64 - take));
-          outw |= bits << (need - take);
-          need -= take;
-          p += take;
-        }
-        if (need > 0) outw |= (need == 32) ? 0xffffffffu : ((1u << need) - 1u);   // past the end: 1-bits
-      }
-      dst[i] = outw;
-      const unsigned long long byte0 = (wbeg + i) * 4;
-      const int valid = byte0 >= U ? 0 : (U - byte0 >= 4 ? 4 : static_cast<int>(U - byte0));
-      ffs = count_ff(outw, valid);
-    }
-    // the 64 words of a wave sit in one chunk unless they straddle a boundary
-    const uint32_t chunk = (wbase + i) >> 10;
-    const uint32_t chunk0 = __builtin_amdgcn_readfirstlane(chunk);
-    if (chunk0 != ff_chunk) {                                // uniform
-      if (ff_chunk != 0xffffffffu) ff_flush();
-      ff_chunk = chunk0;
-    }
-    if (chunk == chunk0) ff_acc += ffs;
-    else if (ffs != 0u) atomicAdd(&cff[chunk], ffs);
-  };
-#pragma unroll
-  for (int k = 0; k < kSpec; ++k) {
-    if (ibase + static_cast<uint32_t>(k) * kPlaceLanes < nwords) one(ibase + k * kPlaceLanes + lane, spec[k][0], spec[k][1]);
-  }
-  if (a.subs == 1u) {
-    for (uint32_t i0 = kSpec * kPlaceLanes; i0 < nwords; i0 += kPlaceLanes) {
-      const uint32_t i = i0 + lane;
-      one(i, src[i], src[i + 1]);
-    }
-  }
-  if (ff_chunk != 0xffffffffu) ff_flush();
-}
-
-// ------------------------------------------------------------------------------------
-// K4: per frame, exclusive scan of per-chunk 0xFF counts; final stream size
-
-__global__ __launch_bounds__(kThreads) void scan_chunk_offsets(const StitchArgs a) {
-  __shared__ uint32_t scratch[16];
-  const int frame = blockIdx.x;
-  const unsigned long long T = a.seg_off[static_cast<size_t>(frame) * (a.nseg + 1) + a.nseg];
-  const unsigned long long U = (T + 7) >> 3;
-  const uint32_t nchunks = static_cast<uint32_t>((U + kChunkBytes - 1) / kChunkBytes);
-  const uint32_t* ff = a.chunk_ff + static_cast<size_t>(frame) * a.max_chunks;
-  unsigned long long* co = a.chunk_off + static_cast<size_t>(frame) * a.max_chunks;
-  unsigned long long running = 0;
-  for (uint32_t base = 0; base < nchunks; base += kThreads) {
-    const uint32_t i = base + threadIdx.x;
-    const uint32_t x = i < nchunks ? ff[i] : 0u;
-    uint32_t total;
-    const uint32_t ex = wg_exclusive_scan<kThreads>(x, scratch, &total);
-    if (i < nchunks) co[i] = running + ex;
-    running += total;
-  }
-  // a frame that does not fit the caller's slot reports size 0 and is not written
-  const unsigned long long body = U + running;
-  const uint32_t hoff = a.hdr_off ? a.hdr_off[frame] : 0u;
-  const uint32_t hsize = a.hdr_off ? a.hdr_off[frame + 1] - hoff : a.header_size;
-  const unsigned long long size = hsize + body + (a.append_eoi ? 2 : 0);
-  const bool fits = size <= a.out_stride;
-  uint8_t* dst = a.out + static_cast<size_t>(frame) * a.out_stride;
-  if (threadIdx.x == 0) {
-    if (fits && a.append_eoi) {
-      dst[hsize + body] = 0xff;
-      dst[hsize + body + 1] = 0xd9;
-    }
-    a.sizes[frame] = fits ? size : 0ull;
-  }
-  // header bytes in front of the entropy segment
-  if (fits) {
-    for (uint32_t i = threadIdx.x; i < hsize; i += kThreads) dst[i] = a.header[hoff + i];
-  }
-}
-
-// ------------------------------------------------------------------------------------
-// K5: byte stuffing into the caller's slot
-
-__global__ __launch_bounds__(kThreads) void stuff_chunks(const StitchArgs a) {
-  __shared__ uint32_t scratch[16];
-  // stuffed bytes of one chunk (<= 2 * 4 KiB), placed so that LDS words line up with the
-  // 4-byte words of the destination: the copy-out is aligned dword stores
-  __shared__ __attribute__((aligned(16))) uint8_t stage[2 * kChunkBytes + 16];
-  const int frame = blockIdx.y;
-  const unsigned long long T = a.seg_off[static_cast<size_t>(frame) * (a.nseg + 1) + a.nseg];
-  const unsigned long long U = (T + 7) >> 3;
-  const uint32_t nchunks = static_cast<uint32_t>((U + kChunkBytes - 1) / kChunkBytes);
-  const uint32_t* ub = a.ubuf + static_cast<size_t>(frame) * a.ubuf_words;
-  const unsigned long long* co = a.chunk_off + static_cast<size_t>(frame) * a.max_chunks;
-  const uint32_t hsize = a.hdr_off ? a.hdr_off[frame + 1] - a.hdr_off[frame] : a.header_size;
-  uint8_t* const dst0 = a.out + static_cast<size_t>(frame) * a.out_stride + hsize;
-  if (a.sizes[frame] == 0) return;                          // did not fit (see K4)
-  for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
-    const unsigned long long w0 = static_cast<unsigned long long>(chunk) * kChunkWords + threadIdx.x * 4;
-    const unsigned long long byte0 = w0 * 4;
-    uint4 q = make_uint4(0, 0, 0, 0);
-    int valid = 0;
-    if (byte0 < U) {
-      q = *reinterpret_cast<const uint4*>(ub + w0);
-      valid = (U - byte0 >= 16) ? 16 : static_cast<int>(U - byte0);
-    }
-    const uint32_t w[4] = {q.x, q.y, q.z, q.w};
-    uint32_t ffs = 0;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) ffs += count_ff(w[j], valid - 4 * j);
-    uint32_t total_ff;
-    const uint32_t ex = wg_exclusive_scan<kThreads>(ffs, scratch, &total_ff);
-    uint8_t* const dchunk = dst0 + static_cast<unsigned long long>(chunk) * kChunkBytes + co[chunk];
-    const uint32_t mis = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(dchunk) & 3u);
-    uint8_t* sp = stage + mis + threadIdx.x * 16 + ex;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      if (j < valid) {
-        const uint8_t b = static_cast<uint8_t>(w[j >> 2] >> (24 - 8 * (j & 3)));
-        *sp++ = b;
-        if (b == 0xff) *sp++ = 0x00;
-      }
-    }
-    __syncthreads();
-    const unsigned long long rest = U - static_cast<unsigned long long>(chunk) * kChunkBytes;
-    const uint32_t nbytes = static_cast<uint32_t>(rest < kChunkBytes ? rest : kChunkBytes) + total_ff;
-    // bytes [mis, mis + nbytes) of `stage` go to dchunk - mis + [mis, ...): whole words in
-    // the middle, single bytes at the two ragged ends
-    uint8_t* const dalign = dchunk - mis;
-    const uint32_t lo = mis, hi = mis + nbytes;
-    const uint32_t first_full = (lo + 3u) & ~3u, last_full = hi & ~3u;
-    if (first_full <= last_full) {
-      for (uint32_t i = first_full / 4 + threadIdx.x; i < last_full / 4; i += kThreads) {
-        reinterpret_cast<uint32_t*>(dalign)[i] = reinterpret_cast<const uint32_t*>(stage)[i];
-      }
-      if (threadIdx.x < first_full - lo) dalign[lo + threadIdx.x] = stage[lo + threadIdx.x];
-      if (threadIdx.x < hi - last_full) dalign[last_full + threadIdx.x] = stage[last_full + threadIdx.x];
-    } else {
-      if (threadIdx.x < nbytes) dalign[lo + threadIdx.x] = stage[lo + threadIdx.x];
-    }
-    __syncthreads();
-  }
-}
+#include "scan_device.h"
+#include "scan_segments.h"
+#include "scan_reduce.h"
+#include "stitch_kernels.h"
 
 // ------------------------------------------------------------------------------------
 // host side
