@@ -277,6 +277,8 @@ struct Encoder {
 
   bool Run();
 
+  bool RunImpl();
+
  private:
   HostSource src_;
   int W_, H_;
@@ -293,7 +295,21 @@ struct Encoder {
   bool search_ok_ = true;
 };
 
+// The API promises "no exceptions" (include/sjpeg.h): a failed host allocation inside the pipeline
+// (std::vector / std::string growth) ends the encode like any other failure.
 bool Encoder::Run() {
+  try {
+    return RunImpl();
+  } catch (const std::bad_alloc&) {
+    sink_->Reset();
+    return Fail("out of host memory");
+  } catch (...) {
+    sink_->Reset();
+    return Fail("unexpected exception in the encoder");
+  }
+}
+
+bool Encoder::RunImpl() {
   sink_->Reset();                                                   // src/enc.cc:90
   if (W_ > 65535 || H_ > 65535) return Fail("dimension > 65535");   // src/enc.cc:406
   if (src_.format == SJPEG_HIP_SRC_GRAY) yuv_mode_ = SJPEG_YUV_400;                 // src/encoders.cc:256-276

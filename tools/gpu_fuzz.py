@@ -43,4 +43,25 @@ for it in range(12):
             if got != want:
                 bad += 1
                 print("MISMATCH ones", w, h, mode, method)
+# batches with per-frame tables and headers (sjpeg_hip_*_multi): mixed content in one launch
+for it in range(N // 6):
+    w, h = int(rng.choice([1, 8, 17, 100, 257, 640])), int(rng.choice([1, 8, 33, 99, 360]))
+    f = int(rng.randint(1, 6))
+    imgs = []
+    for k in range(f):
+        u = rng.rand()
+        if u < 0.4:
+            imgs.append(rng.randint(0, 256, (h, w, 3)).astype(np.uint8))
+        elif u < 0.7:
+            imgs.append(synth.g_struct(w, h, int(rng.randint(1 << 30))))
+        else:
+            imgs.append(np.full((h, w, 3), int(rng.randint(256)), np.uint8))
+    mode = int(rng.choice([1, 3, 4]))
+    q = float(rng.choice([1, 30, 75, 95, 100]))
+    m = int(rng.choice([0, 1, 3, 4, 6]))
+    got = sj.encode_device_method(torch.from_numpy(np.stack(imgs)).cuda(), q, mode, m, engine=eng)
+    for k in range(f):
+        if got[k] != o.encode_method(imgs[k], q, mode, m):
+            bad += 1
+            print("MISMATCH batch", w, h, f, k, mode, q, m)
 print("fuzz done, mismatches:", bad)
