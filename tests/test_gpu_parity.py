@@ -274,6 +274,40 @@ def test_multi_rejects_bad_header_offsets(engine):
     assert rc != 0 and "header_offsets" in sj.lib().sjpeg_hip_last_error().decode()
 
 
+def test_row_offsets_beyond_2_31_bytes(engine, oracle):
+    """64-bit addressing: rows whose byte offset in the source passes 2^31 (and 2^32).  The same
+    pixels coded from a contiguous buffer are the expected bytes (a stride never changes the
+    output).  The reference itself addresses MCUs with 32-bit ints (src/encoders.cc:171,207,240)
+    and is not a checker past 2^31: DESIGN.md section 6, tools/huge_frame_vs_oracle.py."""
+    w, h = 200, 120
+    img = synth.g_struct(w, h, 2468)
+    stride = 40 * 1000 * 1000 + 16                 # row 54 starts beyond 2^31, row 108 beyond 2^32
+    big = torch.empty(h * stride, dtype=torch.uint8, device="cuda")
+    rows = big.as_strided((1, h, w * 3), (h * stride, stride, 1))
+    rows.copy_(torch.from_numpy(img).cuda().view(1, h, w * 3))
+    t, q = sj.make_tables(quality=80.0)
+    for mode in (1, 3, 4):
+        src, _ = sj.make_source(sj.SRC_RGB, [rows])
+        out, sizes = engine.encode_source(src, 1, w, h, t, sj.make_header(w, h, mode, q), mode)
+        torch.cuda.synchronize()
+        got = bytes(out[0, :int(sizes[0])].cpu().numpy())
+        assert got == oracle.encode(img, 80.0, mode), mode
+    # a planar source with the same property (luma plane of a 4:2:0 source)
+    cw, ch = (w + 1) // 2, (h + 1) // 2
+    rng = np.random.RandomState(3)
+    yp = rng.randint(0, 256, (h, w)).astype(np.uint8)
+    up = rng.randint(0, 256, (ch, cw)).astype(np.uint8)
+    vp = rng.randint(0, 256, (ch, cw)).astype(np.uint8)
+    ybig = big.as_strided((1, h, w), (h * stride, stride, 1))
+    ybig.copy_(torch.from_numpy(yp).cuda().view(1, h, w))
+    want = sj.encode_source_method(5, [torch.from_numpy(yp).cuda().unsqueeze(0), torch.from_numpy(up).cuda().unsqueeze(0),
+                                       torch.from_numpy(vp).cuda().unsqueeze(0)], w, h, 80.0, 1, 0, engine=engine)
+    got = sj.encode_source_method(5, [ybig, torch.from_numpy(up).cuda().unsqueeze(0),
+                                      torch.from_numpy(vp).cuda().unsqueeze(0)], w, h, 80.0, 1, 0, engine=engine)
+    assert got == want
+    del big
+
+
 def test_c5_recompress_default_params(engine, digests):
     d = digests["recompress|r90|default"]
     src = np.array(digests["recompress|r90|m0"]["source_quant"], np.uint8).reshape(2, 64)
