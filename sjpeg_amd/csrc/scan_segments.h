@@ -722,8 +722,9 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
   uint32_t ur0 = 0xffffffffu, ur1 = 0xffffffffu, ur2 = 0xffffffffu, ur3 = 0xffffffffu;
   auto ur_get = [&](int r) { return r == 0 ? ur0 : r == 1 ? ur1 : r == 2 ? ur2 : ur3; };
   // The list is sorted: handed out in order, wave 0's 64 parts would be the heaviest of every
-  // round and its SIMD the busiest of the CU.  The waves draw groups of 64 parts from a queue
-  // instead (heaviest first, at most four each: 4 x 4 covers the 16 groups of a full segment).
+  // round and the other waves would wait for it at the barrier below.  The waves draw groups of
+  // 64 parts from a queue instead (heaviest first, at most four each: 4 x 4 covers the 16 groups
+  // of a full segment).  Measured: K1 1.194 -> 1.16 ms per 64 4K frames.
   const uint32_t n_groups = (n_units + 63u) >> 6;
   for (int r = 0; r < 4; ++r) {
     uint32_t grp = 0;
