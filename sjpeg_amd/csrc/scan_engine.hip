@@ -114,6 +114,12 @@ struct sjpeg_hip_engine {
   int device = 0;
   DevBuf<DevTables> tables;
   DevBuf<uint8_t> header;
+  // what the two buffers hold, and the stream that put it there: a call with the same tables /
+  // header on the same stream skips the upload (two of the ~6 runtime calls of a small encode)
+  std::vector<DevTables> tables_held;
+  std::vector<uint8_t> header_held;
+  const void* tables_held_at = nullptr; const void* header_held_at = nullptr;
+  hipStream_t tables_stream = nullptr, header_stream = nullptr;
   DevBuf<uint32_t> seg_words, seg_nbits, spill, ubuf, chunk_ff, partial, replay;
   int replay_w = 0, replay_h = 0, replay_mode = 0, replay_nframes = 0;   // what `replay` holds (0 = nothing)
   DevBuf<unsigned long long> seg_off, chunk_off, stamps;
@@ -239,7 +245,19 @@ int prepare_scan(sjpeg_hip_engine* e, const sjpeg_hip_source* src,
     // (pageable source: the copy has left the host buffer when the call returns)
     std::vector<DevTables> host_tables(ntab);
     for (int i = 0; i < ntab; ++i) digest_tables(tables + i, &host_tables[i]);
-    HIP_TRY(hipMemcpyAsync(e->tables.p, host_tables.data(), sizeof(DevTables) * ntab, hipMemcpyHostToDevice, st));
+    const bool held = e->tables_held_at == e->tables.p && e->tables_stream == st &&
+                      e->tables_held.size() == static_cast<size_t>(ntab) &&
+                      memcmp(e->tables_held.data(), host_tables.data(), sizeof(DevTables) * ntab) == 0;
+    if (!held) {
+      e->tables_held_at = nullptr;
+      HIP_TRY(hipMemcpyAsync(e->tables.p, host_tables.data(), sizeof(DevTables) * ntab, hipMemcpyHostToDevice, st));
+      if (ntab <= 16) {                            // (a big batch of per-frame tables is not worth holding)
+        e->tables_held.swap(host_tables);
+        e->tables_held_at = e->tables.p; e->tables_stream = st;
+      } else {
+        e->tables_held.clear();
+      }
+    }
   }
   a->W = W; a->H = H; a->mb_w = g->mb_w; a->n_mcus = g->n_mcus; a->nseg = g->nseg;
   a->seg_first = 0;
@@ -520,7 +538,15 @@ static int encode_scan_impl(sjpeg_hip_engine* e, const sjpeg_hip_source* src, in
   if ((rc = e->chunk_off.ensure(static_cast<size_t>(nframes) * max_chunks))) return rc;
   if ((rc = e->header.ensure(header_size > 0 ? header_size : 1))) return rc;
   if (header_size > 0) {
-    HIP_TRY(hipMemcpyAsync(e->header.p, header, header_size, hipMemcpyHostToDevice, st));
+    const uint8_t* const hb = static_cast<const uint8_t*>(header);
+    const bool held = e->header_held_at == e->header.p && e->header_stream == st &&
+                      e->header_held.size() == header_size && memcmp(e->header_held.data(), hb, header_size) == 0;
+    if (!held) {
+      e->header_held_at = nullptr;
+      HIP_TRY(hipMemcpyAsync(e->header.p, header, header_size, hipMemcpyHostToDevice, st));
+      e->header_held.assign(hb, hb + header_size);
+      e->header_held_at = e->header.p; e->header_stream = st;
+    }
   }
 
   e->last_nseg = g.nseg; e->last_nframes = nframes;
@@ -678,6 +704,7 @@ int sjpeg_hip_stitch_bands(sjpeg_hip_engine* e, int nbands, const uint32_t* d_wo
   if ((rc = e->chunk_ff.ensure(max_chunks))) return rc;
   if ((rc = e->chunk_off.ensure(max_chunks))) return rc;
   if ((rc = e->header.ensure(header_size > 0 ? header_size : 1))) return rc;
+  e->header_held_at = nullptr;                     // (this path does not track what it uploads)
   if (header_size > 0) HIP_TRY(hipMemcpyAsync(e->header.p, header, header_size, hipMemcpyHostToDevice, st));
   StitchArgs s;
   memset(&s, 0, sizeof(s));
