@@ -83,6 +83,8 @@ def main():
     ap.add_argument("--frames", type=int, default=64, help="device-resident 4K frames per GPU per step")
     ap.add_argument("--input", choices=["struct", "noise"], default="struct")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pipelined", type=int, default=0,
+                    help="1: engine pipelined mode (stitch of step i under K1 of step i + 1)")
     args = ap.parse_args()
 
     import torch
@@ -126,6 +128,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    eng.set_pipelined(bool(args.pipelined))
     for _ in range(args.warmup):
         step()
     fence()
@@ -139,6 +142,18 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    piped_scan_ms = None
+    if args.pipelined:                            # K1 under the overlap, then back to ordered calls
+        eng.set_timing(True)
+        acc = []
+        for _ in range(4):                        # K1 of the LAST of four back-to-back steps: under the stitch of the third
+            for _ in range(4):
+                step()
+            torch.cuda.synchronize()
+            acc.append(eng.last_scan_ms())
+        piped_scan_ms = float(np.mean(acc))
+        eng.set_timing(False)
+        eng.set_pipelined(False)
     # ---- dominant-kernel duration, HIP events on the launch stream -------------------------
     eng.set_timing(True)
     scan_ms, total_ms = [], []
@@ -241,6 +256,9 @@ def main():
                          "stream_read_GBps": None if stream_gbps is None else round(stream_gbps, 1),
                          "frac_of_stream_read": None if not stream_gbps else round(achieved / 1e9 / stream_gbps, 4)},
         }
+        res["config"]["pipelined"] = bool(args.pipelined)
+        if piped_scan_ms is not None:
+            res["roofline"]["kernel_ms_pipelined"] = round(piped_scan_ms, 4)
         if gather_ms is not None:
             res["gather_ms"] = round(gather_ms, 2)
         if gather_error is not None:

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SJPEG_HIP_ABI_VERSION 9
+#define SJPEG_HIP_ABI_VERSION 10
 
 enum {
   SJPEG_HIP_OK = 0,
@@ -272,6 +272,17 @@ int sjpeg_hip_scan_symbol_stats_src(sjpeg_hip_engine* engine, const sjpeg_hip_so
                                     int width, int height, int yuv_mode, int nframes,
                                     const sjpeg_hip_scan_tables* tables, uint32_t* d_freq,
                                     void* stream);
+
+/* Pipelined mode, for back-to-back encode calls on one engine (a service coding batch after
+ * batch): K1 of a call runs on the caller's stream, the stitch kernels K2..K5 on a stream of the
+ * engine, over two sets of segment buffers, so the stitch of call i (HBM-bound) runs under the
+ * K1 of call i + 1 (ALU-bound).  In this mode d_out / d_sizes of an encode call are complete
+ * only after sjpeg_hip_engine_wait(engine, stream) -- which makes `stream` wait for everything
+ * the engine has in flight -- or a device synchronisation; do not touch them in between.
+ * Results are the same bytes.  The other entry points stay ordered on the caller's stream (they
+ * wait for the engine's stream first).  Off by default; switching it off drains the engine. */
+int sjpeg_hip_engine_set_pipelined(sjpeg_hip_engine* engine, int on);
+int sjpeg_hip_engine_wait(sjpeg_hip_engine* engine, void* stream);
 
 /* A batch whose frames each carry their OWN tables and header -- what a batch of the reference's
  * default encodes is (method 4: per-image adapted quantizer and per-image optimised Huffman

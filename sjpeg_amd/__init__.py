@@ -188,6 +188,10 @@ def lib() -> C.CDLL:
     L.sjpeg_hip_adapt_quant_sums.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                              C.c_int, C.c_int, C.c_void_p]
     L.sjpeg_hip_adapt_quant_sums.restype = None
+    L.sjpeg_hip_engine_set_pipelined.argtypes = [C.c_void_p, C.c_int]
+    L.sjpeg_hip_engine_set_pipelined.restype = C.c_int
+    L.sjpeg_hip_engine_wait.argtypes = [C.c_void_p, C.c_void_p]
+    L.sjpeg_hip_engine_wait.restype = C.c_int
     L.sjpeg_hip_encode_scan_multi.argtypes = [C.c_void_p, srcp, C.c_int, C.c_int, C.c_int, C.c_int,
                                               C.c_void_p, C.c_char_p, C.POINTER(C.c_size_t), C.c_int,
                                               C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
@@ -237,6 +241,7 @@ EXPORTED_C_SYMBOLS = [
     "sjpeg_hip_encode_scan_src", "sjpeg_hip_scan_coeffs_src", "sjpeg_hip_scan_histogram_src",
     "sjpeg_hip_scan_symbol_stats_src", "sjpeg_hip_scan_quant_error_src", "sjpeg_hip_engine_entropy_bits",
     "sjpeg_hip_encode_scan_multi", "sjpeg_hip_scan_symbol_stats_multi",
+    "sjpeg_hip_engine_set_pipelined", "sjpeg_hip_engine_wait",
     "sjpeg_hip_optimize_huffman", "sjpeg_hip_make_header_ex", "sjpeg_hip_make_header_meta",
     "sjpeg_hip_sharp_workspace", "sjpeg_hip_sharp_yuv",
     "sjpeg_hip_set_riskiness_table", "sjpeg_hip_has_riskiness_table", "sjpeg_hip_riskiness_sums",
@@ -451,6 +456,15 @@ class Engine:
 
     def set_timing(self, on: bool):
         lib().sjpeg_hip_engine_set_timing(self._h, int(on))
+
+    def set_pipelined(self, on: bool):
+        """Back-to-back encode calls overlap (stitch of call i under K1 of call i + 1); outputs are
+        complete after wait() or a device synchronisation (include/sjpeg_hip.h)."""
+        self._chk(lib().sjpeg_hip_engine_set_pipelined(self._h, int(on)), "sjpeg_hip_engine_set_pipelined")
+
+    def wait(self):
+        """Makes the current torch stream wait for everything the engine has in flight."""
+        self._chk(lib().sjpeg_hip_engine_wait(self._h, self._stream()), "sjpeg_hip_engine_wait")
 
     def last_scan_ms(self) -> float:
         return lib().sjpeg_hip_engine_last_scan_ms(self._h)

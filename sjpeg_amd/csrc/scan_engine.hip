@@ -131,6 +131,15 @@ struct sjpeg_hip_engine {
   int ablate = 0;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   bool ev_valid = false;
+  // Pipelined mode (sjpeg_hip_engine_set_pipelined): K1 on the caller's stream, K2..K5 on the
+  // engine's own stream, two sets of segment buffers -- the stitch of call i (HBM-bound, little
+  // ALU) runs under the K1 of call i + 1 (ALU-bound, little HBM).
+  bool pipelined = false;
+  hipStream_t side = nullptr;
+  DevBuf<uint32_t> seg_words2, seg_nbits2;
+  int set = 0;                                   // buffer set of the NEXT call
+  hipEvent_t k1_done = nullptr, side_done = nullptr, k3_done[2] = {nullptr, nullptr};
+  bool k3_pending[2] = {false, false}, side_pending = false;
 };
 
 namespace {
@@ -187,7 +196,8 @@ sjpeg_hip_source rgb_source(const void* d_rgb, int64_t row_stride, int64_t frame
 
 int prepare_scan(sjpeg_hip_engine* e, const sjpeg_hip_source* src,
                  int W, int H, int mode, int nframes, const sjpeg_hip_scan_tables* tables,
-                 hipStream_t st, FrameGeo* g, ScanArgs* a, int* src_class, bool per_frame_tables = false) {
+                 hipStream_t st, FrameGeo* g, ScanArgs* a, int* src_class, bool per_frame_tables = false,
+                 bool piped_encode = false) {
   if (e == nullptr || src == nullptr || src->plane[0] == nullptr || tables == nullptr || nframes <= 0) {
     return fail(SJPEG_HIP_EINVAL, "null argument or nframes <= 0");
   }
@@ -234,6 +244,10 @@ int prepare_scan(sjpeg_hip_engine* e, const sjpeg_hip_source* src,
   }
   if (nframes > 65535) return fail(SJPEG_HIP_EINVAL, "nframes > 65535");
   HIP_TRY(hipSetDevice(e->device));
+  // anything but a pipelined encode shares buffers with the stitch still running on the engine's stream
+  if (e->side_pending && !piped_encode) {
+    HIP_TRY(hipStreamWaitEvent(st, e->side_done, 0));
+  }
   int rc;
   const int ntab = per_frame_tables ? nframes : 1;
   if ((rc = e->tables.ensure(ntab))) return rc;
@@ -325,7 +339,37 @@ void sjpeg_hip_engine_destroy(sjpeg_hip_engine* e) {
   e->tables.release(); e->header.release(); e->seg_words.release(); e->seg_nbits.release(); e->spill.release(); e->replay.release();
   e->ubuf.release(); e->chunk_ff.release(); e->partial.release(); e->seg_off.release(); e->chunk_off.release(); e->hdr_off.release();
   for (auto& ev : e->ev) if (ev) (void)hipEventDestroy(ev);
+  e->seg_words2.release(); e->seg_nbits2.release();
+  if (e->side) { (void)hipStreamSynchronize(e->side); (void)hipStreamDestroy(e->side); }
+  for (hipEvent_t ev : {e->k1_done, e->side_done, e->k3_done[0], e->k3_done[1]}) if (ev) (void)hipEventDestroy(ev);
   delete e;
+}
+
+int sjpeg_hip_engine_set_pipelined(sjpeg_hip_engine* e, int on) {
+  if (e == nullptr) return fail(SJPEG_HIP_EINVAL, "engine == NULL");
+  HIP_TRY(hipSetDevice(e->device));
+  if (on && e->side == nullptr) {
+    HIP_TRY(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
+    for (hipEvent_t* ev : {&e->k1_done, &e->side_done, &e->k3_done[0], &e->k3_done[1]}) {
+      HIP_TRY(hipEventCreateWithFlags(ev, hipEventDisableTiming));
+    }
+  }
+  if (!on && e->pipelined) {                       // drain: from here on the caller's stream orders everything again
+    HIP_TRY(hipStreamSynchronize(e->side));
+    e->k3_pending[0] = e->k3_pending[1] = e->side_pending = false;
+  }
+  e->pipelined = on != 0;
+  e->header_held_at = nullptr;                    // the header buffer changes streams
+  return 0;
+}
+
+int sjpeg_hip_engine_wait(sjpeg_hip_engine* e, void* stream) {
+  if (e == nullptr) return fail(SJPEG_HIP_EINVAL, "engine == NULL");
+  if (e->side_pending) {
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamWaitEvent(static_cast<hipStream_t>(stream), e->side_done, 0));
+  }
+  return 0;
 }
 
 size_t sjpeg_hip_frame_bound(int width, int height, int yuv_mode, size_t header_size) {
@@ -507,8 +551,10 @@ static int encode_scan_impl(sjpeg_hip_engine* e, const sjpeg_hip_source* src, in
   FrameGeo g;
   ScanArgs a;
   int cls = 0;
-  int rc = prepare_scan(e, src, width, height, yuv_mode, nframes, tables, st, &g, &a, &cls, multi);
+  const bool piped = e->pipelined;
+  int rc = prepare_scan(e, src, width, height, yuv_mode, nframes, tables, st, &g, &a, &cls, multi, piped);
   if (rc) return rc;
+  hipStream_t hs = piped ? e->side : st;           // the stream of the stitch kernels and of what only they read
   size_t largest_header = header_size;
   if (multi) {
     if (tables->flags & SJPEG_HIP_QUANT_REPLAY) {
@@ -524,7 +570,7 @@ static int encode_scan_impl(sjpeg_hip_engine* e, const sjpeg_hip_source* src, in
       if (f > 0 && header_offsets[f] - header_offsets[f - 1] > largest_header) largest_header = header_offsets[f] - header_offsets[f - 1];
     }
     if ((rc = e->hdr_off.ensure(static_cast<size_t>(nframes) + 1))) return rc;
-    HIP_TRY(hipMemcpyAsync(e->hdr_off.p, offs.data(), offs.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(e->hdr_off.p, offs.data(), offs.size() * sizeof(uint32_t), hipMemcpyHostToDevice, hs));
   }
   header_size = header == nullptr ? 0 : header_size;
   if (out_stride < largest_header + 2 + 64) {
@@ -539,21 +585,32 @@ static int encode_scan_impl(sjpeg_hip_engine* e, const sjpeg_hip_source* src, in
   if ((rc = e->header.ensure(header_size > 0 ? header_size : 1))) return rc;
   if (header_size > 0) {
     const uint8_t* const hb = static_cast<const uint8_t*>(header);
-    const bool held = e->header_held_at == e->header.p && e->header_stream == st &&
+    const bool held = e->header_held_at == e->header.p && e->header_stream == hs &&
                       e->header_held.size() == header_size && memcmp(e->header_held.data(), hb, header_size) == 0;
     if (!held) {
       e->header_held_at = nullptr;
-      HIP_TRY(hipMemcpyAsync(e->header.p, header, header_size, hipMemcpyHostToDevice, st));
+      HIP_TRY(hipMemcpyAsync(e->header.p, header, header_size, hipMemcpyHostToDevice, hs));
       e->header_held.assign(hb, hb + header_size);
-      e->header_held_at = e->header.p; e->header_stream = st;
+      e->header_held_at = e->header.p; e->header_stream = hs;
     }
   }
 
   e->last_nseg = g.nseg; e->last_nframes = nframes;
+  const int set = piped ? e->set : 0;
+  if (piped) {
+    if (set == 1) {                                // the second set of what K1 writes and K2 / K3 read
+      const size_t total_segs = static_cast<size_t>(nframes) * g.nseg;
+      if ((rc = e->seg_words2.ensure(total_segs * g.slot_words))) return rc;
+      if ((rc = e->seg_nbits2.ensure(total_segs))) return rc;
+      a.seg_words = e->seg_words2.p; a.seg_nbits = e->seg_nbits2.p;
+    }
+    // this set was last read by the K3 of the call before the previous one
+    if (e->k3_pending[set]) HIP_TRY(hipStreamWaitEvent(st, e->k3_done[set], 0));
+  }
   StitchArgs s;
   s.nseg = g.nseg; s.nframes = nframes;
-  s.seg_nbits = e->seg_nbits.p; s.seg_off = e->seg_off.p;
-  s.seg_words = e->seg_words.p; s.slot_words = g.slot_words;
+  s.seg_nbits = a.seg_nbits; s.seg_off = e->seg_off.p;
+  s.seg_words = a.seg_words; s.slot_words = g.slot_words;
   s.ubuf = e->ubuf.p; s.ubuf_words = ubuf_words;
   s.chunk_ff = e->chunk_ff.p; s.chunk_off = e->chunk_off.p; s.max_chunks = max_chunks;
   s.header = e->header.p; s.header_size = static_cast<uint32_t>(header_size);
@@ -579,21 +636,34 @@ static int encode_scan_impl(sjpeg_hip_engine* e, const sjpeg_hip_source* src, in
   }
   if (rc) return rc;
   if (e->timing) HIP_TRY(hipEventRecord(e->ev[1], st));
+  if (piped) {
+    HIP_TRY(hipEventRecord(e->k1_done, st));
+    HIP_TRY(hipStreamWaitEvent(hs, e->k1_done, 0));
+  }
 
-  hipLaunchKernelGGL(scan_seg_offsets, dim3(nframes), dim3(kThreads), 0, st, s);
+  hipLaunchKernelGGL(scan_seg_offsets, dim3(nframes), dim3(kThreads), 0, hs, s);
   HIP_TRY(hipGetLastError());
   // the chunk count is only known on the device: a fixed grid strides over the chunks
   uint32_t gx = 4096u / static_cast<uint32_t>(nframes);
   if (gx < 64) gx = 64;
   if (gx > max_chunks) gx = max_chunks;
-  hipLaunchKernelGGL(place_segments, dim3((g.nseg + 3) / 4, nframes), dim3(kThreads), 0, st, s);
+  hipLaunchKernelGGL(place_segments, dim3((g.nseg + 3) / 4, nframes), dim3(kThreads), 0, hs, s);
   HIP_TRY(hipGetLastError());
-  hipLaunchKernelGGL(scan_chunk_offsets, dim3(nframes), dim3(kThreads), 0, st, s);
+  if (piped) {
+    HIP_TRY(hipEventRecord(e->k3_done[set], hs));
+    e->k3_pending[set] = true;
+    e->set = set ^ 1;
+  }
+  hipLaunchKernelGGL(scan_chunk_offsets, dim3(nframes), dim3(kThreads), 0, hs, s);
   HIP_TRY(hipGetLastError());
-  hipLaunchKernelGGL(stuff_chunks, dim3(gx, nframes), dim3(kThreads), 0, st, s);
+  hipLaunchKernelGGL(stuff_chunks, dim3(gx, nframes), dim3(kThreads), 0, hs, s);
   HIP_TRY(hipGetLastError());
+  if (piped) {
+    HIP_TRY(hipEventRecord(e->side_done, hs));
+    e->side_pending = true;
+  }
   if (e->timing) {
-    HIP_TRY(hipEventRecord(e->ev[2], st));
+    HIP_TRY(hipEventRecord(e->ev[2], hs));
     e->ev_valid = true;
   }
   return 0;

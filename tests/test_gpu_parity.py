@@ -308,6 +308,40 @@ def test_row_offsets_beyond_2_31_bytes(engine, oracle):
     del big
 
 
+def test_pipelined_calls_same_bytes(oracle):
+    """Back-to-back encode calls in pipelined mode (stitch of call i under K1 of call i + 1, two
+    sets of segment buffers): every call's output equals the oracle, whatever follows it --
+    different pictures, geometries and batch sizes in consecutive calls, a statistics call in
+    between, and switching the mode off again."""
+    eng = sj.Engine(0)
+    eng.set_pipelined(True)
+    rng = np.random.RandomState(99)
+    jobs, keep = [], []
+    for it in range(9):
+        w, h = [(640, 360), (333, 217), (1280, 720), (64, 48)][it % 4]
+        f = 1 + it % 3
+        mode = (1, 3, 4)[it % 3]
+        imgs = [synth.g_struct(w, h, 500 + 10 * it + k) if (it + k) % 2 else rng.randint(0, 256, (h, w, 3)).astype(np.uint8)
+                for k in range(f)]
+        frames = torch.from_numpy(np.stack(imgs)).cuda()
+        t, q = sj.make_tables(quality=70.0 + it)
+        hdr = sj.make_header(w, h, mode, q)
+        out, sizes = eng.encode_frames(frames, t, hdr, mode)          # own output buffers per call
+        keep.append(frames)
+        jobs.append((imgs, 70.0 + it, mode, out, sizes))
+        if it == 4:                                                  # an ordered entry point in the middle
+            eng.scan_symbol_stats(frames, t, mode)
+    eng.wait()
+    torch.cuda.synchronize()
+    for (imgs, q, mode, out, sizes) in jobs:
+        sz = sizes.cpu().numpy()
+        for k, img in enumerate(imgs):
+            assert bytes(out[k, :int(sz[k])].cpu().numpy()) == oracle.encode(img, q, mode), (img.shape, q, mode, k)
+    eng.set_pipelined(False)
+    img = synth.g_struct(321, 123, 5)
+    assert sj.encode_device(torch.from_numpy(img).cuda().unsqueeze(0), 75.0, 1, engine=eng)[0] == oracle.encode(img, 75.0, 1)
+
+
 def test_c5_recompress_default_params(engine, digests):
     d = digests["recompress|r90|default"]
     src = np.array(digests["recompress|r90|m0"]["source_quant"], np.uint8).reshape(2, 64)
