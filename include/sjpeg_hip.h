@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SJPEG_HIP_ABI_VERSION 10
+#define SJPEG_HIP_ABI_VERSION 11
 
 enum {
   SJPEG_HIP_OK = 0,
@@ -272,6 +272,22 @@ int sjpeg_hip_scan_symbol_stats_src(sjpeg_hip_engine* engine, const sjpeg_hip_so
                                     int width, int height, int yuv_mode, int nframes,
                                     const sjpeg_hip_scan_tables* tables, uint32_t* d_freq,
                                     void* stream);
+
+/* A whole batch the way the reference codes ONE picture with its default parameters
+ * (Encoder::Encode, src/enc.cc:391-448): per-picture adapted quantizer (method >= 3:
+ * CollectHistograms + AnalyseHisto) and per-picture optimised Huffman codes (method not 0 / 3:
+ * the statistics half of SinglePassScanOptimized), then headers and the scan -- one launch per
+ * device pass for all frames (histograms, analysis sums, symbol statistics, encode), the float
+ * regression and BuildOptimalTable per frame on the host in between (two synchronisations of
+ * `stream`).  quant = the two starting matrices (natural order, e.g. sjpeg_hip_quality_matrices),
+ * min_quant NULL = ones, q_bias / qdelta_max_* as EncoderParam (0x78, 12, 1).  method 0..6 as
+ * SjpegEncode (trellis methods: host API).  Output as sjpeg_hip_encode_scan_src (complete JPEGs,
+ * EOI included). */
+int sjpeg_hip_encode_batch_src(sjpeg_hip_engine* engine, const sjpeg_hip_source* src,
+                               int width, int height, int yuv_mode, int nframes,
+                               const uint8_t quant[2][64], const uint8_t* min_quant /*[2][64]*/, int q_bias,
+                               int method, int qdelta_max_luma, int qdelta_max_chroma,
+                               void* d_out, size_t out_stride, uint64_t* d_sizes, void* stream);
 
 /* Pipelined mode, for back-to-back encode calls on one engine (a service coding batch after
  * batch): K1 of a call runs on the caller's stream, the stitch kernels K2..K5 on a stream of the

@@ -188,6 +188,10 @@ def lib() -> C.CDLL:
     L.sjpeg_hip_adapt_quant_sums.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                              C.c_int, C.c_int, C.c_void_p]
     L.sjpeg_hip_adapt_quant_sums.restype = None
+    L.sjpeg_hip_encode_batch_src.argtypes = [C.c_void_p, srcp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                             C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                             C.c_size_t, C.c_void_p, C.c_void_p]
+    L.sjpeg_hip_encode_batch_src.restype = C.c_int
     L.sjpeg_hip_engine_set_pipelined.argtypes = [C.c_void_p, C.c_int]
     L.sjpeg_hip_engine_set_pipelined.restype = C.c_int
     L.sjpeg_hip_engine_wait.argtypes = [C.c_void_p, C.c_void_p]
@@ -241,7 +245,7 @@ EXPORTED_C_SYMBOLS = [
     "sjpeg_hip_encode_scan_src", "sjpeg_hip_scan_coeffs_src", "sjpeg_hip_scan_histogram_src",
     "sjpeg_hip_scan_symbol_stats_src", "sjpeg_hip_scan_quant_error_src", "sjpeg_hip_engine_entropy_bits",
     "sjpeg_hip_encode_scan_multi", "sjpeg_hip_scan_symbol_stats_multi",
-    "sjpeg_hip_engine_set_pipelined", "sjpeg_hip_engine_wait",
+    "sjpeg_hip_engine_set_pipelined", "sjpeg_hip_engine_wait", "sjpeg_hip_encode_batch_src",
     "sjpeg_hip_optimize_huffman", "sjpeg_hip_make_header_ex", "sjpeg_hip_make_header_meta",
     "sjpeg_hip_sharp_workspace", "sjpeg_hip_sharp_yuv",
     "sjpeg_hip_set_riskiness_table", "sjpeg_hip_has_riskiness_table", "sjpeg_hip_riskiness_sums",
@@ -566,6 +570,26 @@ class Engine:
                   "sjpeg_hip_scan_symbol_stats_multi")
         return out
 
+    def encode_batch(self, src: Source, nframes, w, h, yuv_mode, quant, method=4, min_quant=None, q_bias=0x78,
+                     dmax_luma=12, dmax_chroma=1, out_stride=None, device="cuda", out=None, sizes=None):
+        """The reference's per-picture analysis (methods 0..6) for a whole batch in one C call
+        (sjpeg_hip_encode_batch_src).  Returns (out [F, stride] uint8, sizes [F] int64)."""
+        import torch
+        q = np.ascontiguousarray(quant, np.uint8).reshape(2, 64)
+        mq = None if min_quant is None else np.ascontiguousarray(min_quant, np.uint8).reshape(2, 64)
+        if out_stride is None:
+            out_stride = frame_bound(w, h, yuv_mode, 2048)
+        if out is None:
+            out = torch.empty((nframes, out_stride), dtype=torch.uint8, device=device)
+        if sizes is None:
+            sizes = torch.zeros(nframes, dtype=torch.int64, device=device)
+        self._chk(lib().sjpeg_hip_encode_batch_src(self._h, C.byref(src), w, h, yuv_mode, nframes, q.ctypes.data,
+                                                   mq.ctypes.data if mq is not None else None, q_bias, int(method),
+                                                   dmax_luma, dmax_chroma, out.data_ptr(), out_stride,
+                                                   sizes.data_ptr(), self._stream()),
+                  "sjpeg_hip_encode_batch_src")
+        return out, sizes
+
     def scan_quant_error_source(self, src: Source, nframes, w, h, tables, yuv_mode, device="cuda"):
         import torch
         out = torch.zeros(nframes, dtype=torch.int64, device=device)
@@ -655,35 +679,23 @@ class Engine:
 def encode_device_method(frames, quality=75.0, yuv_mode=YUV_420, method=4, engine=None, quant=None,
                          min_quant=None, q_bias=0x78, dmax_luma=12, dmax_chroma=1):
     """Per-frame adaptive quantization / optimised Huffman tables (reference methods 0..6) for a
-    batch of device-resident frames, driven through the C-ABI: every device pass is ONE launch
-    over the whole batch (histograms; symbol statistics and encode with per-frame tables and
-    headers), the per-frame analysis between them is the reference's host code.  Returns a list
-    of JPEG byte strings."""
-    import torch
+    batch of device-resident frames [F, H, W, 3]: one call of sjpeg_hip_encode_batch_src (every
+    device pass is one launch over the batch).  Returns a list of JPEG byte strings."""
     eng = engine or Engine(frames.device.index or 0)
     method = max(0, min(int(method), 8))
     if method >= 7:
         raise SjpegError("trellis methods: use the host API (SjpegEncode / sjpeg::Encode)")
-    adaptive, optimize = method >= 3, method not in (0, 3)
     f, h, w, _ = frames.shape
     assert frames.stride(3) == 1 and frames.stride(2) == 3
     rows = frames.as_strided((f, h, w * 3), (frames.stride(0), frames.stride(1), 1))
     src, _ = make_source(SRC_RGB, [rows])
-    base, q0 = make_tables(quality=quality, quant=quant, min_quant=min_quant, q_bias=q_bias)
-    tabs, quants = [base] * f, [q0] * f
-    if adaptive:
-        pairs = adapt_quant_device_batch(eng.scan_histogram(frames, yuv_mode), yuv_mode, q0, min_quant, q_bias,
-                                         dmax_luma, dmax_chroma)
-        tabs, quants = [p[0] for p in pairs], [p[1] for p in pairs]
-    specs = [None] * f
-    if optimize:
-        freq = eng.scan_symbol_stats_multi(src, f, w, h, tabs, yuv_mode,
-                                           device=frames.device).cpu().numpy().view(np.uint32)
-        if tabs[0] is base:                       # optimize_huffman writes the codes into its tables
-            tabs = [ScanTables.from_buffer_copy(base) for _ in range(f)]
-        specs = [optimize_huffman(freq[k], yuv_mode, tabs[k]) for k in range(f)]
-    headers = [make_header_ex(w, h, yuv_mode, quants[k], specs[k]) for k in range(f)]
-    out, sizes = eng.encode_source_multi(src, f, w, h, tabs, headers, yuv_mode, device=frames.device)
+    if quant is None:
+        q = np.zeros((2, 64), np.uint8)
+        lib().sjpeg_hip_quality_matrices(float(quality), q.ctypes.data)
+    else:
+        q = np.asarray(quant, np.uint8).reshape(2, 64)
+    out, sizes = eng.encode_batch(src, f, w, h, yuv_mode, q, method, min_quant, q_bias, dmax_luma, dmax_chroma,
+                                  device=frames.device)
     return _fetch_frames(out, sizes)
 
 

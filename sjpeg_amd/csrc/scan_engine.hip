@@ -821,6 +821,126 @@ int sjpeg_hip_adapt_sums(const uint32_t* d_hist, int nframes, const uint8_t quan
   return 0;
 }
 
+// ---- a whole batch with the reference's per-picture analysis (methods 0..6), device-resident ----
+// What Encoder::Encode does for ONE picture with adaptive quantization and optimised Huffman
+// codes (src/enc.cc:391-448: CollectHistograms + AnalyseHisto, the statistics half of
+// SinglePassScanOptimized, headers, the scan), done for nframes pictures with one launch per
+// device pass and the per-picture float / Huffman work on the host in between.
+namespace {
+constexpr int kAdaptDeltas = 25;      // candidate steps -12 .. +12 (jpeg_host.h)
+struct BatchScratch {                 // per host thread: device scratch of sjpeg_hip_encode_batch_src
+  void* d_hist = nullptr; size_t hist_cap = 0;
+  void* d_sums = nullptr; size_t sums_cap = 0;
+  void* d_freq = nullptr; size_t freq_cap = 0;
+  int device = -1;
+  void Drop() {
+    if (d_hist) (void)hipFree(d_hist);
+    if (d_sums) (void)hipFree(d_sums);
+    if (d_freq) (void)hipFree(d_freq);
+    d_hist = d_sums = d_freq = nullptr; hist_cap = sums_cap = freq_cap = 0;
+  }
+  ~BatchScratch() { if (device >= 0) { (void)hipSetDevice(device); Drop(); } }
+  bool Ensure(void** p, size_t* cap, size_t need) {
+    if (need <= *cap) return true;
+    if (*p) (void)hipFree(*p);
+    *p = nullptr; *cap = 0;
+    if (hipMalloc(p, need) != hipSuccess) return false;
+    *cap = need;
+    return true;
+  }
+};
+thread_local BatchScratch g_batch;
+}  // namespace
+
+int sjpeg_hip_encode_batch_src(sjpeg_hip_engine* engine, const sjpeg_hip_source* src,
+                                          int width, int height, int yuv_mode, int nframes,
+                                          const uint8_t quant_in[2][64], const uint8_t* min_quant, int q_bias,
+                                          int method, int qdelta_max_luma, int qdelta_max_chroma,
+                                          void* d_out, size_t out_stride, uint64_t* d_sizes, void* stream) {
+  if (engine == nullptr || src == nullptr || quant_in == nullptr || nframes <= 0) {
+    return fail(SJPEG_HIP_EINVAL, "null argument or nframes <= 0");
+  }
+  if (method < 0) method = 0;
+  if (method > 6) return fail(SJPEG_HIP_EINVAL, "sjpeg_hip_encode_batch_src: methods 0..6 (trellis goes through the host API)");
+  try {
+    const bool adaptive = method >= 3, optimize = (method != 0) && (method != 3);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    BatchScratch& sc = g_batch;
+    const int device = engine->device;
+    if (sc.device != device) { if (sc.device >= 0) { (void)hipSetDevice(sc.device); sc.Drop(); } sc.device = device; }
+    HIP_TRY(hipSetDevice(device));
+    const size_t n = static_cast<size_t>(nframes);
+    std::vector<sjpeg_hip_scan_tables> tables(n);
+    std::vector<uint8_t> quant(n * 128);
+    {
+      sjpeg_hip_scan_tables t0;
+      memset(&t0, 0, sizeof(t0));
+      uint8_t q0[2][64];
+      memcpy(q0, quant_in, sizeof(q0));
+      sjpeg_hip_finalize_quant(q0, min_quant, q_bias, &t0);
+      sjpeg_hip_default_huffman(&t0);
+      for (size_t f = 0; f < n; ++f) { tables[f] = t0; memcpy(&quant[f * 128], q0, 128); }
+    }
+    if (adaptive) {
+      constexpr size_t kHist = 2 * 64 * 128 * sizeof(uint32_t);
+      constexpr size_t kSums = 2 * 64 * kAdaptDeltas * 2 * sizeof(int64_t), kTot = 2 * 64 * 2 * sizeof(int32_t);
+      if (!sc.Ensure(&sc.d_hist, &sc.hist_cap, n * kHist) || !sc.Ensure(&sc.d_sums, &sc.sums_cap, n * (kSums + kTot))) {
+        return fail(SJPEG_HIP_ENOMEM, "hipMalloc(batch scratch) failed");
+      }
+      int64_t* const d_sums = static_cast<int64_t*>(sc.d_sums);
+      int32_t* const d_tot = reinterpret_cast<int32_t*>(static_cast<uint8_t*>(sc.d_sums) + n * kSums);
+      int rc = sjpeg_hip_scan_histogram_src(engine, src, width, height, yuv_mode, nframes,
+                                            static_cast<uint32_t*>(sc.d_hist), stream);
+      if (rc == 0) {
+        rc = sjpeg_hip_adapt_sums(static_cast<const uint32_t*>(sc.d_hist), nframes,
+                                  reinterpret_cast<const uint8_t(*)[64]>(&quant[0]), min_quant, d_sums, d_tot, stream);
+      }
+      if (rc != 0) return rc;
+      std::vector<uint8_t> host(n * (kSums + kTot));
+      if (hipMemcpyAsync(host.data(), sc.d_sums, host.size(), hipMemcpyDeviceToHost, st) != hipSuccess ||
+          hipStreamSynchronize(st) != hipSuccess) {
+        return fail(SJPEG_HIP_ERUNTIME, "analysis sums read-back failed");
+      }
+      for (size_t f = 0; f < n; ++f) {
+        sjpeg_hip_adapt_quant_sums(reinterpret_cast<const int64_t*>(host.data() + f * kSums),
+                                   reinterpret_cast<const int32_t*>(host.data() + n * kSums + f * kTot), yuv_mode,
+                                   reinterpret_cast<uint8_t(*)[64]>(&quant[f * 128]), min_quant, q_bias,
+                                   qdelta_max_luma, qdelta_max_chroma, &tables[f]);
+      }
+    }
+    std::vector<sjpeg_hip_huffman_spec> specs;
+    if (optimize) {
+      constexpr size_t kFreq = 2 * 272 * sizeof(uint32_t);
+      if (!sc.Ensure(&sc.d_freq, &sc.freq_cap, n * kFreq)) return fail(SJPEG_HIP_ENOMEM, "hipMalloc(batch scratch) failed");
+      const int rc = sjpeg_hip_scan_symbol_stats_multi(engine, src, width, height, yuv_mode, nframes, tables.data(),
+                                                       static_cast<uint32_t*>(sc.d_freq), stream);
+      if (rc != 0) return rc;
+      std::vector<uint32_t> freq(n * 2 * 272);
+      if (hipMemcpyAsync(freq.data(), sc.d_freq, n * kFreq, hipMemcpyDeviceToHost, st) != hipSuccess ||
+          hipStreamSynchronize(st) != hipSuccess) {
+        return fail(SJPEG_HIP_ERUNTIME, "symbol statistics read-back failed");
+      }
+      specs.resize(n * 4);
+      for (size_t f = 0; f < n; ++f) sjpeg_hip_optimize_huffman(&freq[f * 2 * 272], yuv_mode, &specs[f * 4], &tables[f]);
+    }
+    std::vector<uint8_t> headers;
+    std::vector<size_t> offs(n + 1, 0);
+    uint8_t one[2048];
+    for (size_t f = 0; f < n; ++f) {
+      const size_t hs = sjpeg_hip_make_header_ex(width, height, yuv_mode, reinterpret_cast<const uint8_t(*)[64]>(&quant[f * 128]),
+                                                 optimize ? &specs[f * 4] : nullptr, one, sizeof(one));
+      if (hs == 0) return fail(SJPEG_HIP_EINVAL, "header generation failed");
+      headers.insert(headers.end(), one, one + hs);
+      offs[f + 1] = headers.size();
+    }
+    const int rc_enc = sjpeg_hip_encode_scan_multi(engine, src, width, height, yuv_mode, nframes, tables.data(), headers.data(),
+                                       offs.data(), /*append_eoi=*/1, d_out, out_stride, d_sizes, stream);
+    return rc_enc;
+  } catch (...) {
+    return fail(SJPEG_HIP_ENOMEM, "out of host memory");
+  }
+}
+
 // ---- measurement aid: what a read-only streaming kernel reaches on this device ------------------
 // (SURVEY section 8d asks for the achieved read bandwidth beside the 8 TB/s spec figure)
 
