@@ -377,6 +377,32 @@ def test_source_layouts_vs_oracle(engine, oracle, fmt):
                 assert got == want, (fmt, w, h, mode, q, method)
 
 
+@pytest.mark.parametrize("fmt", [1, 3, 4, 5, 6, 7])
+def test_batch_entry_other_layouts(engine, oracle, fmt):
+    """sjpeg_hip_encode_batch_src over batches in the other source layouts: every frame equals the
+    oracle's single-picture encode with the same method."""
+    rng = np.random.RandomState(700 + fmt)
+    implied = {3: 4, 4: 3, 5: 1, 6: 1, 7: 1}
+    for (w, h, f) in ((33, 21, 3), (250, 130, 4)):
+        per_frame = [_random_planes(rng, fmt, w, h) for _ in range(f)]
+        if w >= 97:
+            per_frame = [[(p // 4 + np.arange(p.shape[1])[None, :] // 3 + 7 * k).astype(np.uint8) for p in planes]
+                         for k, planes in enumerate(per_frame)]
+        stacked = [torch.from_numpy(np.stack([pf[i] for pf in per_frame])).cuda() for i in range(len(per_frame[0]))]
+        src, n = sj.make_source(fmt, stacked)
+        assert n == f
+        mode = implied.get(fmt, 1)
+        for q, method in ((75.0, 4), (50.0, 1), (90.0, 3), (75.0, 0)):
+            out, sizes = engine.encode_batch(src, f, w, h, mode, oracle.quality_matrices(q), method)
+            torch.cuda.synchronize()
+            sz = sizes.cpu().numpy()
+            for k in range(f):
+                want = oracle.encode_src(fmt, per_frame[k], w, h, oracle.quality_matrices(q), yuv_mode=mode, method=method)
+                assert bytes(out[k, :int(sz[k])].cpu().numpy()) == want, (fmt, w, h, k, q, method)
+    with pytest.raises(sj.SjpegError):
+        engine.encode_batch(src, f, w, h, mode, oracle.quality_matrices(75.0), 7)
+
+
 @pytest.mark.parametrize("fmt", [0, 1, 3, 4, 5, 6])
 def test_search_pass_measurements_vs_oracle(engine, oracle, fmt):
     """What one pass of the size / PSNR search measures on the device: the squared quantization
