@@ -111,7 +111,9 @@ typedef struct sjpeg_hip_huffman_spec {
 } sjpeg_hip_huffman_spec;
 
 /* Opaque engine: one HIP device, cached device scratch.  Not thread-safe; use one engine
- * per host thread (they may share a device). */
+ * per host thread (they may share a device).  Every call is asynchronous on the stream it is
+ * given; the scratch is shared by all calls, so a call on another stream than the previous one
+ * first waits (on the device) for that one's work -- use one engine per stream to overlap. */
 typedef struct sjpeg_hip_engine sjpeg_hip_engine;
 
 int sjpeg_hip_abi_version(void);

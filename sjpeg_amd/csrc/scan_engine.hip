@@ -134,6 +134,11 @@ struct sjpeg_hip_engine {
   // Pipelined mode (sjpeg_hip_engine_set_pipelined): K1 on the caller's stream, K2..K5 on the
   // engine's own stream, two sets of segment buffers -- the stitch of call i (HBM-bound, little
   // ALU) runs under the K1 of call i + 1 (ALU-bound, little HBM).
+  // the scratch buffers are shared by all calls: a call on another stream than the previous one
+  // waits for that one's work first
+  hipStream_t last_stream = nullptr;
+  bool last_stream_valid = false;
+  hipEvent_t cross_ev = nullptr;
   bool pipelined = false;
   hipStream_t side = nullptr;
   DevBuf<uint32_t> seg_words2, seg_nbits2;
@@ -194,6 +199,19 @@ sjpeg_hip_source rgb_source(const void* d_rgb, int64_t row_stride, int64_t frame
   return s;
 }
 
+// Orders this call after everything the engine was asked to do on another stream.
+int order_on_stream(sjpeg_hip_engine* e, hipStream_t st) {
+  if (e->last_stream_valid && e->last_stream != st) {
+    if (e->cross_ev == nullptr) HIP_TRY(hipEventCreateWithFlags(&e->cross_ev, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(e->cross_ev, e->last_stream));
+    HIP_TRY(hipStreamWaitEvent(st, e->cross_ev, 0));
+    if (e->side_pending) HIP_TRY(hipStreamWaitEvent(st, e->side_done, 0));
+  }
+  e->last_stream = st;
+  e->last_stream_valid = true;
+  return 0;
+}
+
 int prepare_scan(sjpeg_hip_engine* e, const sjpeg_hip_source* src,
                  int W, int H, int mode, int nframes, const sjpeg_hip_scan_tables* tables,
                  hipStream_t st, FrameGeo* g, ScanArgs* a, int* src_class, bool per_frame_tables = false,
@@ -244,6 +262,7 @@ int prepare_scan(sjpeg_hip_engine* e, const sjpeg_hip_source* src,
   }
   if (nframes > 65535) return fail(SJPEG_HIP_EINVAL, "nframes > 65535");
   HIP_TRY(hipSetDevice(e->device));
+  if (int rc0 = order_on_stream(e, st)) return rc0;
   // anything but a pipelined encode shares buffers with the stitch still running on the engine's stream
   if (e->side_pending && !piped_encode) {
     HIP_TRY(hipStreamWaitEvent(st, e->side_done, 0));
@@ -341,7 +360,7 @@ void sjpeg_hip_engine_destroy(sjpeg_hip_engine* e) {
   for (auto& ev : e->ev) if (ev) (void)hipEventDestroy(ev);
   e->seg_words2.release(); e->seg_nbits2.release();
   if (e->side) { (void)hipStreamSynchronize(e->side); (void)hipStreamDestroy(e->side); }
-  for (hipEvent_t ev : {e->k1_done, e->side_done, e->k3_done[0], e->k3_done[1]}) if (ev) (void)hipEventDestroy(ev);
+  for (hipEvent_t ev : {e->k1_done, e->side_done, e->k3_done[0], e->k3_done[1], e->cross_ev}) if (ev) (void)hipEventDestroy(ev);
   delete e;
 }
 
@@ -766,6 +785,7 @@ int sjpeg_hip_stitch_bands(sjpeg_hip_engine* e, int nbands, const uint32_t* d_wo
   if (out_cap < header_size + 2 + 64) return fail(SJPEG_HIP_ECAPACITY, "out_cap too small");
   hipStream_t st = static_cast<hipStream_t>(stream);
   HIP_TRY(hipSetDevice(e->device));
+  if (int rc0 = order_on_stream(e, st)) return rc0;
   int rc;
   const size_t ubuf_words = (static_cast<size_t>(nbands) * band_stride_words + kChunkWords + 3) & ~size_t(3);
   const uint32_t max_chunks = static_cast<uint32_t>((ubuf_words + kChunkWords - 1) / kChunkWords);

@@ -342,6 +342,29 @@ def test_pipelined_calls_same_bytes(oracle):
     assert sj.encode_device(torch.from_numpy(img).cuda().unsqueeze(0), 75.0, 1, engine=eng)[0] == oracle.encode(img, 75.0, 1)
 
 
+def test_non_default_streams(oracle):
+    """Everything is ordered on the stream the caller passes, and the engine orders calls that
+    arrive on different streams (they share its scratch): two torch streams alternate on one
+    engine, inputs are produced on the stream that codes them."""
+    eng = sj.Engine(0)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    img = [synth.g_struct(500, 300, 40 + k) for k in range(6)]
+    host = [torch.from_numpy(im).pin_memory() for im in img]
+    t, q = sj.make_tables(quality=82.0)
+    hdr = sj.make_header(500, 300, 1, q)
+    outs = []
+    for k in range(6):
+        st = s1 if k % 2 == 0 else s2
+        with torch.cuda.stream(st):
+            frames = host[k].to("cuda", non_blocking=True).unsqueeze(0)      # the upload is on the same stream
+            out, sizes = eng.encode_frames(frames, t, hdr, 1)
+            outs.append((frames, out, sizes))
+    s1.synchronize()
+    s2.synchronize()
+    for k, (_, out, sizes) in enumerate(outs):
+        assert bytes(out[0, :int(sizes[0])].cpu().numpy()) == oracle.encode(img[k], 82.0, 1), k
+
+
 def test_c5_recompress_default_params(engine, digests):
     d = digests["recompress|r90|default"]
     src = np.array(digests["recompress|r90|m0"]["source_quant"], np.uint8).reshape(2, 64)
