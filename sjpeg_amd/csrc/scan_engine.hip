@@ -932,6 +932,11 @@ int sjpeg_hip_encode_batch_src(sjpeg_hip_engine* engine, const sjpeg_hip_source*
     if (optimize) {
       constexpr size_t kFreq = 2 * 272 * sizeof(uint32_t);
       if (!sc.Ensure(&sc.d_freq, &sc.freq_cap, n * kFreq)) return fail(SJPEG_HIP_ENOMEM, "hipMalloc(batch scratch) failed");
+      // the statistics pass leaves its quantized blocks behind (144 B each) and the encode pass
+      // replays them: no second colour conversion / DCT / quantization (the reference's stored
+      // run/levels, src/enc.cc:121-129,374-386)
+      // (measured: 3 % of the call for 32 4K frames -- writing and reading the blocks costs nearly what it saves)
+      for (size_t f = 0; f < n; ++f) tables[f].flags |= SJPEG_HIP_QUANT_KEEP;
       const int rc = sjpeg_hip_scan_symbol_stats_multi(engine, src, width, height, yuv_mode, nframes, tables.data(),
                                                        static_cast<uint32_t*>(sc.d_freq), stream);
       if (rc != 0) return rc;
@@ -941,6 +946,7 @@ int sjpeg_hip_encode_batch_src(sjpeg_hip_engine* engine, const sjpeg_hip_source*
         return fail(SJPEG_HIP_ERUNTIME, "symbol statistics read-back failed");
       }
       specs.resize(n * 4);
+      for (size_t f = 0; f < n; ++f) tables[f].flags = (tables[f].flags & ~SJPEG_HIP_QUANT_KEEP) | SJPEG_HIP_QUANT_REPLAY;
       for (size_t f = 0; f < n; ++f) sjpeg_hip_optimize_huffman(&freq[f * 2 * 272], yuv_mode, &specs[f * 4], &tables[f]);
     }
     std::vector<uint8_t> headers;
