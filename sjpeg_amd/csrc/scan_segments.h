@@ -46,6 +46,11 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
     for (int i = tid; i < 512; i += kScanThreads) lac[i] = (&t->ac[0][0])[i];
     if (tid < 24) ldc[tid] = (&t->dc[0][0])[tid];
     if (TRELLIS && tid < 128) reinterpret_cast<uint32_t*>(smem + kOffTlen)[tid] = reinterpret_cast<const uint32_t*>(&t->tlen[0][0])[tid];
+    // bookkeeping of the entropy phase that nothing touches until then: the sort's bins, the group queue
+    if (KIND == kKindEncode) {
+      if (tid < 32) win[kSortHist + tid] = 0;
+      if (tid == 32) misc[10] = 0;
+    }
   };
 
   // ---- P1: colour conversion, strips of 8 pixels (x2 rows for 4:2:0) --------------------
@@ -511,10 +516,19 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
   uint32_t* const tail = reinterpret_cast<uint32_t*>(slot + 128);
   tail[3] = static_cast<uint32_t>(dc_val);
   // (sort bookkeeping that aliases nothing still in use is cleared under the same barrier)
+  // The counting sort of the parts (below) starts here: the bins were cleared when the tables were
+  // staged, and the atomics that rank this block's parts are in flight across the DC barrier.
+  uint32_t pc[4] = {0, 0, 0, 0}, rank[4] = {0, 0, 0, 0};
   if (KIND == kKindEncode) {
-    if (tid < 32) win[kSortHist + tid] = 0;
-    if (tid == 32) misc[10] = 0;                   // the queue of part groups (P3)
     *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(win + 64 + 512) + 4 * tid) = make_uint2(0u, 0u);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) pc[q] = static_cast<uint32_t>(__popc(nzq[q]));
+    if (emits) {
+      uint32_t* const hist0 = win + kSortHist;
+      rank[0] = atomicAdd(&hist0[pc[0]], 1u);      // quarter 0 always makes a part (DC, EOB)
+#pragma unroll
+      for (int q = 1; q < 4; ++q) if (pc[q] != 0u) rank[q] = atomicAdd(&hist0[pc[q]], 1u);
+    }
   }
   __syncthreads();
   int pred = 0;
@@ -582,43 +596,35 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
   // themselves.  Parts are handed to threads sorted by their number of non-zeros (counting sort,
   // descending), 256 per round: walks of at most 16 symbols with similar trip counts per wave.
   // The unit list and the part lengths live in the bit window, idle until the stitch.
-  uint32_t* const hist = win + kSortHist;          // [32], bins 0..16 (cleared before the DC barrier)
-  uint32_t* const bin_start = win + kSortHist + 32;   // [32]
+  uint32_t* const hist = win + kSortHist;          // [32], bins 0..16 (cleared with the tables, filled before the DC barrier)
   uint16_t* const ulist = reinterpret_cast<uint16_t*>(win + 64);          // [1024] block | quarter << 8
   uint16_t* const ulen = reinterpret_cast<uint16_t*>(win + 64 + 512);     // [256][4] bits per part
+  uint32_t n_units;
   {
-    uint32_t c[4] = {static_cast<uint32_t>(__popc(nzq[0])), static_cast<uint32_t>(__popc(nzq[1])),
-                     static_cast<uint32_t>(__popc(nzq[2])), static_cast<uint32_t>(__popc(nzq[3]))};
-    uint32_t rank[4] = {0, 0, 0, 0};
-    if (emits) {
-      rank[0] = atomicAdd(&hist[c[0]], 1u);        // quarter 0 always makes a part (DC, EOB)
+    // every wave scans the 17 bins (16, 15, ... 0) for itself: no hand-over through LDS, no barrier
+    const int ln = tid & 63;
+    const uint32_t hcnt = ln <= 16 ? hist[16 - ln] : 0u;
+    uint32_t incl = hcnt;
 #pragma unroll
-      for (int q = 1; q < 4; ++q) if (c[q] != 0u) rank[q] = atomicAdd(&hist[c[q]], 1u);
+    for (int d = 1; d < 32; d <<= 1) {
+      const uint32_t y = __shfl_up(incl, d, 64);
+      if (ln >= d) incl += y;
     }
-    __syncthreads();
-    if (tid < 64) {                                // wave 0: exclusive scan over bins 16, 15, ... 0
-      const uint32_t h = tid <= 16 ? hist[16 - tid] : 0u;
-      uint32_t incl = h;
+    const uint32_t excl = incl - hcnt;             // lane l: where bin 16 - l starts
+    n_units = __shfl(incl, 16, 64);                // number of parts
+    uint32_t start[4];
 #pragma unroll
-      for (int d = 1; d < 32; d <<= 1) {
-        const uint32_t y = __shfl_up(incl, d, 64);
-        if (tid >= d) incl += y;
-      }
-      if (tid <= 16) bin_start[16 - tid] = incl - h;
-      if (tid == 16) misc[9] = incl;               // number of parts
-    }
-    __syncthreads();
+    for (int q = 0; q < 4; ++q) start[q] = __shfl(excl, 16 - static_cast<int>(pc[q]), 64);
     if (emits) {
-      ulist[bin_start[c[0]] + rank[0]] = static_cast<uint16_t>(tid);
+      ulist[start[0] + rank[0]] = static_cast<uint16_t>(tid);
 #pragma unroll
       for (int q = 1; q < 4; ++q) {
-        if (c[q] != 0u) ulist[bin_start[c[q]] + rank[q]] = static_cast<uint16_t>(tid | (q << 8));
+        if (pc[q] != 0u) ulist[start[q] + rank[q]] = static_cast<uint16_t>(tid | (q << 8));
       }
     }
     __syncthreads();
   }
   stamp(3);
-  const uint32_t n_units = misc[9];
 
   // the walk reads 16-bit entries and writes 32-bit words in the same slot: no type-based reordering
   typedef uint16_t __attribute__((may_alias)) u16_alias;
