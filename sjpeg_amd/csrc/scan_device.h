@@ -473,7 +473,7 @@ __device__ __forceinline__ void fetch_plane(const uint8_t* plane, long long stri
 }
 
 // workgroup exclusive scan of one uint32 per thread; returns exclusive prefix, *total = sum
-template <int NT>
+template <int NT, bool TRAILING_BARRIER = true>
 __device__ __forceinline__ uint32_t wg_exclusive_scan(uint32_t x, uint32_t* scratch /*>=8 u32*/,
                                                       uint32_t* total) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -492,7 +492,7 @@ __device__ __forceinline__ uint32_t wg_exclusive_scan(uint32_t x, uint32_t* scra
     if (w < wave) base += s;
     sum += s;
   }
-  __syncthreads();
+  if (TRAILING_BARRIER) __syncthreads();          // (scratch may be reused right away)
   *total = sum;
   return base + incl - x;
 }

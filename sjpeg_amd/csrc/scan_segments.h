@@ -755,8 +755,15 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
     const uint2 L = *reinterpret_cast<const uint2*>(ulen + 4 * tid);
     const uint32_t l0 = L.x & 0xffffu, l1 = L.x >> 16, l2 = L.y & 0xffffu, l3 = L.y >> 16;
     tail[2] = l0 | (l1 << 10) | (l2 << 20);
-    const uint32_t my_start = wg_exclusive_scan<kScanThreads>(l0 + l1 + l2 + l3, misc, &total);
+    // (the scratch words are not used again: the barrier after the window is cleared, below, closes the scan)
+    const uint32_t my_start = wg_exclusive_scan<kScanThreads, false>(l0 + l1 + l2 + l3, misc, &total);
     tail[3] = my_start;
+  }
+  // every thread has read its part lengths (barrier inside the scan): the window can be cleared
+  // for the stitch under the same barrier that publishes the offsets
+  if (a.ablate != 3) {
+    for (int i = tid; i < kWinWords / 4; i += kScanThreads) reinterpret_cast<uint4*>(win)[i] = make_uint4(0, 0, 0, 0);
+    if (tid == 0) { win[kWinWords] = 0; misc[8] = total; }
   }
   if (a.ablate == 3) { if (tid == 0) a.seg_nbits[static_cast<size_t>(frame) * a.nseg + seg] = total; return; }
   __syncthreads();
@@ -816,13 +823,15 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
   uint32_t pending = 0;                            // bit r: part of round r still has to be placed
 #pragma unroll
   for (int r = 0; r < 4; ++r) if (ur_get(r) != 0xffffffffu) pending |= 1u << r;
-  for (;;) {
-    for (int i = tid; i < kWinWords / 4; i += kScanThreads) reinterpret_cast<uint4*>(win)[i] = make_uint4(0, 0, 0, 0);
-    if (tid == 0) win[kWinWords] = 0;
+  for (bool first_window = true;; first_window = false) {
     // the usual case -- the rest of the segment fits the window -- needs no vote
     const bool all_fit = total <= base + kWinWords * 32u;            // uniform
-    if (!all_fit && tid == 0) misc[8] = total;
-    __syncthreads();
+    if (!first_window) {                           // (the first window was cleared above)
+      for (int i = tid; i < kWinWords / 4; i += kScanThreads) reinterpret_cast<uint4*>(win)[i] = make_uint4(0, 0, 0, 0);
+      if (tid == 0) win[kWinWords] = 0;
+      if (!all_fit && tid == 0) misc[8] = total;
+      __syncthreads();
+    }
     if (tid == 0 && carry != 0) atomicOr(&win[0], carry);
     uint32_t fits = 0;
 #pragma unroll
