@@ -47,9 +47,13 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
     if (tid < 24) ldc[tid] = (&t->dc[0][0])[tid];
     if (TRELLIS && tid < 128) reinterpret_cast<uint32_t*>(smem + kOffTlen)[tid] = reinterpret_cast<const uint32_t*>(&t->tlen[0][0])[tid];
     // bookkeeping of the entropy phase that nothing touches until then: the sort's bins, the group queue
-    if (KIND == kKindEncode) {
+    if (KIND == kKindEncode || KIND == kKindStats) {
       if (tid < 32) win[kSortHist + tid] = 0;
       if (tid == 32) misc[10] = 0;
+    }
+    if (KIND == kKindStats) {                      // the symbol counters (their own LDS behind everything else)
+      uint32_t* const lf0 = reinterpret_cast<uint32_t*>(smem + kOffStats);
+      for (int i = tid; i < kStatsWords; i += kScanThreads) lf0[i] = 0;
     }
   };
 
@@ -519,8 +523,10 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
   // The counting sort of the parts (below) starts here: the bins were cleared when the tables were
   // staged, and the atomics that rank this block's parts are in flight across the DC barrier.
   uint32_t pc[4] = {0, 0, 0, 0}, rank[4] = {0, 0, 0, 0};
-  if (KIND == kKindEncode) {
-    *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(win + 64 + 512) + 4 * tid) = make_uint2(0u, 0u);
+  if (KIND == kKindEncode || KIND == kKindStats) {
+    if (KIND == kKindEncode) {
+      *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(win + 64 + 512) + 4 * tid) = make_uint2(0u, 0u);
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q) pc[q] = static_cast<uint32_t>(__popc(nzq[q]));
     if (emits) {
@@ -552,38 +558,18 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
   }
   tail[0] = nz_lo; tail[1] = nz_hi; tail[2] = dc_word;   // (the predictors live in tail[3])
 
+  uint32_t* const lf = reinterpret_cast<uint32_t*>(smem + kOffStats);   // kKindStats: [2][272], 256 AC then 16 DC
   if (KIND == kKindStats) {
     // Symbol statistics for optimised Huffman tables (reference AddEntropyStats,
     // src/entropy.cc:208-227): per table, counts of AC symbols (run << 4 | size, ZRL, EOB) and
-    // of DC size categories.  LDS counters, flushed as this workgroup's partial.
-    uint32_t* const lf = reinterpret_cast<uint32_t*>(smem + kOffStats);   // [2][272]: 256 AC then 16 DC
-    for (int i = tid; i < kStatsWords; i += kScanThreads) lf[i] = 0;
-    __syncthreads();
+    // of DC size categories, in LDS counters (cleared with the tables) flushed as this
+    // workgroup's partial.  The DC category here, the AC symbols by the same sorted parts the
+    // encode kind walks (below).
     if (emits) {
-      uint32_t* const f = lf + tbl * 272;
-      {
-        const int diff = dc_val - pred;
-        const int ad = diff < 0 ? -diff : diff;
-        atomicAdd(&f[256 + (32 - __clz(ad))], 1u);
-      }
-      const uint16_t* const zz = reinterpret_cast<const uint16_t*>(slot);
-      unsigned long long m = (static_cast<unsigned long long>(nz_hi) << 32) | nz_lo;
-      int prev = 1;
-      while (m) {
-        const int i = __builtin_ctzll(m);
-        m &= m - 1;
-        const uint32_t mag = zz[i] & 0x7fffu;
-        const int run = i - prev;
-        prev = i + 1;
-        if (run >> 4) atomicAdd(&f[0xf0], static_cast<uint32_t>(run >> 4));
-        atomicAdd(&f[((run & 15) << 4) | (32 - __clz(mag))], 1u);
-      }
-      if (prev <= 63) atomicAdd(&f[0x00], 1u);
+      const int diff = dc_val - pred;
+      const int ad = diff < 0 ? -diff : diff;
+      atomicAdd(&lf[tbl * 272 + 256 + (32 - __clz(ad))], 1u);
     }
-    __syncthreads();
-    uint32_t* const dst = a.partial + (static_cast<size_t>(frame) * a.nseg + seg) * kStatsWords;
-    for (int i = tid; i < kStatsWords; i += kScanThreads) dst[i] = lf[i];
-    return;
   }
 
   // The run/size coding of a block (src/entropy.cc:161-198) is a serial walk over its non-zero
@@ -625,6 +611,47 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
     __syncthreads();
   }
   stamp(3);
+  if (KIND == kKindStats) {
+    // a part's symbols are counted instead of coded: same masks, same runs, same quarter cut
+    const uint32_t n_groups_s = (n_units + 63u) >> 6;
+    for (int r = 0; r < 4; ++r) {
+      uint32_t grp = 0;
+      if ((tid & 63) == 0) grp = atomicAdd(&misc[10], 1u);
+      grp = __builtin_amdgcn_readfirstlane(grp);
+      if (grp >= n_groups_s) break;
+      const uint32_t idx = grp * 64u + (tid & 63u);
+      if (idx < n_units) {
+        const uint32_t unit = ulist[idx];
+        const int blk = static_cast<int>(unit & 255u), q = static_cast<int>(unit >> 8);
+        const unsigned char* const bslot = smem + blk * kSlotBytes;
+        const uint32_t* const btail = reinterpret_cast<const uint32_t*>(bslot + 128);
+        const unsigned long long m_all = (static_cast<unsigned long long>(btail[1]) << 32) | btail[0];
+        const int b_k = blk % BPM;
+        const int b_tbl = (MODE == SJPEG_HIP_YUV420) ? (b_k >= 4) : (MODE == SJPEG_HIP_YUV444 ? (b_k >= 1) : 0);
+        uint32_t* const f = lf + b_tbl * 272;
+        const uint16_t* const zz = reinterpret_cast<const uint16_t*>(bslot);
+        const int sh = 16 * q;
+        uint32_t m = static_cast<uint32_t>(m_all >> sh) & 0xffffu;
+        const unsigned long long below = m_all & ((1ull << sh) - 1ull);
+        const bool is_last = (q == 3) || ((m_all >> (sh + 16)) == 0ull);
+        int prev = below ? 64 - __builtin_clzll(below) : 1;
+        while (m) {
+          const int i = sh + __builtin_ctz(m);
+          m &= m - 1;
+          const uint32_t mag = zz[i] & 0x7fffu;
+          const int run = i - prev;
+          prev = i + 1;
+          if (run >> 4) atomicAdd(&f[0xf0], static_cast<uint32_t>(run >> 4));
+          atomicAdd(&f[((run & 15) << 4) | (32 - __clz(mag))], 1u);
+        }
+        if (is_last && prev <= 63) atomicAdd(&f[0x00], 1u);
+      }
+    }
+    __syncthreads();
+    uint32_t* const dst = a.partial + (static_cast<size_t>(frame) * a.nseg + seg) * kStatsWords;
+    for (int i = tid; i < kStatsWords; i += kScanThreads) dst[i] = lf[i];
+    return;
+  }
 
   // the walk reads 16-bit entries and writes 32-bit words in the same slot: no type-based reordering
   typedef uint16_t __attribute__((may_alias)) u16_alias;
