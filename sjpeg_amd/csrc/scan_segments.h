@@ -580,7 +580,8 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
   // A part needs only the block's non-zero mask to know the run in front of its first symbol and
   // whether it carries the EOB, and its bits are stitched at bit granularity like the blocks
   // themselves.  Parts are handed to threads sorted by their number of non-zeros (counting sort,
-  // descending), 256 per round: walks of at most 16 symbols with similar trip counts per wave.
+  // descending) in groups of 64 the waves draw from a queue: walks of at most 16 symbols with
+  // similar trip counts per wave.
   // The unit list and the part lengths live in the bit window, idle until the stitch.
   uint32_t* const hist = win + kSortHist;          // [32], bins 0..16 (cleared with the tables, filled before the DC barrier)
   uint16_t* const ulist = reinterpret_cast<uint16_t*>(win + 64);          // [1024] block | quarter << 8
