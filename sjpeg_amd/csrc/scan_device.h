@@ -65,7 +65,15 @@ constexpr int kOffWin = kSamplesBytes;
 constexpr int kOffQ = kOffWin;                                  // uint4[64]
 constexpr int kOffDc = kOffWin + 1024;                          // uint32[24]
 constexpr int kOffTlen = kOffWin + 1152;                        // uint8[2][256], trellis kinds only
-constexpr int kSortHist = 1100;                                 // window word of the sort's bins: beyond everything P2 reads
+// Entropy-phase bookkeeping inside the (still idle) bit window, as window WORD offsets.  All of it
+// lies behind the tables staged at the front of the window (quantizer 0..1023, DC codes ..1151,
+// trellis lengths ..1663 bytes): the DC codes are still being read by slow waves when fast ones
+// already write the part list -- there is no barrier between the two any more.
+constexpr int kPartLens = 576;                                  // u16 [256][4]: bits per part (bytes 2304..4351)
+constexpr int kSortHist = 1100;                                 // u32 [32]: the sort's bins (bytes 4400..4527)
+constexpr int kPartList = 1168;                                 // u16 [1024]: block | quarter << 8 (bytes 4672..6719)
+static_assert(kPartLens * 4 >= 1664 && kSortHist >= kPartLens + 512 && kPartList >= kSortHist + 32 &&
+              kPartList + 512 <= kWinWords, "bookkeeping behind the tables, inside the window");
 constexpr int kOffAc = kOffWin + kWinWords * 4 + 16;            // +1 spare word (16 B keeps alignment)
 constexpr int kOffMisc = kOffAc + 2 * 256 * 4;                  // scan scratch
 constexpr int kLdsBytes = kOffMisc + 64;                        // 47184: three workgroups per CU
@@ -471,6 +479,20 @@ __device__ __forceinline__ void fetch_plane(const uint8_t* plane, long long stri
     }
   }
 }
+
+#ifdef SJPEG_HIP_PRIO_STRESS
+// wave priority by wave index (pattern 1: 3,0,2,1 then 0,3,1,2; pattern 2: the reverse order)
+template <int PATTERN>
+__device__ __forceinline__ void prio_stress(int phase) {
+  const int k = (((threadIdx.x >> 6) & 3) + 2 * phase + (PATTERN == 2 ? 1 : 0)) & 3;
+  switch (k) {
+    case 0: __builtin_amdgcn_s_setprio(3); break;
+    case 1: __builtin_amdgcn_s_setprio(0); break;
+    case 2: __builtin_amdgcn_s_setprio(2); break;
+    default: __builtin_amdgcn_s_setprio(1);
+  }
+}
+#endif
 
 // workgroup exclusive scan of one uint32 per thread; returns exclusive prefix, *total = sum
 template <int NT, bool TRAILING_BARRIER = true>

@@ -40,6 +40,11 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
   const uint8_t* const frame_px = a.plane[0] + frame * a.frame_stride[0];
 
   // tables -> LDS; issued once the first pixel loads are in flight (see P1)
+#ifdef SJPEG_HIP_PRIO_STRESS
+  // race stress (make STRESS=1|2): the waves of a workgroup run at different priorities, flipped at
+  // the entropy phase -- a missing barrier shows up as a parity failure (one did)
+  prio_stress<SJPEG_HIP_PRIO_STRESS>(0);
+#endif
   auto stage_tables = [&]() {
     const DevTables* t = a.tables + frame * a.tables_stride;
     if (tid < 64) lq[tid] = (&t->q[0][0])[tid];
@@ -515,6 +520,9 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
   if (a.ablate == 2) { if (nz_lo + nz_hi + dc_val == 0x7fffffff) a.seg_nbits[0] = 1; return; }
 
   stamp(2);
+#ifdef SJPEG_HIP_PRIO_STRESS
+  prio_stress<SJPEG_HIP_PRIO_STRESS>(1);
+#endif
   // ---- P3: entropy coding ----------------------------------------------------------------
   // DC prediction (src/entropy.cc:133-150) through the 16 spare bytes of each slot.
   uint32_t* const tail = reinterpret_cast<uint32_t*>(slot + 128);
@@ -525,7 +533,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
   uint32_t pc[4] = {0, 0, 0, 0}, rank[4] = {0, 0, 0, 0};
   if (KIND == kKindEncode || KIND == kKindStats) {
     if (KIND == kKindEncode) {
-      *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(win + 64 + 512) + 4 * tid) = make_uint2(0u, 0u);
+      *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(win + kPartLens) + 4 * tid) = make_uint2(0u, 0u);
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) pc[q] = static_cast<uint32_t>(__popc(nzq[q]));
@@ -584,8 +592,8 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
   // similar trip counts per wave.
   // The unit list and the part lengths live in the bit window, idle until the stitch.
   uint32_t* const hist = win + kSortHist;          // [32], bins 0..16 (cleared with the tables, filled before the DC barrier)
-  uint16_t* const ulist = reinterpret_cast<uint16_t*>(win + 64);          // [1024] block | quarter << 8
-  uint16_t* const ulen = reinterpret_cast<uint16_t*>(win + 64 + 512);     // [256][4] bits per part
+  uint16_t* const ulist = reinterpret_cast<uint16_t*>(win + kPartList);   // [1024] block | quarter << 8
+  uint16_t* const ulen = reinterpret_cast<uint16_t*>(win + kPartLens);    // [256][4] bits per part
   uint32_t n_units;
   {
     // every wave scans the 17 bins (16, 15, ... 0) for itself: no hand-over through LDS, no barrier
