@@ -229,6 +229,15 @@ __global__ __launch_bounds__(kSweepThreads) void sharp_sweeps_fast(const SharpAr
   __shared__ int stop;
   __shared__ int16_t above[2][3][kFastCols * kSweepThreads];   // the updated row above, ping-pong
   const int frame = blockIdx.x, tid = threadIdx.x;
+#ifdef SJPEG_HIP_PRIO_STRESS
+  // race stress build (Makefile STRESS=1|2): the 16 waves run at four different priorities
+  switch (((tid >> 6) + SJPEG_HIP_PRIO_STRESS) & 3) {
+    case 0: __builtin_amdgcn_s_setprio(3); break;
+    case 1: __builtin_amdgcn_s_setprio(0); break;
+    case 2: __builtin_amdgcn_s_setprio(2); break;
+    default: __builtin_amdgcn_s_setprio(1);
+  }
+#endif
   for (int i = tid; i <= kMaxY; i += kSweepThreads) g2l[i] = a.tab->g2l[i];
   if (tid < kGammaTab + 2) l2g[tid] = a.tab->l2g[tid];
   uint16_t* const best_y = a.best_y + static_cast<size_t>(frame) * a.w * a.h;
