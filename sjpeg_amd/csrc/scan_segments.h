@@ -11,6 +11,21 @@ enum { kKindEncode = 0, kKindTap = 1, kKindHisto = 2, kKindStats = 3, kKindError
 constexpr int kHistoWords = 2 * 64 * 32;          // per-workgroup partial: u8 counters [2][64][128]
 constexpr int kStatsWords = 2 * 272;              // per-workgroup partial: u32 [2][256 AC + 16 DC]
 
+// Race stress build (make STRESS=1|2): RACE_POINT(n) holds ONE wave of every workgroup back at
+// point n when the engine's SJPEG_HIP_ABLATE is 0x5a000000 | count << 16 | n << 8 | wave -- a
+// wave that must not run ahead (or lag behind) without a barrier shows up as a parity failure
+// (tools/race_sweep.py walks all points and waves).
+#ifdef SJPEG_HIP_PRIO_STRESS
+#define RACE_POINT(n) race_point(a.ablate, n)
+__device__ __forceinline__ void race_point(int code, int n) {
+  if ((code >> 24) == 0x5a && ((code >> 8) & 255) == n && ((threadIdx.x >> 6) & 3) == (code & 3)) {
+    for (int i = 0; i < ((code >> 16) & 255); ++i) __builtin_amdgcn_s_sleep(127);
+  }
+}
+#else
+#define RACE_POINT(n)
+#endif
+
 template <int MODE, int KINDX, int SRC>
 __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) {
   constexpr bool TRELLIS = (KINDX == kKindEncodeTrellis || KINDX == kKindStatsTrellis);
@@ -202,6 +217,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
   }
   __syncthreads();
   stamp(1);
+  RACE_POINT(1);
   if (a.ablate == 1) return;
 
   // ---- P2: one thread per block: fix-up, fDCT, quantize ---------------------------------
@@ -528,6 +544,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
   uint32_t* const tail = reinterpret_cast<uint32_t*>(slot + 128);
   tail[3] = static_cast<uint32_t>(dc_val);
   // (sort bookkeeping that aliases nothing still in use is cleared under the same barrier)
+  RACE_POINT(2);
   // The counting sort of the parts (below) starts here: the bins were cleared when the tables were
   // staged, and the atomics that rank this block's parts are in flight across the DC barrier.
   uint32_t pc[4] = {0, 0, 0, 0}, rank[4] = {0, 0, 0, 0};
@@ -545,6 +562,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
     }
   }
   __syncthreads();
+  RACE_POINT(3);
   int pred = 0;
   {
     int prev;   // slot holding the previous block of the same component, stream order
@@ -596,6 +614,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
   uint16_t* const ulen = reinterpret_cast<uint16_t*>(win + kPartLens);    // [256][4] bits per part
   uint32_t n_units;
   {
+    RACE_POINT(4);
     // every wave scans the 17 bins (16, 15, ... 0) for itself: no hand-over through LDS, no barrier
     const int ln = tid & 63;
     const uint32_t hcnt = ln <= 16 ? hist[16 - ln] : 0u;
@@ -620,6 +639,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
     __syncthreads();
   }
   stamp(3);
+  RACE_POINT(5);
   if (KIND == kKindStats) {
     // a part's symbols are counted instead of coded: same masks, same runs, same quarter cut
     const uint32_t n_groups_s = (n_units + 63u) >> 6;
@@ -769,6 +789,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
   // of a full segment).  Measured: K1 1.194 -> 1.16 ms per 64 4K frames.
   const uint32_t n_groups = (n_units + 63u) >> 6;
   for (int r = 0; r < 4; ++r) {
+    RACE_POINT(6);
     uint32_t grp = 0;
     if ((tid & 63) == 0) grp = atomicAdd(&misc[10], 1u);
     grp = __builtin_amdgcn_readfirstlane(grp);
@@ -784,6 +805,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
   }
   __syncthreads();
   stamp(4);
+  RACE_POINT(7);
   // offsets are a prefix sum in STREAM order (thread tid owns block tid here); the lengths of
   // the first three parts stay with the block so that every part can find its own offset
   uint32_t total;
@@ -795,6 +817,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
     const uint32_t my_start = wg_exclusive_scan<kScanThreads, false>(l0 + l1 + l2 + l3, misc, &total);
     tail[3] = my_start;
   }
+  RACE_POINT(8);
   // every thread has read its part lengths (barrier inside the scan): the window can be cleared
   // for the stitch under the same barrier that publishes the offsets
   if (a.ablate != 3) {
@@ -803,6 +826,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
   }
   if (a.ablate == 3) { if (tid == 0) a.seg_nbits[static_cast<size_t>(frame) * a.nseg + seg] = total; return; }
   __syncthreads();
+  RACE_POINT(9);
   uint32_t us0 = 0, us1 = 0, us2 = 0, us3 = 0;     // bit offset of each of them in the segment
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
@@ -889,6 +913,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
     }
     __syncthreads();
     stamp(6);
+    RACE_POINT(10);
     const uint32_t filled = limit - base;          // bits valid in the window
     const bool last = (limit == total);
     const uint32_t nfull = last ? (filled + 31) >> 5 : filled >> 5;
@@ -898,6 +923,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
     base += filled & ~31u;
     __syncthreads();
   }
+  RACE_POINT(11);
   if (tid == 0) a.seg_nbits[static_cast<size_t>(frame) * a.nseg + seg] = total;
   stamp(7);
 }
