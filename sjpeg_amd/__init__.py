@@ -696,6 +696,7 @@ def encode_device_method(frames, quality=75.0, yuv_mode=YUV_420, method=4, engin
         q = np.asarray(quant, np.uint8).reshape(2, 64)
     out, sizes = eng.encode_batch(src, f, w, h, yuv_mode, q, method, min_quant, q_bias, dmax_luma, dmax_chroma,
                                   device=frames.device)
+    eng.wait()                                   # (pipelined mode: the output is complete after this)
     return _fetch_frames(out, sizes)
 
 
@@ -746,4 +747,5 @@ def encode_device(frames, quality=75.0, yuv_mode=YUV_420, engine=None, quant=Non
     f, h, w, _ = frames.shape
     header = make_header(w, h, yuv_mode, q)
     out, sizes = eng.encode_frames(frames, tables, header, yuv_mode)
+    eng.wait()                                   # (pipelined mode: the output is complete after this)
     return _fetch_frames(out, sizes)
