@@ -49,6 +49,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
     }
   };
   stamp(0);
+  RACE_POINT(0);
   const int m_first = (seg + a.seg_first) * G::kSegMcus;       // first coded MCU of the segment
   const int n_coded = min(G::kSegMcus, a.n_mcus - m_first);
   const int halo = m_first > 0 ? 1 : 0;                        // previous MCU: DC predictors only
@@ -260,6 +261,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
     }
     reinterpret_cast<int*>(slot + 128)[3] = sum;
     __syncthreads();
+    RACE_POINT(12);
     if (has_block && k >= 1 && k <= 3) {
       const int mcu = m_first - 1 + ml;
       const int mb_y = mcu / a.mb_w;
@@ -281,6 +283,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
       }
     }
     __syncthreads();
+    RACE_POINT(13);
   }
 
   // forward DCT: two columns per op, then row by row fused with quantization
