@@ -18,7 +18,8 @@ constexpr int kStatsWords = 2 * 272;              // per-workgroup partial: u32 
 #ifdef SJPEG_HIP_PRIO_STRESS
 #define RACE_POINT(n) race_point(a.ablate, n)
 __device__ __forceinline__ void race_point(int code, int n) {
-  if ((code >> 24) == 0x5a && ((code >> 8) & 255) == n && ((threadIdx.x >> 6) & 3) == (code & 3)) {
+  // (bit 7 set: every wave BUT that one is held back, i.e. the one wave runs ahead)
+  if ((code >> 24) == 0x5a && ((code >> 8) & 255) == n && ((((threadIdx.x >> 6) & 3) == (code & 3)) != ((code & 0x80) != 0))) {
     for (int i = 0; i < ((code >> 16) & 255); ++i) __builtin_amdgcn_s_sleep(127);
   }
 }

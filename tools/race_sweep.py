@@ -24,8 +24,8 @@ for i, (img, mode) in enumerate(cases):
 dev = [torch.from_numpy(img).cuda().unsqueeze(0) for (img, _) in cases]
 bad = runs = 0
 for point in range(0, 14):
-    for wave in range(4):
-        os.environ["SJPEG_HIP_ABLATE"] = str(0x5a000000 | (6 << 16) | (point << 8) | wave)
+    for wave in range(8):                          # 0..3: that wave lags; 4..7: that wave runs ahead of the others
+        os.environ["SJPEG_HIP_ABLATE"] = str(0x5a000000 | (6 << 16) | (point << 8) | (0x80 if wave >= 4 else 0) | (wave & 3))
         eng = sj.Engine(0)
         for i, (img, mode) in enumerate(cases):
             for method in (0, 4):
@@ -36,4 +36,4 @@ for point in range(0, 14):
                     print(f"MISMATCH point {point} wave {wave} case {i} method {method}", flush=True)
         eng.close()
 os.environ.pop("SJPEG_HIP_ABLATE", None)
-print(f"race sweep: {runs} encodes over 14 points x 4 waves, mismatches: {bad}")
+print(f"race sweep: {runs} encodes over 14 points x 4 waves, lagging and leading, mismatches: {bad}")
