@@ -1,0 +1,24 @@
+#!/bin/bash
+# Everything that guards parity, on a GPU box (through gpurun: /usr/local/graft/bin/gpurun --timeout 1800 -- 'bash tools/run_all_checks.sh').
+# Builds nothing itself except the stress configuration, and ALWAYS leaves the plain (shipped) build behind.
+set -u
+cd "$(dirname "$0")/.."
+run() { echo "== $*"; timeout "${T:-600}" "$@" 2>&1 | grep -v amdgpu.ids | tail -${N:-3}; }
+N=2 run python -m pytest tests -m gpu -x -q
+N=1 run python tools/gpu_fuzz.py 1 240
+N=1 run python tools/gpu_soak.py 1 "${SOAK:-120}"
+N=1 run python tools/thread_soak.py 16 100
+N=2 run python tools/engine_churn.py 100
+N=5 run python tools/many_frames_check.py
+if command -v hipcc >/dev/null 2>&1 || [ -x /opt/rocm/bin/hipcc ]; then
+  for s in 1 2; do
+    make -s -C sjpeg_amd/csrc STRESS=$s || exit 1
+    echo "== stress build $s"
+    N=2 run python -m pytest tests -m gpu -x -q
+    N=1 run python tools/race_sweep.py
+    N=1 run python tools/gpu_soak.py $((40 + s)) 60
+  done
+  make -s -C sjpeg_amd/csrc || exit 1
+  ls -a sjpeg_amd/csrc | grep config_
+fi
+N=1 run python bench.py --no-cpu-baseline
