@@ -235,15 +235,30 @@ __global__ __launch_bounds__(kThreads) void stuff_chunks(const StitchArgs a) {
   const uint32_t hsize = a.hdr_off ? a.hdr_off[frame + 1] - a.hdr_off[frame] : a.header_size;
   uint8_t* const dst0 = a.out + static_cast<size_t>(frame) * a.out_stride + hsize;
   if (a.sizes[frame] == 0) return;                          // did not fit (see K4)
-  for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+  // the 16 bytes of this thread in the NEXT chunk of the workgroup are requested while the current
+  // ones are stuffed
+  auto fetch = [&](uint32_t chunk, uint4* q, int* valid, unsigned long long* off) {
+    *q = make_uint4(0, 0, 0, 0);
+    *valid = 0;
+    *off = 0;
+    if (chunk >= nchunks) return;
     const unsigned long long w0 = static_cast<unsigned long long>(chunk) * kChunkWords + threadIdx.x * 4;
     const unsigned long long byte0 = w0 * 4;
-    uint4 q = make_uint4(0, 0, 0, 0);
-    int valid = 0;
+    *off = co[chunk];
     if (byte0 < U) {
-      q = *reinterpret_cast<const uint4*>(ub + w0);
-      valid = (U - byte0 >= 16) ? 16 : static_cast<int>(U - byte0);
+      *q = *reinterpret_cast<const uint4*>(ub + w0);
+      *valid = (U - byte0 >= 16) ? 16 : static_cast<int>(U - byte0);
     }
+  };
+  uint4 q_next;
+  int valid_next;
+  unsigned long long off_next;
+  fetch(blockIdx.x, &q_next, &valid_next, &off_next);
+  for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+    const uint4 q = q_next;
+    const int valid = valid_next;
+    const unsigned long long chunk_off = off_next;
+    fetch(chunk + gridDim.x, &q_next, &valid_next, &off_next);
     const uint32_t w[4] = {q.x, q.y, q.z, q.w};
     uint32_t ffs = 0;
     if (valid == 16) {
@@ -255,7 +270,7 @@ __global__ __launch_bounds__(kThreads) void stuff_chunks(const StitchArgs a) {
     }
     uint32_t total_ff;
     const uint32_t ex = wg_exclusive_scan<kThreads>(ffs, scratch, &total_ff);
-    uint8_t* const dchunk = dst0 + static_cast<unsigned long long>(chunk) * kChunkBytes + co[chunk];
+    uint8_t* const dchunk = dst0 + static_cast<unsigned long long>(chunk) * kChunkBytes + chunk_off;
     const uint32_t mis = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(dchunk) & 3u);
     uint8_t* sp = stage + mis + threadIdx.x * 16 + ex;
     // (4-byte stores at the lanes' odd offsets and a permute-based expansion of the words that
