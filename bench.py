@@ -170,7 +170,7 @@ def main():
     traffic = None
     try:
         import re
-        txt = open(os.path.join(ROOT, "profiles", "r01", "v8_pmc_summary.txt")).read()
+        txt = open(os.path.join(ROOT, "profiles", "r01", "v9_pmc_summary.txt")).read()
         blk = txt[txt.index("scan_segments<1"):]
         blk = blk[:blk.index("==", 5)] if "==" in blk[5:] else blk
         fetch = float(re.search(r"FETCH_SIZE\s+total=\S+\s+per_dispatch=(\S+)", blk).group(1))
