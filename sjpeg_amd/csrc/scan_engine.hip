@@ -346,7 +346,13 @@ int sjpeg_hip_engine_create(int device, sjpeg_hip_engine** engine) {
   sjpeg_hip_engine* e = new (std::nothrow) sjpeg_hip_engine;
   if (e == nullptr) return fail(SJPEG_HIP_ENOMEM, "host allocation failed");
   e->device = device;
-  if (const char* ab = getenv("SJPEG_HIP_ABLATE")) e->ablate = atoi(ab);   // profiling only
+  if (const char* ab = getenv("SJPEG_HIP_ABLATE")) {                       // profiling / race-stress aid only
+    e->ablate = atoi(ab);
+    if (e->ablate != 0) {
+      fprintf(stderr, "sjpeg_amd: SJPEG_HIP_ABLATE=%d is set: kernels skip phases or stall waves on purpose, "
+                      "the output of this engine is NOT valid JPEG data\n", e->ablate);
+    }
+  }
   e->want_stamps = getenv("SJPEG_HIP_STAMPS") != nullptr;
   *engine = e;
   return 0;
