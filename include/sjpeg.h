@@ -46,21 +46,18 @@ typedef enum {
 
 // One-call encode, reference: src/sjpeg.h:45 (== SjpegEncode(method 4, SJPEG_YUV_AUTO)).
 // *out_data is allocated with new[]; free with delete[] or SjpegFreeBuffer().
-size_t SjpegCompress(const uint8_t* rgb, int width, int height, float quality,
-                     uint8_t** out_data);
+size_t SjpegCompress(const uint8_t* rgb, int width, int height, float quality, uint8_t** out_data);
 
 // reference: src/sjpeg.h:104-109.  'stride' in bytes, |stride| >= 3*width, may be negative.
 // compression_method 0..8 as tabulated in the reference header (clamped).
-size_t SjpegEncode(const uint8_t* rgb, int width, int height, int stride,
-                   uint8_t** out_data, float quality, int compression_method,
-                   SjpegYUVMode yuv_mode);
+size_t SjpegEncode(const uint8_t* rgb, int width, int height, int stride, uint8_t** out_data,
+    float quality, int compression_method, SjpegYUVMode yuv_mode);
 
 // reference: src/sjpeg.h:113
 void SjpegFreeBuffer(const uint8_t* buffer);
 
 // JPEG-parsing helpers, reference: src/sjpeg.h:122-150 (pure host code)
-bool SjpegDimensions(const uint8_t* data, size_t size,
-                     int* width, int* height, int* is_yuv420);
+bool SjpegDimensions(const uint8_t* data, size_t size, int* width, int* height, int* is_yuv420);
 int SjpegFindQuantizer(const uint8_t* data, size_t size, uint8_t quant[2][64]);
 float SjpegEstimateQuality(const uint8_t matrix[64], bool for_chroma);
 void SjpegQuantMatrix(float quality, bool for_chroma, uint8_t matrix[64]);
@@ -76,10 +73,8 @@ const char* SjpegHipLastError();
 #endif
 
 // std::string flavours, reference: src/sjpeg.h:159-165
-bool SjpegCompress(const uint8_t* rgb, int width, int height, float quality,
-                   std::string* output);
-bool SjpegDimensions(const std::string& jpeg_data,
-                     int* width, int* height, int* is_yuv420);
+bool SjpegCompress(const uint8_t* rgb, int width, int height, float quality, std::string* output);
+bool SjpegDimensions(const std::string& jpeg_data, int* width, int* height, int* is_yuv420);
 int SjpegFindQuantizer(const std::string& jpeg_data, uint8_t quant[2][64]);
 
 namespace sjpeg {
@@ -140,40 +135,38 @@ struct EncoderParam {
 };
 
 // reference: src/sjpeg.h:280-292
-bool Encode(const uint8_t* rgb, int width, int height, int stride,
-            const EncoderParam& param, std::string* output);
-size_t Encode(const uint8_t* rgb, int width, int height, int stride,
-              const EncoderParam& param, uint8_t** out_data);
-bool Encode(const uint8_t* rgb, int width, int height, int stride,
-            const EncoderParam& param, sjpeg::ByteSink* sink);
+bool Encode(const uint8_t* rgb, int width, int height, int stride, const EncoderParam& param,
+    std::string* output);
+size_t Encode(const uint8_t* rgb, int width, int height, int stride, const EncoderParam& param,
+    uint8_t** out_data);
+bool Encode(const uint8_t* rgb, int width, int height, int stride, const EncoderParam& param,
+    sjpeg::ByteSink* sink);
 
 // Other input layouts, reference: src/sjpeg.h:300-349.  BGRA/RGBA: 4 bytes per pixel, alpha
 // ignored, stride >= 4*width.  Gray: luma samples as they are (YUV 4:0:0).  NV12/NV21: luma
 // plane + interleaved U,V (resp. V,U) plane of (width+1)/2 x (height+1)/2 pairs (YUV 4:2:0).
 // YUV444 / YUV420: three planes.  The colour mode is implied by the layout for all but
 // BGRA/RGBA (where param.yuv_mode selects 420 / 444 / 400).
-bool EncodeBGRA(const uint8_t* bgra, int width, int height, int stride,
-                const EncoderParam& param, sjpeg::ByteSink* sink);
-bool EncodeBGRA(const uint8_t* bgra, int width, int height, int stride,
-                const EncoderParam& param, std::string* output);
-bool EncodeRGBA(const uint8_t* rgba, int width, int height, int stride,
-                const EncoderParam& param, sjpeg::ByteSink* sink);
-bool EncodeRGBA(const uint8_t* rgba, int width, int height, int stride,
-                const EncoderParam& param, std::string* output);
-bool EncodeGray(const uint8_t* gray, int width, int height, int stride,
-                const EncoderParam& param, sjpeg::ByteSink* sink);
-bool EncodeGray(const uint8_t* gray, int width, int height, int stride,
-                const EncoderParam& param, std::string* output);
-bool EncodeNV21(const uint8_t* y, int y_stride, const uint8_t* vu, int vu_stride,
-                int width, int height, const EncoderParam& param, sjpeg::ByteSink* output);
-bool EncodeNV12(const uint8_t* y, int y_stride, const uint8_t* uv, int uv_stride,
-                int width, int height, const EncoderParam& param, sjpeg::ByteSink* output);
-bool EncodeYUV444(const uint8_t* Y, int Y_stride, const uint8_t* U, int U_stride,
-                  const uint8_t* V, int V_stride, int width, int height,
-                  const EncoderParam& param, sjpeg::ByteSink* output);
-bool EncodeYUV420(const uint8_t* Y, int Y_stride, const uint8_t* U, int U_stride,
-                  const uint8_t* V, int V_stride, int width, int height,
-                  const EncoderParam& param, sjpeg::ByteSink* output);
+bool EncodeBGRA(const uint8_t* bgra, int width, int height, int stride, const EncoderParam& param,
+    sjpeg::ByteSink* sink);
+bool EncodeBGRA(const uint8_t* bgra, int width, int height, int stride, const EncoderParam& param,
+    std::string* output);
+bool EncodeRGBA(const uint8_t* rgba, int width, int height, int stride, const EncoderParam& param,
+    sjpeg::ByteSink* sink);
+bool EncodeRGBA(const uint8_t* rgba, int width, int height, int stride, const EncoderParam& param,
+    std::string* output);
+bool EncodeGray(const uint8_t* gray, int width, int height, int stride, const EncoderParam& param,
+    sjpeg::ByteSink* sink);
+bool EncodeGray(const uint8_t* gray, int width, int height, int stride, const EncoderParam& param,
+    std::string* output);
+bool EncodeNV21(const uint8_t* y, int y_stride, const uint8_t* vu, int vu_stride, int width,
+    int height, const EncoderParam& param, sjpeg::ByteSink* output);
+bool EncodeNV12(const uint8_t* y, int y_stride, const uint8_t* uv, int uv_stride, int width,
+    int height, const EncoderParam& param, sjpeg::ByteSink* output);
+bool EncodeYUV444(const uint8_t* Y, int Y_stride, const uint8_t* U, int U_stride, const uint8_t* V,
+    int V_stride, int width, int height, const EncoderParam& param, sjpeg::ByteSink* output);
+bool EncodeYUV420(const uint8_t* Y, int Y_stride, const uint8_t* U, int U_stride, const uint8_t* V,
+    int V_stride, int width, int height, const EncoderParam& param, sjpeg::ByteSink* output);
 
 // reference: src/sjpeg.h:355-373
 struct SearchHook {
