@@ -15,7 +15,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libsjpeg_amd.so")
+LIB_PATH = os.environ.get("SJPEG_AMD_LIB") or os.path.join(CSRC, "libsjpeg_amd.so")   # (override: A/B builds in tools/)
 
 YUV_AUTO, YUV_420, YUV_SHARP, YUV_444, YUV_400 = range(5)
 

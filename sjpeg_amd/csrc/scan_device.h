@@ -32,6 +32,16 @@ struct DevTables {
   uint32_t dc[2][12];
   uint32_t ac[2][256];
   uint8_t tlen[2][256];    // trellis quantization: AC code lengths the rate is priced with
+  // Lean entropy walk: acm[c][22 + 9 - (n - 1) ...] -- row = clz(level) - 22 (level 1..1023 <=> clz 31..22),
+  // column = run & 15: (code << n) | (code length + n) << 27, i.e. everything of a run/size symbol but
+  // the n suffix bits, in one word.
+  uint32_t acm[2][10][16];
+  // bits a block's AC entries (sign-magnitude pairs) must NOT have for the lean walk to be provably
+  // in place: levels of n <= n_safe bits, n_safe = largest n with len(0, n') + n' <= 16 for all n' <= n
+  uint32_t safe_mask[2];
+  // 1, 2 or 3 ZRL codes as a left-aligned 64-bit pattern {high word, low word, bits, 0} (index 0 unused):
+  // what the stitch puts in front of a part whose first run is 16 or longer
+  uint4 zrlpat[2][4];
 };
 
 // source classes the colour phase is specialised for
@@ -75,8 +85,10 @@ constexpr int kPartList = 1168;                                 // u16 [1024]: b
 static_assert(kPartLens * 4 >= 1664 && kSortHist >= kPartLens + 512 && kPartList >= kSortHist + 32 &&
               kPartList + 512 <= kWinWords, "bookkeeping behind the tables, inside the window");
 constexpr int kOffAc = kOffWin + kWinWords * 4 + 16;            // +1 spare word (16 B keeps alignment)
-constexpr int kOffMisc = kOffAc + 2 * 256 * 4;                  // scan scratch
-constexpr int kLdsBytes = kOffMisc + 64;                        // 47184: three workgroups per CU
+constexpr int kOffAcm = kOffAc + 2 * 256 * 4;                   // uint32[2][10][16]: merged code words of the lean walk
+constexpr int kOffZrl = kOffAcm + 2 * 160 * 4;                  // uint4[2][4]: ZRL patterns
+constexpr int kOffMisc = kOffZrl + 128;                         // scan scratch
+constexpr int kLdsBytes = kOffMisc + 64;                        // 48592: three workgroups per CU
 constexpr int kOffStats = kLdsBytes;                            // kKindStats only: u32[2][272]
 constexpr int kLdsBytesStats = kOffStats + 2 * 272 * 4;
 static_assert(kWinWords * 4 >= 1152 + 512 && kWinWords >= 64 + 512 + 512, "window region too small");

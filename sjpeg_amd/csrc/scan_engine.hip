@@ -161,6 +161,36 @@ void digest_tables(const sjpeg_hip_scan_tables* t, DevTables* d) {
   memcpy(d->dc, t->dc_codes, sizeof(d->dc));
   memcpy(d->ac, t->ac_codes, sizeof(d->ac));
   memcpy(d->tlen, t->trellis_len, sizeof(d->tlen));
+  // the lean walk's merged code words and the level bound under which it is provably in place
+  // (scan_segments.h, P3): a symbol of run 0 must not emit more than 16 bits
+  for (int c = 0; c < 2; ++c) {
+    int n_safe = 0;
+    for (int n = 1; n <= 10; ++n) {
+      const uint32_t len0 = t->ac_codes[c][n] & 0xffu;            // symbol (run 0, size n); 0 = not in the table
+      if (len0 + n > 16u) break;
+      n_safe = n;
+    }
+    {
+      const uint32_t zrl = t->ac_codes[c][0xf0];
+      const uint32_t zl = zrl & 0xffu;
+      unsigned long long v = 0;
+      d->zrlpat[c][0] = make_uint4(0, 0, 0, 0);
+      for (uint32_t k = 1; k <= 3; ++k) {
+        v = (v << zl) | (zrl >> 16);
+        const unsigned long long left = (zl == 0u) ? 0ull : v << (64u - k * zl);
+        d->zrlpat[c][k] = make_uint4(static_cast<uint32_t>(left >> 32), static_cast<uint32_t>(left), k * zl, 0u);
+      }
+    }
+    const uint32_t bad = ~((1u << n_safe) - 1u) & 0x7fffu;
+    d->safe_mask[c] = bad | (bad << 16);
+    for (int n = 1; n <= 10; ++n) {
+      for (int run = 0; run < 16; ++run) {
+        const uint32_t cw = t->ac_codes[c][(run << 4) | n];
+        const uint32_t len = cw & 0xffu, code = cw >> 16;
+        d->acm[c][10 - n][run] = len == 0u ? 0u : ((code << n) | ((len + n) << 27));
+      }
+    }
+  }
 }
 
 template <int KIND, int SRC>

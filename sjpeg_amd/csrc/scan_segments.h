@@ -67,6 +67,12 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
     if (tid < 64) lq[tid] = (&t->q[0][0])[tid];
     for (int i = tid; i < 512; i += kScanThreads) lac[i] = (&t->ac[0][0])[i];
     if (tid < 24) ldc[tid] = (&t->dc[0][0])[tid];
+    if (tid >= 24 && tid < 26) ldc[tid] = t->safe_mask[tid - 24];
+    if (KIND == kKindEncode) {
+      uint32_t* const lacm0 = reinterpret_cast<uint32_t*>(smem + kOffAcm);
+      for (int i = tid; i < 320; i += kScanThreads) lacm0[i] = (&t->acm[0][0][0])[i];
+      if (tid >= 32 && tid < 40) reinterpret_cast<uint4*>(smem + kOffZrl)[tid - 32] = (&t->zrlpat[0][0])[tid - 32];
+    }
     if (TRELLIS && tid < 128) reinterpret_cast<uint32_t*>(smem + kOffTlen)[tid] = reinterpret_cast<const uint32_t*>(&t->tlen[0][0])[tid];
     // bookkeeping of the entropy phase that nothing touches until then: the sort's bins, the group queue
     if (KIND == kKindEncode || KIND == kKindStats) {
@@ -231,6 +237,8 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
   unsigned char* const slot = smem + tid * kSlotBytes;
   uint32_t nzq[4] = {0, 0, 0, 0};                   // non-zero masks of the four zig-zag quarters
   int dc_val = 0;
+  // some AC level of the block has more bits than the lean walk (P3) is provably in place for
+  uint32_t unsafe = 0;
   // what a statistics pass keeps for the replay kind: the slot as P2 leaves it + masks + DC value
   uint4* const keep = (a.replay == nullptr) ? nullptr
       : reinterpret_cast<uint4*>(a.replay) + ((static_cast<size_t>(frame) * a.nseg + seg) * kScanThreads + tid) * 9;
@@ -240,6 +248,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
     const uint4 t = keep[8];
     nzq[0] = t.x & 0xffffu; nzq[1] = t.x >> 16; nzq[2] = t.y & 0xffffu; nzq[3] = t.y >> 16;
     dc_val = static_cast<int>(t.z);
+    unsafe = t.w;
   }
   if (!REPLAY) {
   // rows as packed int16 pairs, straight from the slot: p[r][c] = (s[r][2c], s[r][2c+1])
@@ -416,6 +425,12 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
   if (!TRELLIS) {
     const int dc_mag = static_cast<int>(ent[0] & 0x7fffu);
     dc_val = (ent[0] & 0x8000u) ? -dc_mag : dc_mag;
+    if (KIND == kKindEncode || KIND == kKindStats) {
+      uint32_t any = ent[0] & 0xffff0000u;         // (the DC entry is not an AC level)
+#pragma unroll
+      for (int i = 1; i < 32; ++i) any |= ent[i];
+      unsafe = (any & ldc[24 + tbl]) != 0u ? 1u : 0u;
+    }
   } else {
     // Trellis quantization (reference Encoder::TrellisQuantizeBlock + SearchBestPrev,
     // src/quantize.cc:325-457): the slot holds the RAW coefficients in zig-zag order.  For every
@@ -507,6 +522,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
         const uint32_t pos = (ci >> 12) & 63u;
         zzw[pos] = static_cast<uint16_t>((ci & 0x7ffu) | (((ci >> 11) & 1u) << 15));
         nzm |= 1ull << pos;
+        unsafe |= ((ci & 0x7ffu) & ldc[24 + tbl]) != 0u ? 1u : 0u;
       }
     } else {
 #pragma unroll
@@ -519,7 +535,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
   if (KIND == kKindStats && keep != nullptr) {   // leave the quantized block behind for the replay kind
 #pragma unroll
     for (int r = 0; r < 8; ++r) keep[r] = *reinterpret_cast<const uint4*>(slot + 16 * r);
-    keep[8] = make_uint4(nzq[0] | (nzq[1] << 16), nzq[2] | (nzq[3] << 16), static_cast<uint32_t>(dc_val), 0u);
+    keep[8] = make_uint4(nzq[0] | (nzq[1] << 16), nzq[2] | (nzq[3] << 16), static_cast<uint32_t>(dc_val), unsafe);
   }
   }   // !REPLAY
   const uint32_t nz_lo = nzq[0] | (nzq[1] << 16), nz_hi = nzq[2] | (nzq[3] << 16);
@@ -586,6 +602,8 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
     const uint32_t code = ldc[tbl * 12 + n];
     dc_word = (((code & 0xffu) + n) << 24) | ((code >> 16) << n) | suffix;
   }
+  // bit 29: the block takes the checked walk; bit 30: chroma tables (read by whoever codes a part of it)
+  dc_word |= (unsafe << 29) | (static_cast<uint32_t>(tbl) << 30);
   tail[0] = nz_lo; tail[1] = nz_hi; tail[2] = dc_word;   // (the predictors live in tail[3])
 
   uint32_t* const lf = reinterpret_cast<uint32_t*>(smem + kOffStats);   // kKindStats: [2][272], 256 AC then 16 DC
@@ -759,7 +777,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
     };
     int iA = next_pos(), iB = kEnd;
     uint32_t eA = zz[iA], eB = 0, cA = 0, cB = 0, sA = 0, sB = 0;
-    if (q == 0) append(b_dc & 0xffffffu, b_dc >> 24, iA);
+    if (q == 0) append(b_dc & 0xffffffu, (b_dc >> 24) & 31u, iA);
     bool pend = false;                             // a symbol waits for stage B (in cA/sA)
     while (iA != kEnd) {
       step(iA, eA, iB, eB, cA, sA, pend, cB, sB);
@@ -780,17 +798,89 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
     spill_out = wr > wr_lim ? wr_lim : kNoSpill;
   };
 
-  // what this thread coded in each round: unit | spill << 10 | len << 16, 0xffffffff = nothing.
-  // (four registers picked by the round counter: one copy of the walk for all rounds)
+  // The LEAN walk codes every part of a block whose AC levels have at most n_safe bits (all of them in
+  // ordinary pictures; DevTables::safe_mask).  It has no stage pipeline, no spill row and no
+  // frontier test: a finished word is stored over the part's own entries unconditionally, because
+  // under the level bound it can never reach an entry that is still to be read.  Proof: let T(i) be
+  // the bits produced once the entry at local position i (0..15) is coded.  A symbol of run r makes
+  // at most 16 + n_safe <= 16 (r + 1) bits when r >= 1, and at most 16 when r = 0 (that IS the
+  // definition of n_safe); the DC symbol in front of quarter 0 has at most 27 <= 16 + 15 bits; the run
+  // of a part's FIRST symbol is taken modulo 16 here, its ZRL codes travel in the part's record and
+  // are placed by the stitch.  Hence T(i) <= 16 (i + 1) + 15 by induction, the words complete at that
+  // point are 0 .. floor(T(i) / 32) - 1, and the last of them covers the entries up to
+  // 2 floor(T(i) / 32) - 1 <= i: all read.  With the EOB (<= 16 bits) T <= 287, so at most 8 words are
+  // stored (the quarter has room for exactly 8); the last, partial word stays in a register.
+  // Code words come from the merged table (code << n | total length << 27), indexed by clz(level)
+  // and run, so a symbol costs two LDS reads and about thirty simple instructions.
+  const uint32_t acm_base = static_cast<uint32_t>(kOffAcm) - 22u * 64u;   // row = clz - 22, 64 bytes per row
+  auto walk_lean = [&](uint32_t unit, uint4 bt, uint32_t& rec_out, uint32_t& tail_out) {
+    const uint32_t blk = unit & 255u, q = unit >> 8;
+    const uint32_t slot_off = blk * kSlotBytes;
+    const uint32_t b_tbl = (bt.z >> 30) & 1u;
+    const uint32_t* const ac = lac + b_tbl * 256;
+    const uint32_t tb = acm_base + b_tbl * 640u;
+    const uint32_t lo = bt.x, hi = bt.y;
+    const uint32_t mw = (q & 2u) ? hi : lo;
+    uint32_t m = (q & 1u) ? (mw >> 16) : (mw & 0xffffu);           // the part's own 16 positions
+    const uint32_t below_lo = q >= 2u ? lo : (q == 1u ? (lo & 0xffffu) : 0u);
+    const uint32_t below_hi = q == 3u ? (hi & 0xffffu) : 0u;
+    uint32_t prev = below_hi ? 64u - __clz(below_hi) : 32u - __clz(below_lo | 1u);   // position after the previous non-zero (1 = none)
+    const uint32_t above = q == 0u ? ((lo >> 16) | hi) : (q == 1u ? hi : (q == 2u ? (hi >> 16) : 0u));
+    const uint32_t sh = 16u * q;
+    uint32_t acc = 0, fill = 0;                    // bits of the word in the making, left-aligned; their number
+    const uint32_t wp0 = slot_off + 32u * q;
+    uint32_t wp = wp0;                             // byte offset of the next word
+    if (q == 0u) {
+      fill = (bt.z >> 24) & 31u;
+      acc = __builtin_amdgcn_alignbit(bt.z & 0xffffffu, 0u, fill);   // DC bits << (32 - fill)
+    }
+    uint32_t nzrl = 0;
+    if (m) nzrl = (sh + static_cast<uint32_t>(__builtin_ctz(m)) - prev) >> 4;   // (always 0 in quarter 0)
+    auto append = [&](uint32_t bits, uint32_t nb) {                  // 1 <= nb <= 27
+      const uint32_t t = fill + nb;
+      const uint32_t s5 = t & 31u;
+      const uint32_t P = __builtin_amdgcn_alignbit(bits, 0u, s5);   // bits << (32 - s5); 0 for s5 == 0
+      const uint32_t Q = bits >> s5;
+      const bool full = t >= 32u;
+      if (full) *reinterpret_cast<u32_alias*>(smem + wp) = acc | Q;
+      acc = full ? P : (acc | P);
+      wp += (t >> 3) & 4u;
+      fill = s5;
+    };
+    while (m) {
+      const uint32_t i = sh + static_cast<uint32_t>(__builtin_ctz(m));
+      m &= m - 1u;
+      const uint32_t e = *reinterpret_cast<const u16_alias*>(smem + slot_off + 2u * i);
+      const uint32_t run = (i - prev) & 15u;
+      prev = i + 1u;
+      const uint32_t mag = e & 0x7fffu;
+      const uint32_t nl = static_cast<uint32_t>(__clz(mag));      // 32 - n
+      const uint32_t ones = 0xffffffffu >> nl;
+      const uint32_t sgn = static_cast<uint32_t>(__builtin_amdgcn_sbfe(static_cast<int>(e), 15, 1));
+      const uint32_t cw = *reinterpret_cast<const uint32_t*>(smem + tb + nl * 64u + run * 4u);
+      append((cw & 0x07ffffffu) | (mag ^ (ones & sgn)), cw >> 27);
+    }
+    if (above == 0u && prev <= 63u) { const uint32_t eob = ac[0x00]; append(eob >> 16, eob & 0xffu); }
+    const uint32_t len = ((wp - wp0) << 3) + fill;
+    const uint32_t zl = ac[0xf0] & 0xffu;
+    ulen[4 * blk + q] = static_cast<uint16_t>(len + nzrl * zl);
+    rec_out = unit | (31u << 10) | (nzrl << 15) | (len << 17) | (1u << 27) | (b_tbl << 28);
+    tail_out = acc;
+  };
+
+  // what this thread coded in each round: unit | spill << 10 | ZRLs in front << 15 | len << 17 |
+  // lean << 27 | chroma tables << 28, 0xffffffff = nothing; and the part's last, partial word (lean walk)
+  // (four registers picked by the round counter: one copy of the walks for all rounds)
   uint32_t ur0 = 0xffffffffu, ur1 = 0xffffffffu, ur2 = 0xffffffffu, ur3 = 0xffffffffu;
+  uint32_t tw0 = 0, tw1 = 0, tw2 = 0, tw3 = 0;
   auto ur_get = [&](int r) { return r == 0 ? ur0 : r == 1 ? ur1 : r == 2 ? ur2 : ur3; };
+  auto tw_get = [&](int r) { return r == 0 ? tw0 : r == 1 ? tw1 : r == 2 ? tw2 : tw3; };
   // The list is sorted: handed out in order, wave 0's 64 parts would be the heaviest of every
   // round and the other waves would wait for it at the barrier below.  Groups of 64 parts go to
   // the waves in boustrophedon order instead (0 1 2 3 / 7 6 5 4 / ...), which is static: a thread
   // knows its (up to) four parts at once and fetches their list entries and block tails together,
-  // instead of one dependent chain of LDS round trips in front of every walk.  (A queue the waves
-  // drew groups from balanced as well but kept the chains: 1.14 against 1.125 ms per 64 4K frames.)
-  uint32_t un[4]; unsigned long long mm[4]; uint32_t dd[4];
+  // instead of one dependent chain of LDS round trips in front of every walk.
+  uint32_t un[4]; uint4 bts[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const uint32_t grp = static_cast<uint32_t>(4 * r) + ((r & 1) ? 3u - (tid >> 6) : (tid >> 6));
@@ -799,33 +889,36 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
   }
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const uint32_t* const bt = reinterpret_cast<const uint32_t*>(smem + (un[r] & 255u) * kSlotBytes + 128);
-    mm[r] = (static_cast<unsigned long long>(bt[1]) << 32) | bt[0];
-    dd[r] = bt[2];
+    bts[r] = *reinterpret_cast<const uint4*>(smem + (un[r] & 255u) * kSlotBytes + 128);
   }
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     RACE_POINT(6);
     if (un[r] != 0xffffffffu) {
-      uint32_t len, wsp;
-      walk(un[r], mm[r], dd[r], len, wsp);
-      const uint32_t rec = un[r] | ((wsp & 31u) << 10) | (len << 16);   // spill index 0..15, 31 = none
-      if (r == 0) ur0 = rec; else if (r == 1) ur1 = rec; else if (r == 2) ur2 = rec; else ur3 = rec;
+      uint32_t rec, tw = 0;
+      if ((bts[r].z >> 29) & 1u) {
+        uint32_t len, wsp;
+        walk(un[r], (static_cast<unsigned long long>(bts[r].y) << 32) | bts[r].x, bts[r].z, len, wsp);
+        rec = un[r] | ((wsp & 31u) << 10) | (len << 17) | (((bts[r].z >> 30) & 1u) << 28);   // spill index 0..15, 31 = none
+      } else {
+        walk_lean(un[r], bts[r], rec, tw);
+      }
+      if (r == 0) { ur0 = rec; tw0 = tw; } else if (r == 1) { ur1 = rec; tw1 = tw; }
+      else if (r == 2) { ur2 = rec; tw2 = tw; } else { ur3 = rec; tw3 = tw; }
     }
   }
   __syncthreads();
   stamp(4);
   RACE_POINT(7);
-  // offsets are a prefix sum in STREAM order (thread tid owns block tid here); the lengths of
-  // the first three parts stay with the block so that every part can find its own offset
+  // offsets are a prefix sum in STREAM order (thread tid owns block tid here); the block's tail
+  // (masks and DC word: consumed) becomes the bit offsets of its four parts
   uint32_t total;
   {
     const uint2 L = *reinterpret_cast<const uint2*>(ulen + 4 * tid);
     const uint32_t l0 = L.x & 0xffffu, l1 = L.x >> 16, l2 = L.y & 0xffffu, l3 = L.y >> 16;
-    tail[2] = l0 | (l1 << 10) | (l2 << 20);
     // (the scratch words are not used again: the barrier after the window is cleared, below, closes the scan)
-    const uint32_t my_start = wg_exclusive_scan<kScanThreads, false>(l0 + l1 + l2 + l3, misc, &total);
-    tail[3] = my_start;
+    const uint32_t s0 = wg_exclusive_scan<kScanThreads, false>(l0 + l1 + l2 + l3, misc, &total);
+    *reinterpret_cast<uint4*>(tail) = make_uint4(s0, s0 + l0, s0 + l0 + l1, s0 + l0 + l1 + l2);
   }
   RACE_POINT(8);
   // every thread has read its part lengths (barrier inside the scan): the window can be cleared
@@ -837,19 +930,10 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
   if (a.ablate == 3) { if (tid == 0) a.seg_nbits[static_cast<size_t>(frame) * a.nseg + seg] = total; return; }
   __syncthreads();
   RACE_POINT(9);
-  uint32_t us0 = 0, us1 = 0, us2 = 0, us3 = 0;     // bit offset of each of them in the segment
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const uint32_t rec = ur_get(r);
-    if (rec != 0xffffffffu) {
-      const uint32_t* const btail = reinterpret_cast<const uint32_t*>(smem + (rec & 255u) * kSlotBytes + 128);
-      const uint32_t pk = btail[2], q = (rec >> 8) & 3u;
-      const uint32_t l0 = pk & 1023u, l1 = (pk >> 10) & 1023u, l2 = (pk >> 20) & 1023u;
-      const uint32_t st = btail[3] + (q >= 1u ? l0 : 0u) + (q >= 2u ? l1 : 0u) + (q >= 3u ? l2 : 0u);
-      if (r == 0) us0 = st; else if (r == 1) us1 = st; else if (r == 2) us2 = st; else us3 = st;
-    }
-  }
-  auto us_get = [&](int r) { return r == 0 ? us0 : r == 1 ? us1 : r == 2 ? us2 : us3; };
+  // a part's bit offset in the segment: word q of its block's tail
+  auto part_start = [&](uint32_t rec) {
+    return *reinterpret_cast<const uint32_t*>(smem + (rec & 255u) * kSlotBytes + 128 + 4u * ((rec >> 8) & 3u));
+  };
 
   stamp(5);
   // Stitch: every part's words are shifted to its bit offset and ORed into the LDS window,
@@ -858,41 +942,56 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
   uint32_t* const out_words = a.seg_words + (static_cast<size_t>(frame) * a.nseg + seg) * a.slot_words;
   uint32_t base = 0;                               // bit position of window word 0, multiple of 32
   uint32_t carry = 0;
-  auto place = [&](uint32_t rec, uint32_t start) {
-    const uint32_t blk = rec & 255u, q = (rec >> 8) & 3u, len = rec >> 16;
+  auto place = [&](uint32_t rec, uint32_t pos, uint32_t tailw) {   // pos: bit position in the window
+    const uint32_t blk = rec & 255u, q = (rec >> 8) & 3u, len = (rec >> 17) & 1023u;
+    const uint32_t nzrl = (rec >> 15) & 3u;
+    if (nzrl) {
+      // the ZRL codes in front of the part's first symbol (lean walk): up to 3 x 16 bits
+      const uint4 zp = reinterpret_cast<const uint4*>(smem + kOffZrl)[((rec >> 28) & 1u) * 4u + nzrl];
+      const uint32_t o = pos & 31u;
+      uint32_t* const dst = win + (pos >> 5);
+      atomicOr(dst, zp.x >> o);
+      atomicOr(dst + 1, __builtin_amdgcn_alignbit(zp.x, zp.y, o));
+      if (o + zp.z > 64u) atomicOr(dst + 2, zp.y << (32u - o));
+      pos += zp.z;
+    }
+    const uint32_t o = pos & 31u;
+    if ((rec >> 27) & 1u) {
+      // lean walk: len >> 5 full words in the part's quarter, the rest (left-aligned) in tailw
+      uint32_t src = blk * kSlotBytes + 32u * q;
+      const uint32_t src_end = src + ((len >> 5) << 2);
+      uint32_t dst = static_cast<uint32_t>(kOffWin) + ((pos >> 5) << 2);
+      uint32_t before = 0;                         // source word j - 1
+      while (src != src_end) {
+        const uint32_t v = *reinterpret_cast<const u32_alias*>(smem + src);
+        atomicOr(reinterpret_cast<uint32_t*>(smem + dst), __builtin_amdgcn_alignbit(before, v, o));   // (before:v) >> o
+        before = v;
+        src += 4u; dst += 4u;
+      }
+      atomicOr(reinterpret_cast<uint32_t*>(smem + dst), __builtin_amdgcn_alignbit(before, tailw, o));
+      if (o + (len & 31u) > 32u) atomicOr(reinterpret_cast<uint32_t*>(smem + dst + 4u), tailw << (32u - o));
+      return;
+    }
     const uint32_t wr_spill = ((rec >> 10) & 31u) == 31u ? kNoSpill : ((rec >> 10) & 31u);
     const u32_alias* const bw = reinterpret_cast<const u32_alias*>(smem + blk * kSlotBytes) + 8 * q;
     const uint32_t* const spill = spill_wg + blk * kSpillWords + 16 * q;
-    const uint32_t nw = (len + 31u) >> 5;
-    const uint32_t pos = start - base;
-    const uint32_t o = pos & 31u;
+    const uint32_t nw = (len + 31u) >> 5;          // words of the part, the last one left-aligned
     uint32_t* const dst = win + (pos >> 5);
-    uint32_t before = 0;                           // source word j - 1
-    if (wr_spill == kNoSpill) {                    // nw <= 8, all inside the quarter
-      for (uint32_t j0 = 0; j0 < nw; j0 += 4) {
-        const uint4 v4 = *reinterpret_cast<const uint4*>(bw + j0);
-        uint32_t v[4] = {v4.x, v4.y, v4.z, v4.w};
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const uint32_t j = j0 + u;
-          if (j >= nw) v[u] = 0;
-          if (j <= nw) atomicOr(dst + j, __builtin_amdgcn_alignbit(before, v[u], o));   // (before:v) >> o
-          before = v[u];
-        }
-      }
-    } else {
-      for (uint32_t j = 0; j < ((nw + 3u) & ~3u); ++j) {                // same schedule, word by word
-        uint32_t v = 0;
-        if (j < nw) v = (j < wr_spill) ? bw[j] : spill[j];
-        if (j <= nw) atomicOr(dst + j, __builtin_amdgcn_alignbit(before, v, o));
-        before = v;
-      }
+    uint32_t before = 0;
+    for (uint32_t j = 0; j <= nw; ++j) {
+      uint32_t v = 0;
+      if (j < nw) v = (j < wr_spill) ? bw[j] : spill[j];
+      if (j < nw || o != 0u) atomicOr(dst + j, __builtin_amdgcn_alignbit(before, v, o));
+      before = v;
     }
-    if ((nw & 3u) == 0u && o != 0u) atomicOr(dst + nw, before << (32u - o));
   };
+  // bits of a part in the stream, ZRL codes in front included (the window test wants an upper bound: 16 each)
+  auto part_bits = [&](uint32_t rec) { return ((rec >> 17) & 1023u) + 16u * ((rec >> 15) & 3u); };
   uint32_t pending = 0;                            // bit r: part of round r still has to be placed
 #pragma unroll
   for (int r = 0; r < 4; ++r) if (ur_get(r) != 0xffffffffu) pending |= 1u << r;
+  // (the loops over the four rounds are NOT unrolled: four inlined copies of place() had the compiler
+  // hoist ~250 instructions of address arithmetic in front of them, most of it for the rare spill path)
   for (bool first_window = true;; first_window = false) {
     // the usual case -- the rest of the segment fits the window -- needs no vote
     const bool all_fit = total <= base + kWinWords * 32u;            // uniform
@@ -903,22 +1002,27 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
       __syncthreads();
     }
     if (tid == 0 && carry != 0) atomicOr(&win[0], carry);
-    uint32_t fits = 0;
-#pragma unroll
+    uint32_t limit = total;
+    if (!all_fit) {
+#pragma unroll 1
+      for (int r = 0; r < 4; ++r) {
+        if (pending & (1u << r)) {
+          const uint32_t rec = ur_get(r), st = part_start(rec);
+          if (st + part_bits(rec) > base + kWinWords * 32u) atomicMin(&misc[8], st);
+        }
+      }
+      __syncthreads();
+      // everything that starts before the first non-fitting part (stream order) is placed now
+      limit = misc[8];
+    }
+#pragma unroll 1
     for (int r = 0; r < 4; ++r) {
       if (pending & (1u << r)) {
-        if (all_fit || us_get(r) + (ur_get(r) >> 16) <= base + kWinWords * 32u) fits |= 1u << r;
-        else atomicMin(&misc[8], us_get(r));
-      }
-    }
-    if (!all_fit) __syncthreads();
-    // everything that starts before the first non-fitting part (stream order) is placed now
-    const uint32_t limit = all_fit ? total : misc[8];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      if ((fits & (1u << r)) && us_get(r) < limit) {
-        place(ur_get(r), us_get(r));
-        pending &= ~(1u << r);
+        const uint32_t rec = ur_get(r), st = part_start(rec);
+        if (all_fit || (st + part_bits(rec) <= base + kWinWords * 32u && st < limit)) {
+          place(rec, st - base, tw_get(r));
+          pending &= ~(1u << r);
+        }
       }
     }
     __syncthreads();
