@@ -27,22 +27,28 @@ template <> struct Geo<SJPEG_HIP_YUV400> {
 };
 
 // device copy of sjpeg_hip_scan_tables, pre-digested
-struct DevTables {
+// Laid out as the kernels stage it: two contiguous groups copied to LDS 16 bytes per thread.
+struct alignas(16) DevTables {
+  // group A (1152 B, lives in the idle bit window until the DC codes are done)
   uint4 q[2][32];          // per natural-order PAIR (2j, 2j+1): {iq0 | iq1<<16, bias0*iq0, bias1*iq1, q0 | q1<<16}
   uint32_t dc[2][12];
-  uint32_t ac[2][256];
-  uint8_t tlen[2][256];    // trellis quantization: AC code lengths the rate is priced with
-  // Lean entropy walk: acm[c][22 + 9 - (n - 1) ...] -- row = clz(level) - 22 (level 1..1023 <=> clz 31..22),
-  // column = run & 15: (code << n) | (code length + n) << 27, i.e. everything of a run/size symbol but
-  // the n suffix bits, in one word.
-  uint32_t acm[2][10][16];
   // bits a block's AC entries (sign-magnitude pairs) must NOT have for the lean walk to be provably
   // in place: levels of n <= n_safe bits, n_safe = largest n with len(0, n') + n' <= 16 for all n' <= n
   uint32_t safe_mask[2];
+  uint32_t pad_a[6];
+  // group B (3456 B)
+  uint32_t ac[2][256];
+  // Lean entropy walk: row = clz(level) - 22 (level 1..1023 <=> clz 31..22), column = run & 15:
+  // (code << n) | (code length + n) << 27, i.e. everything of a run/size symbol but the n suffix
+  // bits, in one word.
+  uint32_t acm[2][10][16];
   // 1, 2 or 3 ZRL codes as a left-aligned 64-bit pattern {high word, low word, bits, 0} (index 0 unused):
   // what the stitch puts in front of a part whose first run is 16 or longer
   uint4 zrlpat[2][4];
+  uint8_t tlen[2][256];    // trellis quantization: AC code lengths the rate is priced with
 };
+constexpr int kTablesA16 = 72, kTablesB16 = 216;      // uint4 per group
+static_assert(sizeof(uint4) * kTablesA16 == 1152 && sizeof(DevTables) == 1152 + 3456 + 512, "DevTables layout");
 
 // source classes the colour phase is specialised for
 enum { kSrcRgb24 = 0, kSrcRgbx32 = 1, kSrcPlanes = 2 };
@@ -73,7 +79,7 @@ constexpr int kOffWin = kSamplesBytes;
 // The quantizer table (1 KiB) and the DC codes are only read before the bit window is first
 // touched (P2 / DC coding), so they live INSIDE the window region.
 constexpr int kOffQ = kOffWin;                                  // uint4[64]
-constexpr int kOffDc = kOffWin + 1024;                          // uint32[24]
+constexpr int kOffDc = kOffWin + 1024;                          // uint32[24] + safe masks [2]
 constexpr int kOffTlen = kOffWin + 1152;                        // uint8[2][256], trellis kinds only
 // Entropy-phase bookkeeping inside the (still idle) bit window, as window WORD offsets.  All of it
 // lies behind the tables staged at the front of the window (quantizer 0..1023, DC codes ..1151,
@@ -411,11 +417,12 @@ __device__ __forceinline__ void load_px8(const ScanArgs& a, const uint8_t* frame
     if (inside) {
       __builtin_memcpy(w, frame_px + y * a.row_stride[0] + 4ll * x0, 32);
     } else {
+      const int Wc = a.W;
       const int yy = y < a.H ? y : a.H - 1;
       const uint8_t* row = frame_px + yy * a.row_stride[0];
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        const int xx = (x0 + i) < a.W ? (x0 + i) : a.W - 1;
+        const int xx = (x0 + i) < Wc ? (x0 + i) : Wc - 1;
         __builtin_memcpy(&w[i], row + 4ll * xx, 4);
       }
     }
@@ -506,17 +513,24 @@ __device__ __forceinline__ void prio_stress(int phase) {
 }
 #endif
 
+// inclusive prefix sum over the 64 lanes of a wave, DPP only (no LDS round trips): four shifts inside
+// the rows of 16 lanes, then lane 15 of rows 0 / 2 into rows 1 / 3 and lane 31 into rows 2 and 3
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t x) {
+  x += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), 0x111, 0xf, 0xf, false));   // row_shr:1
+  x += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), 0x112, 0xf, 0xf, false));   // row_shr:2
+  x += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), 0x114, 0xf, 0xf, false));   // row_shr:4
+  x += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), 0x118, 0xf, 0xf, false));   // row_shr:8
+  x += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), 0x142, 0xa, 0xf, false));   // row_bcast:15
+  x += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), 0x143, 0xc, 0xf, false));   // row_bcast:31
+  return x;
+}
+
 // workgroup exclusive scan of one uint32 per thread; returns exclusive prefix, *total = sum
 template <int NT, bool TRAILING_BARRIER = true>
 __device__ __forceinline__ uint32_t wg_exclusive_scan(uint32_t x, uint32_t* scratch /*>=8 u32*/,
                                                       uint32_t* total) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  uint32_t incl = x;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const uint32_t y = __shfl_up(incl, d, 64);
-    if (lane >= d) incl += y;
-  }
+  const uint32_t incl = wave_inclusive_scan(x);
   if (lane == 63) scratch[wave] = incl;
   __syncthreads();
   uint32_t base = 0, sum = 0;

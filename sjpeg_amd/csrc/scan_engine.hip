@@ -37,6 +37,7 @@
 #include <string.h>
 
 #include <new>
+#include <type_traits>
 #include <string>
 #include <vector>
 

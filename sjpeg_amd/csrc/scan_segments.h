@@ -64,15 +64,11 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
 #endif
   auto stage_tables = [&]() {
     const DevTables* t = a.tables + frame * a.tables_stride;
-    if (tid < 64) lq[tid] = (&t->q[0][0])[tid];
-    for (int i = tid; i < 512; i += kScanThreads) lac[i] = (&t->ac[0][0])[i];
-    if (tid < 24) ldc[tid] = (&t->dc[0][0])[tid];
-    if (tid >= 24 && tid < 26) ldc[tid] = t->safe_mask[tid - 24];
-    if (KIND == kKindEncode) {
-      uint32_t* const lacm0 = reinterpret_cast<uint32_t*>(smem + kOffAcm);
-      for (int i = tid; i < 320; i += kScanThreads) lacm0[i] = (&t->acm[0][0][0])[i];
-      if (tid >= 32 && tid < 40) reinterpret_cast<uint4*>(smem + kOffZrl)[tid - 32] = (&t->zrlpat[0][0])[tid - 32];
-    }
+    // two contiguous groups, 16 bytes per thread: quantizer + DC codes + level bounds into the idle
+    // window, AC codes + merged code words + ZRL patterns behind it
+    const uint4* const t16 = reinterpret_cast<const uint4*>(t);
+    if (tid < kTablesB16) reinterpret_cast<uint4*>(smem + kOffAc)[tid] = t16[kTablesA16 + tid];
+    if (tid < kTablesA16) reinterpret_cast<uint4*>(smem + kOffQ)[tid] = t16[tid];
     if (TRELLIS && tid < 128) reinterpret_cast<uint32_t*>(smem + kOffTlen)[tid] = reinterpret_cast<const uint32_t*>(&t->tlen[0][0])[tid];
     // bookkeeping of the entropy phase that nothing touches until then: the sort's bins, the group queue
     if (KIND == kKindEncode || KIND == kKindStats) {
@@ -99,17 +95,45 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
     // values) is done once per thread instead of once per strip, and consecutive lanes still
     // read consecutive 24-byte pieces of a picture row.
     const int ngroups = kScanThreads / per_row;                 // 3 for a full 4:2:0 segment
-    const int yp0 = tid / per_row;
+    // tid / per_row without a per-lane division: both are below 256, so
+    // (tid * ceil(2^16 / per_row)) >> 16 is exact
+    const uint32_t magic = (65535u + static_cast<uint32_t>(per_row)) / static_cast<uint32_t>(per_row);   // uniform
+    const int yp0 = static_cast<int>((static_cast<uint32_t>(tid) * magic) >> 16);
     const int rem = tid - yp0 * per_row;
-    const int ml = ml_lo + rem / kStripsX;
+    const int dl = rem / kStripsX;                              // MCU of the strip, counted from the first processed one
+    const int ml = ml_lo + dl;
     const int xs = rem % kStripsX;
-    const int mcu = m_first - 1 + ml;
-    const int mb_y = mcu / a.mb_w;
-    const int mb_x = mcu - mb_y * a.mb_w;
+    // MCU coordinates: the first processed MCU is uniform (scalar division); a thread's own is at
+    // most 41 further on, i.e. at most one row wrap when the picture is 42 MCUs wide or more
+    const int mcu0 = m_first - halo;
+    const int my0 = mcu0 / a.mb_w, mx0 = mcu0 - my0 * a.mb_w;
+    int mb_x = mx0 + dl, mb_y = my0;
+    if (a.mb_w > G::kSegMcus) {
+      if (mb_x >= a.mb_w) { mb_x -= a.mb_w; ++mb_y; }
+    } else {
+      const int mcu = mcu0 + dl;
+      mb_y = mcu / a.mb_w;
+      mb_x = mcu - mb_y * a.mb_w;
+    }
     const int x0 = mb_x * PX + xs * 8;
     const uint32_t k7471 = 7471u, k32768 = 32768u;             // multiplier operands (low halves)
     constexpr int kNW = (SRC == kSrcRgb24) ? 6 : 8;             // dwords per 8 pixels
     constexpr int kBatch = 3;                                   // row pairs in flight per thread
+    // A segment without clipped MCUs (every segment of a picture whose sides are multiples of the MCU,
+    // most segments otherwise) runs a copy of the loop that has no clamped-coordinate path at all:
+    // that path's address arithmetic is hoisted in front of the loop by the compiler, and its mere
+    // presence turns the pixel loads into branches.
+    bool interior = true;                                       // uniform
+    if (a.has_clip) {
+      const int mcu1 = m_first + n_coded - 1;                   // last processed MCU
+      const int my1 = mcu1 / a.mb_w, mx1 = mcu1 - my1 * a.mb_w;
+      const int mb_h = a.n_mcus / a.mb_w;
+      const bool clip_row = (a.H % PX) != 0 && my1 == mb_h - 1;
+      const bool clip_col = (a.W % PX) != 0 && (my1 > my0 || mx1 == a.mb_w - 1);
+      interior = !(clip_row || clip_col);
+    }
+    auto convert = [&](auto interior_tag) {
+    constexpr bool INTERIOR = decltype(interior_tag)::value;
     bool tables_staged = false;
     for (int ypb = yp0; ypb < 8 && yp0 < ngroups; ypb += kBatch * ngroups) {
     // all global loads of the batch are issued before the first one is consumed
@@ -120,7 +144,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
         const int yp = ypb + it * ngroups;
         if (yp < 8) {
           const int y0 = mb_y * PX + yp * kRowsPerStrip;
-          const bool inside = (x0 + 8 <= a.W) && (y0 + kRowsPerStrip <= a.H);
+          const bool inside = INTERIOR || ((x0 + 8 <= a.W) && (y0 + kRowsPerStrip <= a.H));
 #pragma unroll
           for (int r = 0; r < kRowsPerStrip; ++r) load_px8<SRC>(a, frame_px, x0, y0 + r, inside, raw[it][r]);
         }
@@ -222,6 +246,8 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
     }
     }
     if (!tables_staged) stage_tables();
+    };
+    if (interior) convert(std::integral_constant<bool, true>()); else convert(std::integral_constant<bool, false>());
   }
   __syncthreads();
   stamp(1);
@@ -640,14 +666,9 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
     // every wave scans the 17 bins (16, 15, ... 0) for itself: no hand-over through LDS, no barrier
     const int ln = tid & 63;
     const uint32_t hcnt = ln <= 16 ? hist[16 - ln] : 0u;
-    uint32_t incl = hcnt;
-#pragma unroll
-    for (int d = 1; d < 32; d <<= 1) {
-      const uint32_t y = __shfl_up(incl, d, 64);
-      if (ln >= d) incl += y;
-    }
+    const uint32_t incl = wave_inclusive_scan(hcnt);
     const uint32_t excl = incl - hcnt;             // lane l: where bin 16 - l starts
-    n_units = __shfl(incl, 16, 64);                // number of parts
+    n_units = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(incl), 16));   // number of parts
     uint32_t start[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) start[q] = __shfl(excl, 16 - static_cast<int>(pc[q]), 64);
@@ -813,6 +834,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
   // Code words come from the merged table (code << n | total length << 27), indexed by clz(level)
   // and run, so a symbol costs two LDS reads and about thirty simple instructions.
   const uint32_t acm_base = static_cast<uint32_t>(kOffAcm) - 22u * 64u;   // row = clz - 22, 64 bytes per row
+  typedef int16_t __attribute__((may_alias)) i16_alias2;
   auto walk_lean = [&](uint32_t unit, uint4 bt, uint32_t& rec_out, uint32_t& tail_out) {
     const uint32_t blk = unit & 255u, q = unit >> 8;
     const uint32_t slot_off = blk * kSlotBytes;
@@ -850,13 +872,14 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
     while (m) {
       const uint32_t i = sh + static_cast<uint32_t>(__builtin_ctz(m));
       m &= m - 1u;
-      const uint32_t e = *reinterpret_cast<const u16_alias*>(smem + slot_off + 2u * i);
+      const int e = *reinterpret_cast<const i16_alias2*>(smem + slot_off + 2u * i);   // sign-extended: ds_read_i16
       const uint32_t run = (i - prev) & 15u;
       prev = i + 1u;
-      const uint32_t mag = e & 0x7fffu;
-      const uint32_t nl = static_cast<uint32_t>(__clz(mag));      // 32 - n
+      const uint32_t mag = static_cast<uint32_t>(e) & 0x7fffu;    // 1 .. 1023
+      uint32_t nl;                                                 // 32 - n
+      asm("v_ffbh_u32 %0, %1" : "=v"(nl) : "v"(mag));
       const uint32_t ones = 0xffffffffu >> nl;
-      const uint32_t sgn = static_cast<uint32_t>(__builtin_amdgcn_sbfe(static_cast<int>(e), 15, 1));
+      const uint32_t sgn = static_cast<uint32_t>(e >> 31);
       const uint32_t cw = *reinterpret_cast<const uint32_t*>(smem + tb + nl * 64u + run * 4u);
       append((cw & 0x07ffffffu) | (mag ^ (ones & sgn)), cw >> 27);
     }
