@@ -135,6 +135,11 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
     auto convert = [&](auto interior_tag) {
     constexpr bool INTERIOR = decltype(interior_tag)::value;
     bool tables_staged = false;
+    // interior copy: the strip's row pointer advances by a uniform step (no 64-bit multiply per row)
+    constexpr int kBpp = (SRC == kSrcRgb24) ? 3 : 4;
+    const long long rs = a.row_stride[0];
+    const uint8_t* prow = frame_px + static_cast<long long>(mb_y * PX + yp0 * kRowsPerStrip) * rs + kBpp * x0;
+    const long long pstep = static_cast<long long>(ngroups * kRowsPerStrip) * rs;      // uniform
     for (int ypb = yp0; ypb < 8 && yp0 < ngroups; ypb += kBatch * ngroups) {
     // all global loads of the batch are issued before the first one is consumed
     uint32_t raw[kBatch][kRowsPerStrip][kNW];
@@ -144,10 +149,16 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
         const int yp = ypb + it * ngroups;
         if (yp < 8) {
           const int y0 = mb_y * PX + yp * kRowsPerStrip;
-          const bool inside = INTERIOR || ((x0 + 8 <= a.W) && (y0 + kRowsPerStrip <= a.H));
+          if (INTERIOR) {
 #pragma unroll
-          for (int r = 0; r < kRowsPerStrip; ++r) load_px8<SRC>(a, frame_px, x0, y0 + r, inside, raw[it][r]);
+            for (int r = 0; r < kRowsPerStrip; ++r) __builtin_memcpy(raw[it][r], prow + r * rs, kNW * 4);
+          } else {
+            const bool inside = (x0 + 8 <= a.W) && (y0 + kRowsPerStrip <= a.H);
+#pragma unroll
+            for (int r = 0; r < kRowsPerStrip; ++r) load_px8<SRC>(a, frame_px, x0, y0 + r, inside, raw[it][r]);
+          }
         }
+        prow += pstep;
       }
     }
     if (!tables_staged) { stage_tables(); tables_staged = true; }
