@@ -212,18 +212,19 @@ __device__ __forceinline__ void fdct_col8_pk(uint32_t& r0, uint32_t& r1, uint32_
   ed = ed << 3; fd = fd << 3; d34 = d34 << 3; d07 = d07 << 3;
   r2 = as_u32(pk_mulhi(fd, 27146) + ed);
   r6 = as_u32(pk_mulhi(ed, 27146) - fd);
-  d25 = d25 << 4; d16 = d16 << 4;
-  const s16x2 od = pk_mulhi(d16 - d25, 23170);
-  const s16x2 os = pk_mulhi(d16 + d25, 23170);
+  // ((x << 4) * 23170) >> 16 == (x * (23170 << 4)) >> 16: the shift rides in the 24-bit multiplier
+  // (|d16 -+ d25| <= 510, the product stays below 2^28)
+  const s16x2 od = pk_mulhi(d16 - d25, 23170 << 4);
+  const s16x2 os = pk_mulhi(d16 + d25, 23170 << 4);
   const s16x2 p3 = d34 - od, p1 = d34 + od;
   const s16x2 p0 = d07 - os, p2 = d07 + os;
-  const s16x2 one = pk_const(1, 1);
-  const s16x2 t3 = pk_mulhi(p3, -21746) + p3 + one;
-  const s16x2 t1 = pk_mulhi(p1, 13036) + p2 + one;
-  const s16x2 t4 = pk_mulhi(p0, -21746) + p0;
+  // ((p * K) >> 16) + p == (p * (K + 65536)) >> 16 exactly (|p| < 2^13: the product stays below 2^29)
+  const s16x2 u3 = pk_mulhi(p3, 65536 - 21746);              // t3 - 1
+  const s16x2 t4 = pk_mulhi(p0, 65536 - 21746);
   const s16x2 t5 = pk_mulhi(p2, 13036);
-  r1 = as_u32(t1);
-  r3 = as_u32(p0 - t3);
+  // a + b + 1 == a - ~b on two's complement halves (the bitwise NOT is a full-rate op)
+  r1 = as_u32(pk_mulhi(p1, 13036) - as_pk(~as_u32(p2)));     // t1 = mulhi + p2 + 1
+  r3 = as_u32(p0 + as_pk(~as_u32(u3)));                       // p0 - (u3 + 1)
   r5 = as_u32(p3 + t4);
   r7 = as_u32(t5 - p1);
 }
@@ -247,10 +248,13 @@ __device__ __forceinline__ void fdct_row8_pk(const uint32_t* row, int* acc) {
   const s16x2 r3 = pk_swap(as_pk(row[3])), r2 = pk_swap(as_pk(row[2]));
   const s16x2 A01 = p0 + r3, B01 = p0 - r3;       // (a0,a1), (b0,b1)
   const s16x2 A23 = p1 + r2, B23 = p1 - r2;       // (a2,a3), (b2,b3)
-  acc[0] = dot2(A23, C4, C4, dot2z(A01, C4, C4));
-  acc[4] = dot2(A23, -C4, C4, dot2z(A01, C4, -C4));
-  acc[2] = dot2(A23, -C6, -C2, dot2z(A01, C2, C6));
-  acc[6] = dot2(A23, C2, -C6, dot2z(A01, C6, -C2));
+  // even part: (c0, c2) = (a0 + a3, a1 + a2), (c1, c3) = (a0 - a3, a1 - a2); one product pair per output
+  const s16x2 A32 = pk_swap(A23);
+  const s16x2 C02 = A01 + A32, C13 = A01 - A32;
+  acc[0] = dot2z(C02, C4, C4);
+  acc[4] = dot2z(C02, C4, -C4);
+  acc[2] = dot2z(C13, C2, C6);
+  acc[6] = dot2z(C13, C6, -C2);
   acc[1] = dot2(B23, C5, C7, dot2z(B01, C1, C3));
   acc[3] = dot2(B23, -C1, -C5, dot2z(B01, C3, -C7));
   acc[5] = dot2(B23, C7, C3, dot2z(B01, C5, -C1));

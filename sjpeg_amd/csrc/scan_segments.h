@@ -861,40 +861,48 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
     const uint32_t above = q == 0u ? ((lo >> 16) | hi) : (q == 1u ? hi : (q == 2u ? (hi >> 16) : 0u));
     const uint32_t sh = 16u * q;
     uint32_t acc = 0, fill = 0;                    // bits of the word in the making, left-aligned; their number
-    const uint32_t wp0 = slot_off + 32u * q;
+    const uint32_t wp0 = slot_off + 32u * q;       // the quarter: 16 entries, then up to 8 words
     uint32_t wp = wp0;                             // byte offset of the next word
     if (q == 0u) {
       fill = (bt.z >> 24) & 31u;
       acc = __builtin_amdgcn_alignbit(bt.z & 0xffffffu, 0u, fill);   // DC bits << (32 - fill)
     }
+    // positions are local to the quarter from here on; the ZRLs of the first run are taken out of it
+    // (only the first symbol of a part can have a run of 16 or more, and never in quarter 0)
     uint32_t nzrl = 0;
-    if (m) nzrl = (sh + static_cast<uint32_t>(__builtin_ctz(m)) - prev) >> 4;   // (always 0 in quarter 0)
+    int prevl = static_cast<int>(prev) - static_cast<int>(sh);       // may be negative
+    if (m) {
+      nzrl = static_cast<uint32_t>(__builtin_ctz(m) - prevl) >> 4;
+      prevl += static_cast<int>(nzrl << 4);
+    }
     auto append = [&](uint32_t bits, uint32_t nb) {                  // 1 <= nb <= 27
       const uint32_t t = fill + nb;
       const uint32_t s5 = t & 31u;
       const uint32_t P = __builtin_amdgcn_alignbit(bits, 0u, s5);   // bits << (32 - s5); 0 for s5 == 0
-      const uint32_t Q = bits >> s5;
-      const bool full = t >= 32u;
-      if (full) *reinterpret_cast<u32_alias*>(smem + wp) = acc | Q;
-      acc = full ? P : (acc | P);
-      wp += (t >> 3) & 4u;
+      if (t >= 32u) {
+        *reinterpret_cast<u32_alias*>(smem + wp) = acc | (bits >> s5);
+        wp += 4u;
+        acc = P;
+      } else {
+        acc |= P;
+      }
       fill = s5;
     };
     while (m) {
-      const uint32_t i = sh + static_cast<uint32_t>(__builtin_ctz(m));
+      const int i = __builtin_ctz(m);
       m &= m - 1u;
-      const int e = *reinterpret_cast<const i16_alias2*>(smem + slot_off + 2u * i);   // sign-extended: ds_read_i16
-      const uint32_t run = (i - prev) & 15u;
-      prev = i + 1u;
+      const int e = *reinterpret_cast<const i16_alias2*>(smem + wp0 + 2u * static_cast<uint32_t>(i));   // sign-extended: ds_read_i16
+      const uint32_t run = static_cast<uint32_t>(i - prevl);      // 0 .. 15
+      prevl = i + 1;
       const uint32_t mag = static_cast<uint32_t>(e) & 0x7fffu;    // 1 .. 1023
       uint32_t nl;                                                 // 32 - n
       asm("v_ffbh_u32 %0, %1" : "=v"(nl) : "v"(mag));
       const uint32_t ones = 0xffffffffu >> nl;
       const uint32_t sgn = static_cast<uint32_t>(e >> 31);
-      const uint32_t cw = *reinterpret_cast<const uint32_t*>(smem + tb + nl * 64u + run * 4u);
+      const uint32_t cw = *reinterpret_cast<const uint32_t*>(smem + ((tb + nl * 64u) + run * 4u));
       append((cw & 0x07ffffffu) | (mag ^ (ones & sgn)), cw >> 27);
     }
-    if (above == 0u && prev <= 63u) { const uint32_t eob = ac[0x00]; append(eob >> 16, eob & 0xffu); }
+    if (above == 0u && prevl + static_cast<int>(sh) <= 63) { const uint32_t eob = ac[0x00]; append(eob >> 16, eob & 0xffu); }
     const uint32_t len = ((wp - wp0) << 3) + fill;
     const uint32_t zl = ac[0xf0] & 0xffu;
     ulen[4 * blk + q] = static_cast<uint16_t>(len + nzrl * zl);
