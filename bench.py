@@ -5,24 +5,33 @@
 A "step" = one pass of the hot path (sjpeg_hip_encode_scan: colour + fDCT + quantize +
 Huffman + bit stitching + byte stuffing -> complete JPEG streams) over one batch of
 `--frames` DISTINCT synthetic frames that are already resident in HBM.  Every rank codes its
-own batch (frames are independent objects: weak scaling, no data-path collective).  The gather
-of the finished byte streams to rank 0 (config #4) is run and verified once, outside the timed
-region, and reported as `gather_ms`.
+own batch (frames are independent objects: weak scaling, no data-path collective in `value`).
 
   python bench.py --gpus 1 --steps 20 --warmup 3
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 
-Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel (scan_segments) against
-the HBM read roofline with ALGORITHMIC bytes = 3 B/pixel; its duration is
-measured live with HIP events on the launch stream (engine timing API).  `cpu_baseline` times
-the real reference (oracle/_ref, SSE2 path, "reference") or, if that .so cannot load, the
-plain-C oracle ("port") on this host's cores on a bounded sample of the same workload.
+Rank 0 prints ONE JSON line.
+* `roofline` prices the dominant kernel (scan_segments) against the HBM read roofline with
+  ALGORITHMIC bytes = 3 B/pixel; its duration is measured live with HIP
+  events on the launch stream (engine timing API).  `roofline.valu` is the second roofline the
+  kernel actually runs into: VALU instructions per wave (from the committed PMC pass named in
+  `source`) x the cycles a wave64 instruction occupies a SIMD, measured live by a
+  microbenchmark of the two issue classes (tools/valu_rate.hip has the full table).
+* `other_configs`: the other BASELINE.json configurations on this device (C2 with noise, C3 8K
+  4:4:4 q90, C4 64 x 1080p, one resident 4K frame), each parity-checked against
+  tests/golden/digests.json.  Rank 0 at N = 1 only.
+* N > 1: a second timed region with the exchange step INSIDE it (`with_gather`): the streams of
+  every step are packed on the device (sjpeg_hip_compact_streams) and gathered to rank 0 over
+  RCCL under the next step's kernels (sjpeg_amd.dist.exchange_loop).
+* `cpu_baseline` times the real reference (oracle/_ref, SSE2 path, "reference") or, if that .so
+  cannot load, the plain-C oracle ("port") on this host's cores on a bounded sample.
 """
 import argparse
 import hashlib
 import json
 import os
+import re
 import sys
 import time
 
@@ -34,6 +43,9 @@ if ROOT not in sys.path:
 
 W, H, QUALITY = 3840, 2160, 75.0
 HBM_PEAK = 8.0e12          # B/s, MI355X HBM3E spec (MI355X_MICROARCH.md)
+N_SIMD, CLOCK_HZ = 256 * 4, 2.4e9
+# the PMC pass of this build the static figures (HBM traffic, VALU instructions per wave) come from
+PMC_SUMMARY = os.path.join("profiles", "r02", "final_pmc_summary.txt")
 
 
 def cpu_baseline(frames_np, budget_s=12.0):
@@ -75,6 +87,78 @@ def cpu_baseline(frames_np, budget_s=12.0):
             "allcores_value": round(cores * per * W * H / dt_all / 1e6, 1), "allcores": cores}
 
 
+def pmc_figures():
+    """(HBM bytes per K1 launch, VALU instructions per wave, waves per launch) of the committed PMC pass
+    of this build's default bench command, or Nones.  2 x FETCH_SIZE KiB (gfx950 wide-read
+    correction, MI355X_MICROARCH.md) + WRITE_SIZE KiB."""
+    try:
+        txt = open(os.path.join(ROOT, PMC_SUMMARY)).read()
+        blk = txt[txt.index("scan_segments<1"):]
+        blk = blk[:blk.index("==", 5)] if "==" in blk[5:] else blk
+        get = lambda name: float(re.search(name + r"\s+total=\S+\s+per_dispatch=(\S+)", blk).group(1))
+        waves = get("SQ_WAVES")
+        return int((2.0 * get("FETCH_SIZE") + get("WRITE_SIZE")) * 1024), get("SQ_INSTS_VALU") / waves, waves
+    except Exception:
+        return None, None, None
+
+
+def valu_cycles(sj):
+    """Cycles a wave64 instruction of the two VALU issue classes occupies a SIMD on this device,
+    measured live (8 waves per SIMD, independent chains): [packed / VOP3 / multiply / permute
+    class, simple 32-bit integer and f32 class]."""
+    import ctypes as C
+    import torch
+    L = sj.lib()
+    out = (C.c_float * 2)()
+    rc = L.sjpeg_hip_debug_valu_rate(out, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    return (float(out[0]), float(out[1])) if rc == 0 else None
+
+
+def run_config(sj, torch, eng, frames_np, tile, q, mode, want_md5, reps=10):
+    """One of the other BASELINE.json configurations: `tile` copies of the pictures resident in HBM,
+    whole path timed over `reps` calls, K1 by HIP events, frame 0 (or the whole batch) against the
+    committed digest."""
+    h, w = frames_np[0].shape[:2]
+    F = len(frames_np) * tile
+    frames = torch.empty((F, h, w, 3), dtype=torch.uint8, device="cuda")
+    for k in range(F):
+        frames[k] = torch.from_numpy(frames_np[k % len(frames_np)]).cuda()
+    tables, quant = sj.make_tables(quality=q)
+    header = sj.make_header(w, h, mode, quant)
+    bpp = 3 if mode == sj.YUV_444 else 2
+    stride = ((w * h * bpp) // 2 + len(header) + 4095) & ~4095
+    out = torch.empty((F, stride), dtype=torch.uint8, device="cuda")
+    sizes = torch.zeros(F, dtype=torch.int64, device="cuda")
+    step = lambda: eng.encode_frames(frames, tables, header, mode, out=out, sizes=sizes, out_stride=stride)
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    eng.set_timing(True)
+    k1 = []
+    for _ in range(5):
+        step()
+        k1.append(eng.last_scan_ms())
+    eng.set_timing(False)
+    sz = sizes.cpu().numpy()
+    if isinstance(want_md5, dict):                       # whole batch, concatenated
+        cat = hashlib.md5()
+        for k in range(F):
+            cat.update(bytes(out[k, :int(sz[k])].cpu().numpy()))
+        ok = cat.hexdigest() == want_md5["md5"] and int(sz.sum()) == want_md5["size"]
+    else:
+        ok = hashlib.md5(bytes(out[0, :int(sz[0])].cpu().numpy())).hexdigest() == want_md5
+    k1_s = float(np.mean(k1)) * 1e-3
+    return {"frames": F, "width": w, "height": h, "mpix_s": round(F * w * h / dt / 1e6, 1),
+            "ms_per_step": round(dt * 1e3, 4), "kernel_ms": round(k1_s * 1e3, 4),
+            "frac": round(3.0 * w * h * F / k1_s / HBM_PEAK, 4), "bytes_per_frame": int(sz[0]),
+            "bit_exact": bool(ok)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -83,6 +167,7 @@ def main():
     ap.add_argument("--frames", type=int, default=64, help="device-resident 4K frames per GPU per step")
     ap.add_argument("--input", choices=["struct", "noise"], default="struct")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true")
     ap.add_argument("--pipelined", type=int, default=0,
                     help="1: engine pipelined mode (stitch of step i under K1 of step i + 1)")
     args = ap.parse_args()
@@ -114,12 +199,14 @@ def main():
     tables, quant = sj.make_tables(quality=QUALITY)
     header = sj.make_header(W, H, sj.YUV_420, quant)
     out_stride = ((W * H * 3) // 2 + len(header) + 4095) & ~4095       # 1.5 B/px slots
-    out = torch.empty((F, out_stride), dtype=torch.uint8, device="cuda")
-    sizes = torch.zeros(F, dtype=torch.int64, device="cuda")
+    nsets = 2 if world > 1 else 1                 # the exchange of step s overlaps the encode of step s + 1
+    outs = [torch.empty((F, out_stride), dtype=torch.uint8, device="cuda") for _ in range(nsets)]
+    sizes_b = [torch.zeros(F, dtype=torch.int64, device="cuda") for _ in range(nsets)]
+    out, sizes = outs[0], sizes_b[0]
     eng = sj.Engine(local)
 
-    def step():
-        eng.encode_frames(frames, tables, header, sj.YUV_420, out=out, sizes=sizes,
+    def encode(b=0):
+        eng.encode_frames(frames, tables, header, sj.YUV_420, out=outs[b], sizes=sizes_b[b],
                           out_stride=out_stride)
 
     def fence():
@@ -128,19 +215,22 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def max_over_ranks(dt):
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
     eng.set_pipelined(bool(args.pipelined))
     for _ in range(args.warmup):
-        step()
+        encode()
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        encode()
     fence()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = max_over_ranks(time.perf_counter() - t0)
 
     piped_scan_ms = None
     if args.pipelined:                            # K1 under the overlap, then back to ordered calls
@@ -148,7 +238,7 @@ def main():
         acc = []
         for _ in range(4):                        # K1 of the LAST of four back-to-back steps: under the stitch of the third
             for _ in range(4):
-                step()
+                encode()
             torch.cuda.synchronize()
             acc.append(eng.last_scan_ms())
         piped_scan_ms = float(np.mean(acc))
@@ -158,30 +248,20 @@ def main():
     eng.set_timing(True)
     scan_ms, total_ms = [], []
     for _ in range(max(5, min(args.steps, 20))):
-        step()
+        encode()
         scan_ms.append(eng.last_scan_ms())
         total_ms.append(eng.last_total_ms())
     eng.set_timing(False)
     scan_avg = float(np.mean(scan_ms)) * 1e-3
     algo_bytes = 3.0 * W * H * F
     achieved = algo_bytes / scan_avg
-    # HBM bytes per launch from the committed PMC pass of this same command (profiles/):
-    # 2 x FETCH_SIZE KiB (gfx950 wide-read correction, MI355X_MICROARCH.md) + WRITE_SIZE KiB.
-    traffic = None
-    try:
-        import re
-        txt = open(os.path.join(ROOT, "profiles", "r01", "v9_pmc_summary.txt")).read()
-        blk = txt[txt.index("scan_segments<1"):]
-        blk = blk[:blk.index("==", 5)] if "==" in blk[5:] else blk
-        fetch = float(re.search(r"FETCH_SIZE\s+total=\S+\s+per_dispatch=(\S+)", blk).group(1))
-        write = float(re.search(r"WRITE_SIZE\s+total=\S+\s+per_dispatch=(\S+)", blk).group(1))
-        if F == 64 and args.input == "struct":
-            traffic = int((2.0 * fetch + write) * 1024)
-    except Exception:
-        traffic = None
+    traffic, valu_per_wave, waves = pmc_figures()
+    default_workload = (F == 64 and args.input == "struct")
+    if not default_workload:
+        traffic = valu_per_wave = waves = None     # the PMC pass is of the default command
 
     # ---- what a read-only stream kernel reaches on this device (context for `peak`) ----------
-    stream_gbps = None
+    stream_gbps, rates = None, None
     if rank == 0:
         try:
             import ctypes as C
@@ -202,40 +282,73 @@ def main():
             stream_gbps = nbytes * 10 / (s0.elapsed_time(s1) * 1e-3) / 1e9
         except Exception:
             stream_gbps = None
+        try:
+            rates = valu_cycles(sj)
+        except Exception:
+            rates = None
 
     # ---- parity: every coded frame must equal the reference bit for bit -------------------
     torch.cuda.synchronize()
     sz = sizes.cpu().numpy()
     coded = [bytes(out[k, :int(sz[k])].cpu().numpy()) for k in range(F)]
     parity = None
+    digests = json.load(open(os.path.join(ROOT, "tests", "golden", "digests.json")))
     if rank == 0:
         from oracle import orc
         o = orc.oracle()
         want = [o.encode(host[k], QUALITY, orc.YUV_420) for k in range(distinct)]
         parity = all(coded[k] == want[k % distinct] for k in range(F))
         if args.input == "struct":
-            d = json.load(open(os.path.join(ROOT, "tests", "golden", "digests.json")))
-            parity = parity and hashlib.md5(coded[0]).hexdigest() == d["struct4k|420|q75|m0"]["md5"]
+            parity = parity and hashlib.md5(coded[0]).hexdigest() == digests["struct4k|420|q75|m0"]["md5"]
 
-    # ---- config #4 exchange step: gather the byte streams to rank 0, verified, untimed ----
-    gather_ms, gather_error = None, None
+    # ---- N > 1: the same steps with the exchange step of config #4 inside the timed region ----
+    with_gather = None
     if world > 1:
-        from sjpeg_amd.dist import gather_streams
+        from sjpeg_amd.dist import exchange_loop
         ids = list(range(rank, F * world, world))
-        fence()
-        g0 = time.perf_counter()
         try:
-            got = gather_streams(out, sizes, ids, F * world, dst=0)
             fence()
-            gather_ms = (time.perf_counter() - g0) * 1e3
-            if rank == 0:
-                parity = parity and all(got[k] == coded[k // world] for k in ids) and \
-                    all(g is not None and g[:2] == b"\xff\xd8" for g in got)
-        except Exception as exc:                 # the exchange is outside the metric: report, do not lose the line
-            gather_error = repr(exc)
+            exchange_loop(2, encode, outs, sizes_b, ids, F * world, use_streams=True)        # warm-up (buffers, RCCL channels)
+            fence()
+            g0 = time.perf_counter()
+            got = exchange_loop(args.steps, encode, outs, sizes_b, ids, F * world, use_streams=True)
+            fence()
+            gdt = max_over_ranks(time.perf_counter() - g0)
+            ok = True
+            if rank == 0:                          # the last step's gathered streams, brought to the host and checked
+                fr = got[-1].frames()
+                ok = all(fr[k] == coded[k // world] for k in ids) and all(f is not None and f[:2] == b"\xff\xd8" for f in fr)
+                parity = parity and ok
+            with_gather = {"value": round(W * H * F * world * args.steps / gdt / 1e6, 1), "unit": "Mpixels/s",
+                           "ms_per_step": round(gdt / args.steps * 1e3, 4), "verified": bool(ok),
+                           "what": "encode + device-side packing (sjpeg_hip_compact_streams) + all_gather of sizes + "
+                                   "RCCL gather of the packed streams into rank 0's HBM, the exchange of step s "
+                                   "under the kernels of step s + 1; host copy / concatenation not included"}
+        except Exception as exc:                 # the exchange is outside the headline metric: report, do not lose the line
+            with_gather = {"error": repr(exc)}
 
     if rank == 0:
         mpix = W * H * F * world * args.steps / dt / 1e6
+        roof = {"bound": "hbm", "achieved": round(achieved / 1e9, 1), "peak": HBM_PEAK / 1e9,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK, 4), "traffic": traffic,
+                "traffic_source": PMC_SUMMARY if traffic is not None else None,
+                "kernel": "scan_segments<420>", "kernel_ms": round(scan_avg * 1e3, 4),
+                "all_kernels_ms": round(float(np.mean(total_ms)), 4),
+                "algorithmic_bytes_per_launch": int(algo_bytes),
+                "stream_read_GBps": None if stream_gbps is None else round(stream_gbps, 1),
+                "frac_of_stream_read": None if not stream_gbps else round(achieved / 1e9 / stream_gbps, 4)}
+        if rates is not None:
+            valu = {"cycles_per_instr": {"packed_vop3_mul_perm": round(rates[0], 2), "simple_int_f32": round(rates[1], 2)},
+                    "cycles_source": "measured in this run (sjpeg_hip_debug_valu_rate, 8 waves per SIMD, nominal 2.4 GHz)"}
+            if valu_per_wave is not None:
+                # every instruction priced as the slow class (most of K1 is) / as the fast class
+                floor = [valu_per_wave * waves * c / N_SIMD / CLOCK_HZ * 1e3 for c in (rates[1], rates[0])]
+                valu.update({"instr_per_wave": round(valu_per_wave, 1), "waves_per_launch": int(waves),
+                             "instr_source": PMC_SUMMARY,
+                             "floor_ms": [round(floor[0], 4), round(floor[1], 4)],
+                             "frac": [round(floor[0] / (scan_avg * 1e3), 4), round(floor[1] / (scan_avg * 1e3), 4)],
+                             "note": "floor_ms / frac: all instructions at the fast-class rate, all at the slow-class rate"})
+            roof["valu"] = valu
         res = {
             "metric": "Mpixels/s JPEG encode, 4K RGB q=75 YUV420; bit-exact vs ref",
             "value": round(mpix, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps,
@@ -248,25 +361,42 @@ def main():
                        "yuv_mode": "420", "parallelism": f"frame-sharded x{world}, no data-path collective"},
             "bit_exact": bool(parity),
             "bytes_per_frame": int(sz[0]),
-            "roofline": {"bound": "hbm", "achieved": round(achieved / 1e9, 1), "peak": HBM_PEAK / 1e9,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK, 4), "traffic": traffic,
-                         "kernel": "scan_segments<420>", "kernel_ms": round(scan_avg * 1e3, 4),
-                         "all_kernels_ms": round(float(np.mean(total_ms)), 4),
-                         "algorithmic_bytes_per_launch": int(algo_bytes),
-                         "stream_read_GBps": None if stream_gbps is None else round(stream_gbps, 1),
-                         "frac_of_stream_read": None if not stream_gbps else round(achieved / 1e9 / stream_gbps, 4)},
+            "roofline": roof,
         }
         res["config"]["pipelined"] = bool(args.pipelined)
         if piped_scan_ms is not None:
             res["roofline"]["kernel_ms_pipelined"] = round(piped_scan_ms, 4)
-        if gather_ms is not None:
-            res["gather_ms"] = round(gather_ms, 2)
-        if gather_error is not None:
-            res["gather_error"] = gather_error
+        if with_gather is not None:
+            res["with_gather"] = with_gather
+        if world == 1 and not args.no_other_configs:
+            del frames
+            torch.cuda.empty_cache()
+            oc = {}
+            try:
+                oc["C2 4K G_noise q75 420 x32"] = run_config(
+                    sj, torch, eng, [synth.g_noise(W, H, 7654321 + k) for k in range(2)], 16, 75.0, sj.YUV_420,
+                    digests["noise4k|420|q75|m0"]["md5"])
+                c3 = [synth.g_struct(7680, 4320, 7654321)]
+                oc["C3 8K G_struct q90 444 x1"] = run_config(sj, torch, eng, c3, 1, 90.0, sj.YUV_444,
+                                                             digests["struct8k|444|q90|m0"]["md5"], reps=20)
+                oc["C3 8K G_struct q90 444 x4"] = run_config(sj, torch, eng, c3, 4, 90.0, sj.YUV_444,
+                                                             digests["struct8k|444|q90|m0"]["md5"])
+                oc["C4 64 x 1080p G_struct q75 420"] = run_config(
+                    sj, torch, eng, [synth.g_struct(1920, 1080, 7654321 + k) for k in range(64)], 1, 75.0,
+                    sj.YUV_420, digests["struct1080p_k0..63_concat|420|q75|m0"], reps=20)
+                oc["C2 4K G_struct q75 420 x1 (latency)"] = run_config(
+                    sj, torch, eng, [host[0]] if args.input == "struct" else [synth.g_struct(W, H, 7654321)], 1, 75.0,
+                    sj.YUV_420, digests["struct4k|420|q75|m0"]["md5"], reps=50)
+            except Exception as exc:
+                oc["error"] = repr(exc)
+            res["other_configs"] = oc
+            if any(isinstance(v, dict) and v.get("bit_exact") is False for v in oc.values()):
+                parity = False
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(host)
         if not parity:
             res["value"] = 0.0
+            res["bit_exact"] = False
             res["error"] = "output differs from the reference: throughput not counted"
         print(json.dumps(res), flush=True)
     if world > 1:

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SJPEG_HIP_ABI_VERSION 11
+#define SJPEG_HIP_ABI_VERSION 12
 
 enum {
   SJPEG_HIP_OK = 0,
@@ -393,6 +393,18 @@ size_t sjpeg_hip_make_header_meta(int width, int height, int yuv_mode, const uin
                                   const sjpeg_hip_huffman_spec* specs,
                                   const sjpeg_hip_metadata* meta, uint8_t* buf, size_t cap);
 
+/* Exchange step of the multi-device batch path (BASELINE.json config #4; the reference runs on one
+ * thread and has no counterpart): packs the `nframes` coded streams an encode call left at
+ * d_out + f*out_stride / d_sizes[f] back to back into d_packed, so that ONE collective (RCCL gather over
+ * xGMI) or one copy moves them.  Frame f starts at d_offsets[f], a multiple of 16 (the up to 15 bytes
+ * of padding behind a frame are zero); d_offsets[nframes] is the number of bytes the batch needs.
+ * A frame that would end behind packed_capacity is not copied: compare d_offsets[nframes] with the
+ * capacity.  One launch on `stream`, no host synchronisation.  d_out, d_packed and out_stride must be
+ * multiples of 16. */
+int sjpeg_hip_compact_streams(const void* d_out, size_t out_stride, const uint64_t* d_sizes, int nframes,
+                              void* d_packed, size_t packed_capacity, uint64_t* d_offsets /* nframes + 1 */,
+                              void* stream);
+
 /* Duration in milliseconds of the dominant kernel (the fused colour+fDCT+quant+entropy
  * kernel) in the most recent sjpeg_hip_encode_scan() call on this engine, measured with
  * HIP events on the caller's stream.  Timing is recorded only after
@@ -400,6 +412,16 @@ size_t sjpeg_hip_make_header_meta(int width, int height, int yuv_mode, const uin
 int sjpeg_hip_engine_set_timing(sjpeg_hip_engine* engine, int enable);
 float sjpeg_hip_engine_last_scan_ms(sjpeg_hip_engine* engine);
 float sjpeg_hip_engine_last_total_ms(sjpeg_hip_engine* engine);
+
+/* Measurement aids of bench.py (no counterpart in the reference, not part of the encode path).
+ * sjpeg_hip_debug_stream_read: a read-only streaming kernel over `bytes` of d_buf -- what the device's
+ * HBM delivers to the simplest possible reader, beside the 8 TB/s specification figure.
+ * sjpeg_hip_debug_valu_rate: cycles (at the nominal 2.4 GHz) a wave64 VALU instruction occupies a SIMD
+ * at 8 waves per SIMD, for the two issue classes found on gfx950: cycles[0] = v_perm_b32 (every VOP3,
+ * packed, multiply, dot and permute instruction), cycles[1] = v_add_u32 (simple 32-bit integer and
+ * f32 instructions).  Synchronises on `stream`. */
+int sjpeg_hip_debug_stream_read(const void* d_buf, size_t bytes, uint32_t* d_sink, void* stream);
+int sjpeg_hip_debug_valu_rate(float cycles[2], void* stream);
 
 #ifdef __cplusplus
 }

@@ -251,8 +251,32 @@ EXPORTED_C_SYMBOLS = [
     "sjpeg_hip_set_riskiness_table", "sjpeg_hip_has_riskiness_table", "sjpeg_hip_riskiness_sums",
     "sjpeg_hip_segment_count", "sjpeg_hip_band_bound", "sjpeg_hip_encode_band_src", "sjpeg_hip_stitch_bands",
     "sjpeg_hip_engine_set_timing", "sjpeg_hip_engine_last_scan_ms",
-    "sjpeg_hip_engine_last_total_ms",
+    "sjpeg_hip_engine_last_total_ms", "sjpeg_hip_compact_streams",
+    "sjpeg_hip_debug_stream_read", "sjpeg_hip_debug_valu_rate",
 ]
+
+
+def compact_streams(out, sizes, nframes=None, capacity=None, packed=None, offsets=None):
+    """sjpeg_hip_compact_streams: the first `nframes` coded frames of `out` ([F, stride] uint8 CUDA,
+    stride a multiple of 16) / `sizes` ([F] int64 CUDA) back to back, every frame at a multiple of 16.
+    Returns (packed uint8 [capacity], offsets int64 [nframes + 1]); offsets[nframes] = bytes needed.
+    One launch on the current stream, no synchronisation."""
+    import torch
+    n = int(out.shape[0] if nframes is None else nframes)
+    stride = int(out.stride(0))
+    if capacity is None:
+        capacity = n * stride
+    if packed is None:
+        packed = torch.empty(int(capacity), dtype=torch.uint8, device=out.device)
+    if offsets is None:
+        offsets = torch.zeros(n + 1, dtype=torch.int64, device=out.device)
+    rc = lib().sjpeg_hip_compact_streams(C.c_void_p(out.data_ptr()), C.c_size_t(stride), C.c_void_p(sizes.data_ptr()), n,
+                                         C.c_void_p(packed.data_ptr()), C.c_size_t(int(packed.numel())),
+                                         C.c_void_p(offsets.data_ptr()),
+                                         C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    if rc != 0:
+        raise SjpegError(f"sjpeg_hip_compact_streams: {lib().sjpeg_hip_last_error().decode()}")
+    return packed, offsets
 
 
 # ---------------------------------------------------------------- host API (sjpeg.h)
@@ -481,13 +505,22 @@ class Engine:
         import torch
         return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
+    @staticmethod
+    def _check_frames(frames):
+        """The C-ABI takes only a row and a frame stride: pixels must be packed RGB, 3 bytes apart."""
+        import torch
+        if not (frames.is_cuda and frames.dtype == torch.uint8 and frames.dim() == 4 and frames.shape[3] == 3
+                and frames.stride(3) == 1 and frames.stride(2) == 3):
+            raise SjpegError("frames must be a CUDA uint8 tensor [F, H, W, 3] of packed RGB pixels "
+                             "(stride 1 over the channels, 3 over x); call .contiguous() on a permuted or sliced view")
+
     def encode_frames(self, frames, tables: ScanTables, header: bytes, yuv_mode: int,
                       out=None, sizes=None, out_stride=None, append_eoi=True):
         """frames: torch.uint8 CUDA tensor [F, H, W, 3] (contiguous rows).  Returns
         (out [F, out_stride] uint8 CUDA tensor, sizes [F] int64 CUDA tensor).  Asynchronous
         on the current torch stream."""
         import torch
-        assert frames.is_cuda and frames.dtype == torch.uint8 and frames.dim() == 4
+        self._check_frames(frames)
         f, h, w, _ = frames.shape
         if out_stride is None:
             out_stride = frame_bound(w, h, yuv_mode, len(header))
@@ -642,6 +675,7 @@ class Engine:
         import torch
         f, h, w, _ = frames.shape
         out = torch.zeros((f, 2, 64, 128), dtype=torch.int32, device=frames.device)
+        self._check_frames(frames)
         rc = lib().sjpeg_hip_scan_histogram(self._h, frames.data_ptr(), frames.stride(1),
                                             frames.stride(0), w, h, yuv_mode, f, out.data_ptr(),
                                             self._stream())
@@ -654,6 +688,7 @@ class Engine:
         import torch
         f, h, w, _ = frames.shape
         out = torch.zeros((f, 2, 272), dtype=torch.int32, device=frames.device)
+        self._check_frames(frames)
         rc = lib().sjpeg_hip_scan_symbol_stats(self._h, frames.data_ptr(), frames.stride(1),
                                                frames.stride(0), w, h, yuv_mode, f, C.byref(tables),
                                                out.data_ptr(), self._stream())
@@ -668,6 +703,7 @@ class Engine:
         per = {YUV_420: 6, YUV_444: 3, YUV_400: 1}[yuv_mode]
         nb = ((w + px - 1) // px) * ((h + px - 1) // px) * per
         coeffs = torch.zeros((f, nb, 64), dtype=torch.int16, device=frames.device)
+        self._check_frames(frames)
         rc = lib().sjpeg_hip_scan_coeffs(self._h, frames.data_ptr(), frames.stride(1),
                                          frames.stride(0), w, h, yuv_mode, f, C.byref(tables),
                                          coeffs.data_ptr(), self._stream())
@@ -705,6 +741,9 @@ def _fetch_frames(out, sizes):
     one synchronisation."""
     import torch
     sz = sizes.cpu().numpy()
+    if (sz <= 0).any():
+        raise SjpegError("frame %d did not fit its output slot (the device reported size 0): raise out_stride"
+                         % int(np.argmax(sz <= 0)))
     offs = np.concatenate([[0], np.cumsum(sz)]).astype(np.int64)
     stage = torch.empty(int(offs[-1]), dtype=torch.uint8, pin_memory=True)
     for k in range(len(sz)):
@@ -735,8 +774,7 @@ def encode_source_method(fmt, planes, w, h, quality=75.0, yuv_mode=YUV_420, meth
         specs = optimize_huffman(freq, yuv_mode, tables)
     header = make_header_ex(w, h, yuv_mode, q, specs)
     out, sizes = eng.encode_source(src, 1, w, h, tables, header, yuv_mode)
-    torch.cuda.synchronize()
-    return bytes(out[0, :int(sizes[0])].cpu().numpy())
+    return _fetch_frames(out, sizes)[0]
 
 
 def encode_device(frames, quality=75.0, yuv_mode=YUV_420, engine=None, quant=None):

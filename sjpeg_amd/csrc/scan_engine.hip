@@ -1010,6 +1010,64 @@ int sjpeg_hip_encode_batch_src(sjpeg_hip_engine* engine, const sjpeg_hip_source*
   }
 }
 
+// ---- exchange step of the multi-device batch path: the coded frames of one call, back to back ----
+// (BASELINE.json config #4; the reference is single-threaded and has no counterpart.)  One
+// launch, no host round trip: every workgroup sums the (16-byte aligned) sizes of the frames in
+// front of its own and copies 16 bytes per thread.
+
+__global__ __launch_bounds__(256) void compact_streams_kernel(const uint8_t* out, size_t out_stride, const unsigned long long* sizes,
+                                                              int nframes, uint8_t* packed, unsigned long long capacity,
+                                                              unsigned long long* offsets) {
+  const int f = blockIdx.y, tid = threadIdx.x;
+  __shared__ unsigned long long part[4];
+  unsigned long long s = 0;
+  for (int g = tid; g < f; g += 256) s += (sizes[g] + 15ull) & ~15ull;
+  for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d, 64);
+  if ((tid & 63) == 0) part[tid >> 6] = s;
+  __syncthreads();
+  const unsigned long long off = part[0] + part[1] + part[2] + part[3];
+  const unsigned long long n = sizes[f], n16 = (n + 15ull) & ~15ull;
+  if (blockIdx.x == 0 && tid == 0) {
+    offsets[f] = off;
+    if (f == nframes - 1) offsets[nframes] = off + n16;       // bytes needed, whether they fit or not
+  }
+  if (off + n16 > capacity) return;                            // the caller sees it in offsets[nframes]
+  const uint4* const src = reinterpret_cast<const uint4*>(out + static_cast<size_t>(f) * out_stride);
+  uint4* const dst = reinterpret_cast<uint4*>(packed + off);
+  const size_t nch = static_cast<size_t>(n16 >> 4);
+  for (size_t i = static_cast<size_t>(blockIdx.x) * 256 + tid; i < nch; i += static_cast<size_t>(gridDim.x) * 256) {
+    uint4 v = src[i];
+    if (i == nch - 1 && (n & 15ull) != 0ull) {                 // zero the padding behind the last byte
+      uint32_t w[4] = {v.x, v.y, v.z, v.w};
+      const uint32_t keep = static_cast<uint32_t>(n & 15ull);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const uint32_t lo = 4u * k;
+        w[k] = keep <= lo ? 0u : (keep >= lo + 4u ? w[k] : (w[k] & ((1u << (8u * (keep - lo))) - 1u)));
+      }
+      v = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    dst[i] = v;
+  }
+}
+
+int sjpeg_hip_compact_streams(const void* d_out, size_t out_stride, const uint64_t* d_sizes, int nframes,
+                              void* d_packed, size_t packed_capacity, uint64_t* d_offsets, void* stream) {
+  if (d_out == nullptr || d_sizes == nullptr || d_packed == nullptr || d_offsets == nullptr) {
+    return fail(SJPEG_HIP_EINVAL, "sjpeg_hip_compact_streams: NULL argument");
+  }
+  if (nframes <= 0 || nframes > 65535) return fail(SJPEG_HIP_EINVAL, "sjpeg_hip_compact_streams: nframes must be 1 .. 65535");
+  if ((reinterpret_cast<uintptr_t>(d_out) & 15u) != 0 || (reinterpret_cast<uintptr_t>(d_packed) & 15u) != 0 || (out_stride & 15u) != 0) {
+    return fail(SJPEG_HIP_EINVAL, "sjpeg_hip_compact_streams: d_out, d_packed and out_stride must be multiples of 16");
+  }
+  hipLaunchKernelGGL(compact_streams_kernel, dim3(64, nframes), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     static_cast<const uint8_t*>(d_out), out_stride, reinterpret_cast<const unsigned long long*>(d_sizes), nframes,
+                     static_cast<uint8_t*>(d_packed), static_cast<unsigned long long>(packed_capacity),
+                     reinterpret_cast<unsigned long long*>(d_offsets));
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
 // ---- measurement aid: what a read-only streaming kernel reaches on this device ------------------
 // (SURVEY section 8d asks for the achieved read bandwidth beside the 8 TB/s spec figure)
 
@@ -1027,6 +1085,55 @@ int sjpeg_hip_debug_stream_read(const void* d_buf, size_t bytes, uint32_t* d_sin
   if (d_buf == nullptr || d_sink == nullptr || bytes < 16) return SJPEG_HIP_EINVAL;
   hipLaunchKernelGGL(stream_read_kernel, dim3(256 * 16), dim3(256), 0, static_cast<hipStream_t>(stream),
                      static_cast<const uint4*>(d_buf), bytes / 16, d_sink);
+  return hipGetLastError() == hipSuccess ? 0 : SJPEG_HIP_ERUNTIME;
+}
+
+// ---- measurement aid: cycles a wave64 VALU instruction occupies a SIMD, per issue class -----------
+// (the second roofline of K1, bench.py `roofline.valu`; tools/valu_rate.hip has the table of all ops)
+
+#define SJPEG_VALU_RATE_KERNEL(NAME, ASM)                                                              \
+__global__ __launch_bounds__(256) void NAME(uint32_t a, uint32_t b, uint32_t* sink) {                  \
+  uint32_t r[8];                                                                                       \
+  _Pragma("unroll") for (int i = 0; i < 8; ++i) r[i] = threadIdx.x * 2654435761u + i * 40503u + a;      \
+  for (int it = 0; it < 1024; ++it) {                                                                  \
+    _Pragma("unroll") for (int u = 0; u < 32; ++u) asm volatile(ASM : "+v"(r[u & 7]) : "v"(a), "v"(b)); \
+  }                                                                                                    \
+  uint32_t x = 0;                                                                                      \
+  _Pragma("unroll") for (int i = 0; i < 8; ++i) x ^= r[i];                                             \
+  if (x == 0x12345u) sink[0] = 1;                                                                      \
+}
+SJPEG_VALU_RATE_KERNEL(valu_rate_kernel_slow, "v_perm_b32 %0, %0, %1, %2")
+SJPEG_VALU_RATE_KERNEL(valu_rate_kernel_fast, "v_add_u32 %0, %0, %1")
+
+int sjpeg_hip_debug_valu_rate(float cycles[2], void* stream) {
+  if (cycles == nullptr) return SJPEG_HIP_EINVAL;
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, dev));
+  uint32_t* d_sink = nullptr;
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_sink), 64));
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  const hipStream_t st = static_cast<hipStream_t>(stream);
+  const int wps = 8;                               // workgroups per CU = waves per SIMD (256 threads each)
+  const dim3 grid(prop.multiProcessorCount * wps);
+  for (int c = 0; c < 2; ++c) {
+    for (int rep = 0; rep < 2; ++rep) {            // first launch warms up
+      (void)hipEventRecord(e0, st);
+      if (c == 0) hipLaunchKernelGGL(valu_rate_kernel_slow, grid, dim3(256), 0, st, 3u, 5u, d_sink);
+      else hipLaunchKernelGGL(valu_rate_kernel_fast, grid, dim3(256), 0, st, 3u, 5u, d_sink);
+      (void)hipEventRecord(e1, st);
+      (void)hipEventSynchronize(e1);
+    }
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    cycles[c] = ms * 1e-3f * 2.4e9f / (1024.0f * 32.0f * wps);   // at the nominal 2.4 GHz
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipFree(d_sink);
   return hipGetLastError() == hipSuccess ? 0 : SJPEG_HIP_ERUNTIME;
 }
 

@@ -10,6 +10,7 @@ here (process group + device tensors); the encoder itself is the C library.
 """
 from typing import List, Optional, Sequence
 
+import numpy as np  # noqa: F401  (sizes arrive as numpy arrays)
 import torch
 import torch.distributed as dist
 
@@ -19,48 +20,124 @@ def shard_frames(nframes: int, rank: int, world: int) -> List[int]:
     return list(range(rank, nframes, world))
 
 
-def gather_streams(out: torch.Tensor, sizes: torch.Tensor, frame_ids: Sequence[int],
-                   nframes: int, dst: int = 0, group=None) -> Optional[List[bytes]]:
-    """Gathers variable-length coded frames to `dst`.
+def _align16(x):
+    return (x + 15) & ~15
 
-    out   [F_local, stride] uint8, sizes [F_local] int64 (same device as the process group
-    backend expects), frame_ids the global index of each local frame.  Two collectives:
-    all_gather of the sizes (8 B per frame), then one padded gather of the compacted byte
-    streams (RCCL has no gatherv; padding is to the largest per-rank total).  Returns the
-    nframes byte strings in global frame order on `dst`, None elsewhere.
-    """
+
+class GatheredStreams:
+    """What `dst` holds after gather_streams(): the per-rank packed buffers (device resident) and
+    the sizes of all frames; frames() brings them to the host as byte strings in global order."""
+
+    def __init__(self, recv, sizes_all, nframes, world):
+        self.recv, self.sizes_all, self.nframes, self.world = recv, sizes_all, nframes, world
+
+    def frames(self) -> List[bytes]:
+        out: List[Optional[bytes]] = [None] * self.nframes
+        host = torch.stack(self.recv).cpu().numpy()            # one device -> host copy
+        for r in range(self.world):
+            ids = shard_frames(self.nframes, r, self.world)
+            sz = self.sizes_all[r][:len(ids)]
+            offs = [0]
+            for n in sz[:-1]:
+                offs.append(offs[-1] + _align16(int(n)))
+            for k, o, n in zip(ids, offs, sz):
+                out[k] = host[r, o:o + int(n)].tobytes()
+        return out  # type: ignore[return-value]
+
+
+def gather_streams(out: torch.Tensor, sizes: torch.Tensor, frame_ids: Sequence[int],
+                   nframes: int, dst: int = 0, group=None, compact=None,
+                   to_host: bool = True):
+    """Gathers variable-length coded frames to `dst`: the exchange step of the batch path.
+
+    out [F_local, stride] uint8 and sizes [F_local] int64 as an encode call left them,
+    frame_ids the global index of each local frame.  The frames are packed back to back ON THE
+    DEVICE by one kernel (sjpeg_hip_compact_streams: every frame at a multiple of 16, no host
+    round trip), then TWO collectives move them: all_gather of the sizes (8 B per frame) and one
+    gather of the packed buffers, padded to the largest per-rank total (RCCL has no gatherv; its
+    send counts are host values, hence the ONE host read of the gathered sizes).  No per-frame
+    host synchronisation anywhere.  `compact(out, sizes, n, capacity)` -> (packed, offsets)
+    defaults to the C-ABI kernel (CUDA tensors); the CPU/gloo tests pass a torch restatement.
+    Returns on `dst` the nframes byte strings in global order (to_host=True) or a
+    GatheredStreams holding the device-resident buffers (to_host=False); None elsewhere."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     dev = out.device
+    if compact is None:
+        import sjpeg_amd as sj
+        compact = sj.compact_streams
+    n_local = len(frame_ids)
     max_local = (nframes + world - 1) // world
     local_sizes = torch.zeros(max_local, dtype=torch.int64, device=dev)
-    local_sizes[:len(frame_ids)] = sizes[:len(frame_ids)]
+    local_sizes[:n_local] = sizes[:n_local]
     all_sizes = [torch.zeros_like(local_sizes) for _ in range(world)]
     dist.all_gather(all_sizes, local_sizes, group=group)
-    totals = [int(s.sum().item()) for s in all_sizes]
-    pad = max(max(totals), 1)
-    # compact this rank's frames back to back
-    packed = torch.zeros(pad, dtype=torch.uint8, device=dev)
-    pos = 0
-    for i in range(len(frame_ids)):
-        n = int(sizes[i].item())
-        packed[pos:pos + n] = out[i, :n]
-        pos += n
-    recv = [torch.zeros(pad, dtype=torch.uint8, device=dev) for _ in range(world)] \
-        if rank == dst else None
-    dist.gather(packed, recv, dst=dst, group=group)
+    sizes_all = torch.stack(all_sizes).cpu().numpy()           # the one host read (world x frames int64)
+    pad = max(int(_align16(sizes_all).sum(axis=1).max()), 16)
+    if n_local > 0:
+        packed, _ = compact(out, sizes, n_local, pad)
+    else:
+        packed = torch.zeros(pad, dtype=torch.uint8, device=dev)
+    recv = [torch.empty(pad, dtype=torch.uint8, device=dev) for _ in range(world)] if rank == dst else None
+    dist.gather(packed[:pad], recv, dst=dst, group=group)
     if rank != dst:
         return None
-    frames: List[Optional[bytes]] = [None] * nframes
-    for r in range(world):
-        buf = recv[r].cpu().numpy()
-        sz = all_sizes[r].cpu().numpy()
-        pos = 0
-        for j, k in enumerate(shard_frames(nframes, r, world)):
-            n = int(sz[j])
-            frames[k] = buf[pos:pos + n].tobytes()
-            pos += n
-    return frames  # type: ignore[return-value]
+    got = GatheredStreams(recv, sizes_all, nframes, world)
+    return got.frames() if to_host else got
+
+
+def overlapped_steps(nsteps: int, encode, exchange, use_streams: bool):
+    """The multi-rank step loop of bench.py: step s is coded into buffer set s & 1 while the streams
+    of step s - 1 are exchanged.  encode(buf) enqueues one encode call into set `buf`;
+    exchange(buf) runs the exchange of that set (it may block the host: the next encode is
+    already queued).  With use_streams the exchange runs on a side CUDA stream ordered behind the
+    encode by an event, so that it overlaps the next step's kernels; on CPU (gloo tests) the
+    same order of calls runs inline.  Returns the results of the exchanges, in step order."""
+    results = []
+    if use_streams:
+        main = torch.cuda.current_stream()
+        side = torch.cuda.Stream()
+        done = [torch.cuda.Event(), torch.cuda.Event()]
+        freed = [torch.cuda.Event(), torch.cuda.Event()]
+        for s in range(nsteps):
+            b = s & 1
+            if s >= 2:
+                main.wait_event(freed[b])          # set b is being read by the exchange of step s - 2
+            encode(b)
+            done[b].record(main)
+            if s > 0:
+                pb = (s - 1) & 1
+                side.wait_event(done[pb])
+                with torch.cuda.stream(side):
+                    results.append(exchange(pb))
+                    freed[pb].record(side)
+        if nsteps > 0:
+            pb = (nsteps - 1) & 1
+            side.wait_event(done[pb])
+            with torch.cuda.stream(side):
+                results.append(exchange(pb))
+            main.wait_stream(side)
+    else:
+        for s in range(nsteps):
+            encode(s & 1)
+            if s > 0:
+                results.append(exchange((s - 1) & 1))
+        if nsteps > 0:
+            results.append(exchange((nsteps - 1) & 1))
+    return results
+
+
+def exchange_loop(nsteps: int, encode, outs, sizes, frame_ids: Sequence[int], nframes: int,
+                  use_streams: bool, dst: int = 0, group=None, compact=None):
+    """bench.py's timed multi-rank region, as a function so that the CPU/gloo test runs exactly
+    this code: `nsteps` encode calls, double buffered (outs[b], sizes[b], b = 0 / 1), the streams
+    of every step gathered to `dst` (device resident there) under the next step's kernels.
+    Returns the GatheredStreams of every step on `dst`, a list of None elsewhere."""
+    return overlapped_steps(
+        nsteps, encode,
+        lambda b: gather_streams(outs[b], sizes[b], frame_ids, nframes, dst=dst, group=group,
+                                 compact=compact, to_host=False),
+        use_streams)
 
 
 # ---- one frame over several GPUs: bands of consecutive segments (SURVEY.md section 8e) -------------

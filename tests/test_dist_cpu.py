@@ -12,6 +12,18 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _compact_torch(out, sizes, n, capacity):
+    """What sjpeg_hip_compact_streams does (include/sjpeg_hip.h), restated with torch ops for the
+    CPU tests: frames back to back, every one at a multiple of 16, padding zero."""
+    offs = [0]
+    for i in range(n):
+        offs.append(offs[-1] + ((int(sizes[i]) + 15) & ~15))
+    packed = torch.zeros(int(capacity), dtype=torch.uint8)
+    for i in range(n):
+        packed[offs[i]:offs[i] + int(sizes[i])] = out[i, :int(sizes[i])]
+    return packed, torch.tensor(offs, dtype=torch.int64)
+
+
 def _worker(rank, world, port, nframes, q):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -28,7 +40,7 @@ def _worker(rank, world, port, nframes, q):
     for i, c in enumerate(coded):
         out[i, :len(c)] = torch.from_numpy(np.frombuffer(c, np.uint8).copy())
         sizes[i] = len(c)
-    frames = gather_streams(out, sizes, ids, nframes, dst=0)
+    frames = gather_streams(out, sizes, ids, nframes, dst=0, compact=_compact_torch)
     if rank == 0:
         want = [o.encode(synth.g_struct(48, 40, 100 + k), 75.0, 1) for k in range(nframes)]
         q.put(frames == want)
@@ -66,6 +78,62 @@ def test_gather_even():
 def test_gather_ragged_and_empty_rank():
     _run(5)
     _run(1)
+
+
+def _loop_worker(rank, world, port, nframes, nsteps, q):
+    """bench.py's multi-rank region (sjpeg_amd.dist.exchange_loop) with a stand-in encoder: step s
+    leaves the oracle-coded frames of picture set s in buffer set s & 1."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import orc, synth
+    from sjpeg_amd.dist import exchange_loop, shard_frames
+    o = orc.oracle()
+    ids = shard_frames(nframes, rank, world)
+
+    def coded(step, k):
+        return o.encode(synth.g_struct(40 + 8 * (k % 3), 24, 1000 * step + k), 75.0, 1)
+
+    stride = 4096
+    outs = [torch.zeros((max(len(ids), 1), stride), dtype=torch.uint8) for _ in range(2)]
+    sizes = [torch.zeros(max(len(ids), 1), dtype=torch.int64) for _ in range(2)]
+    state = {"step": 0}
+
+    def encode(b):
+        for i, k in enumerate(ids):
+            c = coded(state["step"], k)
+            outs[b][i].zero_()
+            outs[b][i, :len(c)] = torch.from_numpy(np.frombuffer(c, np.uint8).copy())
+            sizes[b][i] = len(c)
+        state["step"] += 1
+
+    got = exchange_loop(nsteps, encode, outs, sizes, ids, nframes, use_streams=False, compact=_compact_torch)
+    if rank == 0:
+        ok = len(got) == nsteps
+        for s, g in enumerate(got):
+            ok = ok and g.frames() == [coded(s, k) for k in range(nframes)]
+        q.put(ok)
+    else:
+        assert got == [None] * nsteps
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_exchange_loop_two_ranks():
+    """Exactly the code path of `python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2`
+    between its two fences, on gloo."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_loop_worker, args=(r, 2, port, 5, 3, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    ok = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert ok
 
 
 # ---- one frame over several ranks: exchange of band bit strings (SURVEY.md section 8e) -------------

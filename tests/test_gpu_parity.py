@@ -800,3 +800,60 @@ def test_sharp_and_auto_with_padded_and_bottom_up_rows(oracle, risk_table):
         lib.SjpegFreeBuffer(out)
         flipped = img[::-1].copy()
         assert sj.SjpegEncode(flipped, 80.0, 4, mode, stride=-flipped.strides[0]) == want
+
+
+# ---- exchange step of the multi-device batch path ------------------------------------------------
+
+def test_compact_streams_vs_restatement(engine):
+    """sjpeg_hip_compact_streams against the torch restatement the gloo tests use
+    (tests/test_dist_cpu.py::_compact_torch): ragged sizes, a frame that fills its slot, a batch
+    that does not fit the packed buffer, and the streams of a real encode call."""
+    from test_dist_cpu import _compact_torch
+    rng = np.random.default_rng(5)
+    stride = 4096 + 16
+    for n in (1, 2, 7, 64, 300):
+        out = torch.from_numpy(rng.integers(0, 256, (n, stride), dtype=np.uint8)).cuda()
+        sz = rng.integers(1, stride + 1, n)
+        sz[0] = stride                                   # full slot
+        if n > 2:
+            sz[1], sz[2] = 1, 16
+        sizes = torch.from_numpy(sz.astype(np.int64)).cuda()
+        need = int(((sz + 15) & ~15).sum())
+        packed, offs = sj.compact_streams(out, sizes, n, need)
+        want, woffs = _compact_torch(out.cpu(), sizes.cpu(), n, need)
+        assert offs.cpu().tolist() == woffs.tolist() and int(offs[-1]) == need
+        assert torch.equal(packed.cpu(), want)
+        # too small a buffer: the needed size is still reported, the frames that fit are intact
+        if n > 2:
+            small = int(woffs[n - 1])                    # room for all but the last frame
+            p2, o2 = sj.compact_streams(out, sizes, n, small)
+            assert int(o2[-1]) == need and torch.equal(p2.cpu(), want[:small])
+    # the real thing: a batch of coded frames survives the packing
+    imgs = [synth.g_struct(160, 96, 70 + k) for k in range(5)]
+    frames = torch.from_numpy(np.stack(imgs)).cuda()
+    tables, quant = sj.make_tables(quality=75.0)
+    header = sj.make_header(160, 96, sj.YUV_420, quant)
+    ostride = (sj.frame_bound(160, 96, sj.YUV_420, len(header)) + 15) & ~15
+    out, sizes = engine.encode_frames(frames, tables, header, sj.YUV_420, out_stride=ostride)
+    packed, offs = sj.compact_streams(out, sizes)
+    torch.cuda.synchronize()
+    o, s, p = offs.cpu().numpy(), sizes.cpu().numpy(), packed.cpu().numpy()
+    for k in range(5):
+        assert p[o[k]:o[k] + s[k]].tobytes() == bytes(out[k, :int(s[k])].cpu().numpy())
+    # misaligned arguments are refused, not mis-copied
+    with pytest.raises(sj.SjpegError):
+        sj.compact_streams(out[:, 1:], sizes)
+
+
+def test_frame_tensor_layout_is_checked(engine):
+    """A permuted / channel-first / sliced view must be refused (the C-ABI sees two strides only)."""
+    img = torch.from_numpy(synth.g_struct(64, 48, 3)).cuda()
+    tables, quant = sj.make_tables(quality=75.0)
+    header = sj.make_header(64, 48, sj.YUV_420, quant)
+    chw = img.permute(2, 0, 1).contiguous().permute(1, 2, 0).unsqueeze(0)     # [1, H, W, 3] view of CHW data
+    with pytest.raises(sj.SjpegError):
+        engine.encode_frames(chw, tables, header, sj.YUV_420)
+    with pytest.raises(sj.SjpegError):
+        engine.encode_frames(img.unsqueeze(0)[:, :, ::2, :], tables, header, sj.YUV_420)
+    out, sizes = engine.encode_frames(chw.contiguous(), tables, header, sj.YUV_420)
+    assert int(sizes[0]) > 0
