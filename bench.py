@@ -168,6 +168,8 @@ def main():
     ap.add_argument("--input", choices=["struct", "noise"], default="struct")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true")
+    ap.add_argument("--exchange", action="store_true",
+                    help="N = 1 only: run the `with_gather` region too (RCCL with a single rank: packing + self-gather)")
     ap.add_argument("--pipelined", type=int, default=0,
                     help="1: engine pipelined mode (stitch of step i under K1 of step i + 1)")
     args = ap.parse_args()
@@ -180,8 +182,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    exchange = world > 1 or args.exchange
+    if exchange:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local))
     torch.cuda.set_device(local)
@@ -199,7 +203,7 @@ def main():
     tables, quant = sj.make_tables(quality=QUALITY)
     header = sj.make_header(W, H, sj.YUV_420, quant)
     out_stride = ((W * H * 3) // 2 + len(header) + 4095) & ~4095       # 1.5 B/px slots
-    nsets = 2 if world > 1 else 1                 # the exchange of step s overlaps the encode of step s + 1
+    nsets = 2 if exchange else 1                  # the exchange of step s overlaps the encode of step s + 1
     outs = [torch.empty((F, out_stride), dtype=torch.uint8, device="cuda") for _ in range(nsets)]
     sizes_b = [torch.zeros(F, dtype=torch.int64, device="cuda") for _ in range(nsets)]
     out, sizes = outs[0], sizes_b[0]
@@ -303,7 +307,7 @@ def main():
 
     # ---- N > 1: the same steps with the exchange step of config #4 inside the timed region ----
     with_gather = None
-    if world > 1:
+    if exchange:
         from sjpeg_amd.dist import exchange_loop
         ids = list(range(rank, F * world, world))
         try:
@@ -399,7 +403,7 @@ def main():
             res["bit_exact"] = False
             res["error"] = "output differs from the reference: throughput not counted"
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if exchange:
         dist.barrier()
         dist.destroy_process_group()
 

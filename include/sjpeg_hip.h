@@ -113,7 +113,10 @@ typedef struct sjpeg_hip_huffman_spec {
 /* Opaque engine: one HIP device, cached device scratch.  Not thread-safe; use one engine
  * per host thread (they may share a device).  Every call is asynchronous on the stream it is
  * given; the scratch is shared by all calls, so a call on another stream than the previous one
- * first waits (on the device) for that one's work -- use one engine per stream to overlap. */
+ * first waits (on the device) for that one's work -- use one engine per stream to overlap.
+ * A stream handed to a call must stay alive until the engine's NEXT call has been issued (that call
+ * orders itself behind it with an event); if it was destroyed earlier the engine falls back to a
+ * device-wide synchronisation instead of failing. */
 typedef struct sjpeg_hip_engine sjpeg_hip_engine;
 
 int sjpeg_hip_abi_version(void);

@@ -17,6 +17,7 @@
 #include <string>
 #include <vector>
 
+#include <dlfcn.h>
 #include <hip/hip_runtime_api.h>
 
 #include "jpeg_host.h"
@@ -109,10 +110,7 @@ std::mutex g_risk_mutex;
 std::vector<uint8_t> g_risk_table;
 int g_risk_generation = 0;
 
-bool LoadRiskTableFromEnv() {                      // under g_risk_mutex
-  if (!g_risk_table.empty()) return true;
-  const char* path = getenv("SJPEG_HIP_RISKINESS_TABLE");
-  if (path == nullptr) return false;
+bool ReadRiskTable(const char* path) {
   FILE* f = fopen(path, "rb");
   if (f == nullptr) return false;
   std::vector<uint8_t> t(SJPEG_HIP_RISKINESS_TABLE_SIZE + 1);
@@ -123,6 +121,23 @@ bool LoadRiskTableFromEnv() {                      // under g_risk_mutex
   g_risk_table.swap(t);
   ++g_risk_generation;
   return true;
+}
+
+// Where the table is looked for, in this order: what sjpeg_hip_set_riskiness_table() installed, the
+// file named by SJPEG_HIP_RISKINESS_TABLE, `riskiness.bin` in the directory this shared library was
+// loaded from (a deployment installs it once, next to the library: tools/extract_riskiness_table.py).
+bool LoadRiskTableFromEnv() {                      // under g_risk_mutex
+  if (!g_risk_table.empty()) return true;
+  const char* path = getenv("SJPEG_HIP_RISKINESS_TABLE");
+  if (path != nullptr && ReadRiskTable(path)) return true;
+  Dl_info info;
+  if (dladdr(reinterpret_cast<const void*>(&ReadRiskTable), &info) != 0 && info.dli_fname != nullptr) {
+    std::string dir(info.dli_fname);
+    const size_t slash = dir.rfind('/');
+    dir = (slash == std::string::npos) ? std::string(".") : dir.substr(0, slash);
+    if (ReadRiskTable((dir + "/riskiness.bin").c_str())) return true;
+  }
+  return false;
 }
 
 // SjpegRiskiness' arithmetic on the three sums (src/jpeg_tools.cc:212-236)
@@ -153,6 +168,9 @@ struct DeviceContext {
   void* d_planes = nullptr; size_t planes_cap = 0;   // SJPEG_YUV_SHARP: converted planes
   void* d_work = nullptr; size_t work_cap = 0;       //                  and the conversion's workspace
   uint64_t* d_size = nullptr;
+  // All work of a host thread runs on the context's own non-blocking stream: concurrent encodes from
+  // several threads do not serialise on the legacy NULL stream or wait for each other's kernels.
+  hipStream_t stream = nullptr;
   // Pinned host memory the device writes directly (fine-grained, visible after a stream
   // synchronise): the coded size, and the whole stream of a small picture -- one wait instead of
   // two device -> host copies, which were a third of the fixed cost of a thumbnail encode.
@@ -162,7 +180,10 @@ struct DeviceContext {
   uint8_t* d_mail = nullptr;                          // the same memory as the device addresses it
   ~DeviceContext() {
     if (engine == nullptr) return;
-    (void)hipSetDevice(device);
+    // (thread_local: this may run at process exit, after the HIP runtime has shut down -- every call
+    // below then fails with hipErrorDeinitialized, which is ignored like any other error here)
+    if (hipSetDevice(device) != hipSuccess) return;
+    if (stream) { (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); }
     if (d_in) (void)hipFree(d_in);
     if (d_out) (void)hipFree(d_out);
     if (d_stats) (void)hipFree(d_stats);
@@ -180,6 +201,7 @@ struct DeviceContext {
     const char* env = getenv("SJPEG_HIP_DEVICE");
     device = env ? atoi(env) : 0;
     if (sjpeg_hip_engine_create(device, &engine) != 0) return FailHip("sjpeg_hip_engine_create");
+    if (hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) return Fail("hipStreamCreate failed");
     if (hipMalloc(reinterpret_cast<void**>(&d_size), sizeof(uint64_t)) != hipSuccess) {
       return Fail("hipMalloc(size word) failed");
     }
@@ -189,18 +211,31 @@ struct DeviceContext {
     }
     return true;
   }
+  // stream-ordered copies (device -> host ones wait for the stream: the data is needed right away)
+  bool ToHost(void* dst, const void* src, size_t n) {
+    return hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, stream) == hipSuccess &&
+           hipStreamSynchronize(stream) == hipSuccess;
+  }
+  bool ToDevice(void* dst, const void* src, size_t n) {
+    return hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, stream) == hipSuccess;
+  }
+  bool ToDevice2D(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height) {
+    return hipMemcpy2DAsync(dst, dpitch, src, spitch, width, height, hipMemcpyHostToDevice, stream) == hipSuccess;
+  }
   // the caller's riskiness table on this device; false (with the reason) if none was supplied
   bool EnsureRiskTable() {
     std::lock_guard<std::mutex> lock(g_risk_mutex);
     if (!LoadRiskTableFromEnv()) {
       return Fail("the riskiness score table is not installed: SJPEG_YUV_AUTO / SjpegCompress / "
-                  "SjpegRiskiness need the reference's trained table (sjpeg_hip_set_riskiness_table() "
-                  "or SJPEG_HIP_RISKINESS_TABLE), which this library does not ship");
+                  "SjpegRiskiness need the reference's trained table (sjpeg_hip_set_riskiness_table(), the file "
+                  "named by SJPEG_HIP_RISKINESS_TABLE, or riskiness.bin next to this library: "
+                  "tools/extract_riskiness_table.py writes it from a build of the reference), which this "
+                  "library does not ship");
     }
     if (risk_generation == g_risk_generation) return true;
     if (d_risk == nullptr && hipMalloc(&d_risk, SJPEG_HIP_RISKINESS_TABLE_SIZE) != hipSuccess) return Fail("hipMalloc failed");
     if (d_sums == nullptr && hipMalloc(reinterpret_cast<void**>(&d_sums), 3 * sizeof(uint64_t)) != hipSuccess) return Fail("hipMalloc failed");
-    if (hipMemcpy(d_risk, g_risk_table.data(), SJPEG_HIP_RISKINESS_TABLE_SIZE, hipMemcpyHostToDevice) != hipSuccess) {
+    if (!ToDevice(d_risk, g_risk_table.data(), SJPEG_HIP_RISKINESS_TABLE_SIZE) || hipStreamSynchronize(stream) != hipSuccess) {
       return Fail("riskiness table upload failed");
     }
     risk_generation = g_risk_generation;
@@ -209,11 +244,11 @@ struct DeviceContext {
   // riskiness of a device-resident RGB / BGRA / RGBA picture
   bool Riskiness(const sjpeg_hip_source& dsrc, int W, int H, SjpegYUVMode* mode, float* risk) {
     if (!EnsureRiskTable()) return false;
-    if (sjpeg_hip_riskiness_sums(&dsrc, W, H, 1, static_cast<const uint8_t*>(d_risk), d_sums, nullptr) != 0) {
+    if (sjpeg_hip_riskiness_sums(&dsrc, W, H, 1, static_cast<const uint8_t*>(d_risk), d_sums, stream) != 0) {
       return Fail("sjpeg_hip_riskiness_sums failed");
     }
     uint64_t sums[3];
-    if (hipMemcpy(sums, d_sums, sizeof(sums), hipMemcpyDeviceToHost) != hipSuccess) return Fail("riskiness read-back failed");
+    if (!ToHost(sums, d_sums, sizeof(sums))) return Fail("riskiness read-back failed");
     *mode = RiskVerdict(sums[0], sums[1], sums[2], W, H, risk);
     return true;
   }
@@ -341,6 +376,9 @@ bool Encoder::RunImpl() {
 
   DeviceContext& ctx = g_ctx;
   if (!ctx.Init()) return false;
+  // the caller's pixels are read by stream-ordered copies: whatever way this call ends, nothing of
+  // it is still in flight when it returns
+  struct SyncOnExit { hipStream_t s; ~SyncOnExit() { (void)hipStreamSynchronize(s); } } sync_on_exit{ctx.stream};
   if (hipSetDevice(ctx.device) != hipSuccess) return Fail("hipSetDevice failed");
 
   // pixels -> device, plane by plane.  Rows keep a 16-byte aligned pitch; a bottom-up plane
@@ -391,7 +429,7 @@ bool Encoder::RunImpl() {
       uint8_t* d = d_in + offset[i];
       if (in_place) {
         for (size_t y = 0; y < rows[i]; ++y) memcpy(h_in + offset[i] + y * pitch[i], lowest + y * host_pitch, row_bytes[i]);
-      } else if (hipMemcpy2D(d, pitch[i], lowest, host_pitch, row_bytes[i], rows[i], hipMemcpyHostToDevice) != hipSuccess) {
+      } else if (!ctx.ToDevice2D(d, pitch[i], lowest, host_pitch, row_bytes[i], rows[i])) {
         return Fail("hipMemcpy2D(host -> device) failed");
       }
       dsrc.plane[i] = st < 0 ? d + pitch[i] * (rows[i] - 1) : d;
@@ -414,7 +452,7 @@ bool Encoder::RunImpl() {
     if (!ctx.Ensure(&ctx.d_planes, &ctx.planes_cap, ysz + 2 * csz + 64)) return false;
     if (!ctx.Ensure(&ctx.d_work, &ctx.work_cap, wsz)) return false;
     uint8_t* const py = static_cast<uint8_t*>(ctx.d_planes);
-    if (sjpeg_hip_sharp_yuv(&dsrc, W_, H_, 1, py, py + ysz, py + ysz + csz, 0, 0, ctx.d_work, wsz, nullptr) != 0) {
+    if (sjpeg_hip_sharp_yuv(&dsrc, W_, H_, 1, py, py + ysz, py + ysz + csz, 0, 0, ctx.d_work, wsz, ctx.stream) != 0) {
       return Fail("sjpeg_hip_sharp_yuv failed");
     }
     memset(&dsrc, 0, sizeof(dsrc));
@@ -453,7 +491,7 @@ bool Encoder::RunImpl() {
     // stays on the device, only the sums AnalyseHisto makes of it come back
     if (!ctx.Ensure(&ctx.d_hist, &ctx.hist_cap, kHistBytes + kSumsBytes + kTotLastBytes)) return false;
     if (sjpeg_hip_scan_histogram_src(ctx.engine, &dsrc, W_, H_, mode, 1,
-                                 static_cast<uint32_t*>(ctx.d_hist), nullptr) != 0) {
+                                 static_cast<uint32_t*>(ctx.d_hist), ctx.stream) != 0) {
       return FailHip("sjpeg_hip_scan_histogram");
     }
   }
@@ -465,9 +503,9 @@ bool Encoder::RunImpl() {
     static thread_local int64_t sums[2][64][sjpeg_host::kAdaptDeltas][2];
     static thread_local int32_t totlast[2][64][2];
     if (sjpeg_hip_adapt_sums(static_cast<const uint32_t*>(ctx.d_hist), 1, quant_, &min_quant_[0][0], d_sums,
-                             d_totlast, nullptr) != 0 ||
-        hipMemcpy(sums, d_sums, kSumsBytes, hipMemcpyDeviceToHost) != hipSuccess ||
-        hipMemcpy(totlast, d_totlast, kTotLastBytes, hipMemcpyDeviceToHost) != hipSuccess) {
+                             d_totlast, ctx.stream) != 0 ||
+        !ctx.ToHost(sums, d_sums, kSumsBytes) ||
+        !ctx.ToHost(totlast, d_totlast, kTotLastBytes)) {
       adapt_ok = false;
       return;
     }
@@ -478,10 +516,10 @@ bool Encoder::RunImpl() {
   };
   auto symbol_stats = [&](uint32_t freq[2][272]) -> bool {
     if (sjpeg_hip_scan_symbol_stats_src(ctx.engine, &dsrc, W_, H_, mode, 1, &tables,
-                                        static_cast<uint32_t*>(ctx.d_stats), nullptr) != 0) {
+                                        static_cast<uint32_t*>(ctx.d_stats), ctx.stream) != 0) {
       return FailHip("sjpeg_hip_scan_symbol_stats");
     }
-    if (hipMemcpy(freq, ctx.d_stats, 2 * 272 * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess) {
+    if (!ctx.ToHost(freq, ctx.d_stats, 2 * 272 * sizeof(uint32_t))) {
       return Fail(std::string("statistics pass failed: ") + hipGetErrorString(hipGetLastError()));
     }
     return true;
@@ -566,18 +604,18 @@ bool Encoder::RunImpl() {
           const size_t cap = sjpeg_hip_frame_bound(W_, H_, mode, 0);
           if (cap == 0 || !ctx.Ensure(&ctx.d_out, &ctx.out_cap, cap)) return false;
           if (sjpeg_hip_encode_scan_src(ctx.engine, &dsrc, W_, H_, mode, 1, &tables, nullptr, 0, 0,
-                                        ctx.d_out, cap, ctx.d_size, nullptr) != 0) {
+                                        ctx.d_out, cap, ctx.d_size, ctx.stream) != 0) {
             return FailHip("sjpeg_hip_encode_scan");
           }
           uint64_t bits = 0, bytes = 0;
           if (sjpeg_hip_engine_entropy_bits(ctx.engine, &bits, 1) != 0) return FailHip("entropy_bits");
-          if (hipMemcpy(&bytes, ctx.d_size, sizeof(bytes), hipMemcpyDeviceToHost) != hipSuccess || bytes == 0) {
+          if (!ctx.ToHost(&bytes, ctx.d_size, sizeof(bytes)) || bytes == 0) {
             return Fail("size pass failed");
           }
           uint64_t escapes = bytes - (bits + 7) / 8;
           if ((bits & 7) != 0 && bytes >= 2) {       // a padded last byte that became 0xFF is not counted
             uint8_t tail[2];
-            if (hipMemcpy(tail, static_cast<const uint8_t*>(ctx.d_out) + bytes - 2, 2, hipMemcpyDeviceToHost) != hipSuccess) {
+            if (!ctx.ToHost(tail, static_cast<const uint8_t*>(ctx.d_out) + bytes - 2, 2)) {
               return Fail("size pass failed");
             }
             if (tail[0] == 0xff && tail[1] == 0x00) --escapes;
@@ -589,10 +627,10 @@ bool Encoder::RunImpl() {
         // ComputePSNR (src/dichotomy.cc:295-323)
         uint64_t err = 0;
         if (sjpeg_hip_scan_quant_error_src(ctx.engine, &dsrc, W_, H_, mode, 1, &tables,
-                                           reinterpret_cast<uint64_t*>(ctx.d_stats), nullptr) != 0) {
+                                           reinterpret_cast<uint64_t*>(ctx.d_stats), ctx.stream) != 0) {
           return FailHip("sjpeg_hip_scan_quant_error");
         }
-        if (hipMemcpy(&err, ctx.d_stats, sizeof(err), hipMemcpyDeviceToHost) != hipSuccess) return Fail("error pass failed");
+        if (!ctx.ToHost(&err, ctx.d_stats, sizeof(err))) return Fail("error pass failed");
         sjpeg_host::FrameLayout L;
         sjpeg_host::LayoutFor(mode, &L);
         const uint64_t nb_mbs = static_cast<uint64_t>((W_ + L.block_w - 1) / L.block_w) * ((H_ + L.block_h - 1) / L.block_h);
@@ -673,10 +711,10 @@ bool Encoder::RunImpl() {
   *h_size = 0;
   if (sjpeg_hip_encode_scan_src(ctx.engine, &dsrc, W_, H_, mode, 1, &tables,
                             staged_header, header.size(), /*append_eoi=*/1, d_stream, bound,
-                            reinterpret_cast<uint64_t*>(ctx.d_mail), nullptr) != 0) {
+                            reinterpret_cast<uint64_t*>(ctx.d_mail), ctx.stream) != 0) {
     return FailHip("sjpeg_hip_encode_scan");
   }
-  if (hipStreamSynchronize(nullptr) != hipSuccess) {
+  if (hipStreamSynchronize(ctx.stream) != hipSuccess) {
     return Fail(std::string("device execution failed: ") + hipGetErrorString(hipGetLastError()));
   }
   const uint64_t size = *h_size;
@@ -687,7 +725,7 @@ bool Encoder::RunImpl() {
   if (!sink_->Commit(0, size, &dst) || dst == nullptr) { sink_->Reset(); return Fail("sink refused the output"); }
   if (mailed) {
     memcpy(dst, ctx.h_mail + 64, size);
-  } else if (hipMemcpy(dst, ctx.d_out, size, hipMemcpyDeviceToHost) != hipSuccess) {
+  } else if (!ctx.ToHost(dst, ctx.d_out, size)) {
     sink_->Reset();
     return Fail("hipMemcpy(device -> host) failed");
   }
@@ -1048,11 +1086,11 @@ SjpegYUVMode SjpegRiskiness(const uint8_t* rgb, int width, int height, int strid
   }
   DeviceContext& ctx = g_ctx;
   if (!ctx.Init() || hipSetDevice(ctx.device) != hipSuccess) return SJPEG_YUV_AUTO;
+  struct SyncOnExit { hipStream_t s; ~SyncOnExit() { (void)hipStreamSynchronize(s); } } sync_on_exit{ctx.stream};
   const size_t pitch = (3 * static_cast<size_t>(width) + 15) & ~static_cast<size_t>(15);
   if (!ctx.Ensure(&ctx.d_in, &ctx.in_cap, pitch * height + 64)) return SJPEG_YUV_AUTO;
   const uint8_t* lowest = stride < 0 ? rgb + static_cast<long long>(height - 1) * stride : rgb;
-  if (hipMemcpy2D(ctx.d_in, pitch, lowest, abs_stride, 3 * static_cast<size_t>(width), height,
-                  hipMemcpyHostToDevice) != hipSuccess) {
+  if (!ctx.ToDevice2D(ctx.d_in, pitch, lowest, abs_stride, 3 * static_cast<size_t>(width), height)) {
     Fail("hipMemcpy2D(host -> device) failed");
     return SJPEG_YUV_AUTO;
   }

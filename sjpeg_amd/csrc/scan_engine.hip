@@ -233,10 +233,19 @@ sjpeg_hip_source rgb_source(const void* d_rgb, int64_t row_stride, int64_t frame
 // Orders this call after everything the engine was asked to do on another stream.
 int order_on_stream(sjpeg_hip_engine* e, hipStream_t st) {
   if (e->last_stream_valid && e->last_stream != st) {
-    if (e->cross_ev == nullptr) HIP_TRY(hipEventCreateWithFlags(&e->cross_ev, hipEventDisableTiming));
-    HIP_TRY(hipEventRecord(e->cross_ev, e->last_stream));
-    HIP_TRY(hipStreamWaitEvent(st, e->cross_ev, 0));
-    if (e->side_pending) HIP_TRY(hipStreamWaitEvent(st, e->side_done, 0));
+    // The previous call's stream belongs to the caller and may be gone by now (sjpeg_hip.h asks for
+    // it to outlive the engine's next call, but a destroyed handle must not wedge the engine): if
+    // the event hand-over fails, wait for the whole device instead and carry on.
+    bool ordered = (e->cross_ev != nullptr) || hipEventCreateWithFlags(&e->cross_ev, hipEventDisableTiming) == hipSuccess;
+    ordered = ordered && hipEventRecord(e->cross_ev, e->last_stream) == hipSuccess &&
+              hipStreamWaitEvent(st, e->cross_ev, 0) == hipSuccess;
+    if (ordered && e->side_pending) ordered = hipStreamWaitEvent(st, e->side_done, 0) == hipSuccess;
+    if (!ordered) {
+      (void)hipGetLastError();                     // clear the sticky error of the stale handle
+      e->last_stream_valid = false;
+      e->tables_held_at = nullptr; e->header_held_at = nullptr;   // (their streams may be the stale one)
+      HIP_TRY(hipDeviceSynchronize());
+    }
   }
   e->last_stream = st;
   e->last_stream_valid = true;
@@ -606,6 +615,7 @@ static int encode_scan_impl(sjpeg_hip_engine* e, const sjpeg_hip_source* src, in
                             const void* header, size_t header_size, const size_t* header_offsets,
                             int append_eoi, void* d_out, size_t out_stride, uint64_t* d_sizes,
                             void* stream) {
+  if (e == nullptr) return fail(SJPEG_HIP_EINVAL, "engine == NULL");
   if (d_out == nullptr || d_sizes == nullptr) return fail(SJPEG_HIP_EINVAL, "d_out/d_sizes == NULL");
   if (header == nullptr) header_size = 0;
   const bool multi = header_offsets != nullptr;

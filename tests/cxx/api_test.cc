@@ -65,9 +65,37 @@ struct FlakySink : public sjpeg::ByteSink {
   void Reset() override { data.clear(); pos = 0; reset_called = true; }
 };
 
+// api_test <outdir> --auto <rgb file> <w> <h> [expect-fail]: the out-of-the-box calls of the reference
+// (SjpegCompress, and sjpeg::Encode with a default EncoderParam = SJPEG_YUV_AUTO), with nothing but the
+// library's own discovery of the riskiness table (file next to the library / SJPEG_HIP_RISKINESS_TABLE).
+static int AutoMode(const std::string& dir, const char* path, int w, int h, bool expect_fail) {
+  std::vector<uint8_t> rgb(3 * static_cast<size_t>(w) * h);
+  FILE* f = fopen(path, "rb");
+  if (f == nullptr || fread(rgb.data(), 1, rgb.size(), f) != rgb.size()) { fprintf(stderr, "cannot read %s\n", path); return 99; }
+  fclose(f);
+  uint8_t* out = nullptr;
+  const size_t n = SjpegCompress(rgb.data(), w, h, 75.f, &out);
+  std::string dflt;
+  const bool ok = sjpeg::Encode(rgb.data(), w, h, 3 * w, sjpeg::EncoderParam(), &dflt);
+  if (expect_fail) {
+    // no table anywhere: both must fail, loudly, never fall back to another colour mode
+    CHECK(n == 0 && out == nullptr && !ok);
+    CHECK(strstr(SjpegHipLastError(), "riskiness") != nullptr);
+  } else {
+    CHECK(n > 0 && out != nullptr && ok);
+    if (n > 0) Save(dir, "compress_c1", std::string(reinterpret_cast<const char*>(out), n));
+    Save(dir, "default_param_auto", dflt);
+  }
+  SjpegFreeBuffer(out);
+  return g_failures;
+}
+
 int main(int argc, char** argv) {
   const std::string dir = argc > 1 ? argv[1] : ".";
   CHECK(SjpegVersion() == 0x000101);
+  if (argc >= 6 && strcmp(argv[2], "--auto") == 0) {
+    return AutoMode(dir, argv[3], atoi(argv[4]), atoi(argv[5]), argc >= 7 && strcmp(argv[6], "expect-fail") == 0);
+  }
 
   // ---- parity cases through EncoderParam (default = adaptive quantization + optimised Huffman)
   const int W = 141, H = 99;
@@ -272,8 +300,10 @@ int main(int argc, char** argv) {
     CHECK(!sjpeg::Encode(rgb.data(), W, H, 3 * W, param, static_cast<sjpeg::ByteSink*>(nullptr)));
     CHECK(sjpeg::Encode(rgb.data(), W, H, 3 * W, param, static_cast<uint8_t**>(nullptr)) == 0);
     CHECK(SjpegEncode(rgb.data(), W, H, 3 * W, &buf, 75.f, 0, static_cast<SjpegYUVMode>(11)) == 0);
-    param.yuv_mode = SJPEG_YUV_AUTO;                    // documented gap of this build: fails loudly
-    CHECK(!sjpeg::Encode(rgb.data(), W, H, 3 * W, param, &out) && strlen(SjpegHipLastError()) > 0);
+    // SJPEG_YUV_AUTO works where the riskiness table is installed (next to the library, environment,
+    // or setter) and fails loudly where it is not; never a silent other mode (--auto checks the bytes)
+    param.yuv_mode = SJPEG_YUV_AUTO;
+    CHECK(sjpeg::Encode(rgb.data(), W, H, 3 * W, param, &out) || strstr(SjpegHipLastError(), "riskiness") != nullptr);
   }
 
   // ---- large dimensions (reference: unit_test.cc:393-409): 65535 is legal

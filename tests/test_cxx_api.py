@@ -14,11 +14,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "tests", "cxx", "api_test.cc")
 
 
-def _build(tmpdir):
+def _build(tmpdir, libdir=None):
+    libdir = libdir or sj.CSRC
     exe = os.path.join(tmpdir, "api_test")
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"), SRC,
-                           "-o", exe, "-L", sj.CSRC, "-lsjpeg_amd", "-lpthread",
-                           "-Wl,-rpath," + sj.CSRC, "-Wl,-rpath-link,/opt/rocm/lib"])
+                           "-o", exe, "-L", libdir, "-lsjpeg_amd", "-lpthread",
+                           "-Wl,-rpath," + libdir, "-Wl,-rpath-link,/opt/rocm/lib"])
     return exe
 
 
@@ -107,3 +108,47 @@ def test_cxx_api_behaviour_and_parity(tmp_path, oracle):
                     idx += 1
     assert read("search_hooked") == oracle.encode_search(orc.SRC_RGB, [img], 141, 99, q60, yuv_mode=1,
                                                          target_mode=1, target_value=5000.0, passes=4)
+
+
+@pytest.mark.gpu
+def test_cxx_out_of_the_box_auto_mode(tmp_path):
+    """SjpegCompress() and sjpeg::Encode(default EncoderParam) -- the reference's out-of-the-box calls,
+    both SJPEG_YUV_AUTO -- through a C++ caller that installs NOTHING: the library finds the riskiness
+    table by itself (file next to it, or the file named by SJPEG_HIP_RISKINESS_TABLE), and without any it
+    fails loudly instead of picking a colour mode.  BASELINE config #1's known answer."""
+    import hashlib
+    import shutil
+    table = os.path.join(sj.CSRC, "riskiness.bin")
+    if not os.path.exists(table):
+        pytest.skip("sjpeg_amd/csrc/riskiness.bin not installed (__graft_entry__.build() extracts it from oracle/_ref)")
+    rgb = os.path.join(ROOT, "tests", "golden", "test128.rgb")
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = "/opt/rocm/lib:" + env.get("LD_LIBRARY_PATH", "")
+    env.pop("SJPEG_HIP_RISKINESS_TABLE", None)
+
+    def run(exe, outdir, extra_env=None, expect_fail=False):
+        os.makedirs(outdir, exist_ok=True)
+        e = dict(env)
+        e.update(extra_env or {})
+        args = [exe, outdir, "--auto", rgb, "128", "128"] + (["expect-fail"] if expect_fail else [])
+        r = subprocess.run(args, capture_output=True, text=True, env=e)
+        assert r.returncode == 0, r.stdout + r.stderr
+        if not expect_fail:
+            got = open(os.path.join(outdir, "compress_c1.jpg"), "rb").read()
+            assert len(got) == 2571 and hashlib.md5(got).hexdigest() == "acc8ce8111f5ff4b32b3faa15ad5d994"
+            assert open(os.path.join(outdir, "default_param_auto.jpg"), "rb").read() == got   # same call by another name
+
+    # 1. the shipped layout: riskiness.bin next to libsjpeg_amd.so
+    run(_build(str(tmp_path)), str(tmp_path / "o1"))
+    # 2. a copy of the library alone in another directory: nothing to find -> loud failure;
+    #    then the environment variable; then the file next to THAT copy
+    libdir = tmp_path / "lib"
+    libdir.mkdir()
+    shutil.copy(sj.LIB_PATH, libdir / "libsjpeg_amd.so")
+    exe2dir = tmp_path / "exe2"
+    exe2dir.mkdir()
+    exe2 = _build(str(exe2dir), str(libdir))
+    run(exe2, str(tmp_path / "o2"), expect_fail=True)
+    run(exe2, str(tmp_path / "o3"), {"SJPEG_HIP_RISKINESS_TABLE": table})
+    shutil.copy(table, libdir / "riskiness.bin")
+    run(exe2, str(tmp_path / "o4"))
