@@ -59,7 +59,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
   // tables -> LDS; issued once the first pixel loads are in flight (see P1)
 #ifdef SJPEG_HIP_PRIO_STRESS
   // race stress (make STRESS=1|2): the waves of a workgroup run at different priorities, flipped at
-  // the entropy phase -- a missing barrier shows up as a parity failure (one did)
+  // the entropy phase -- a missing barrier shows up as a parity failure (one did, profiles/HISTORY_r01.md)
   prio_stress<SJPEG_HIP_PRIO_STRESS>(0);
 #endif
   auto stage_tables = [&]() {

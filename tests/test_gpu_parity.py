@@ -281,7 +281,7 @@ def test_row_offsets_beyond_2_31_bytes(engine, oracle):
     """64-bit addressing: rows whose byte offset in the source passes 2^31 (and 2^32).  The same
     pixels coded from a contiguous buffer are the expected bytes (a stride never changes the
     output).  The reference itself addresses MCUs with 32-bit ints (src/encoders.cc:171,207,240)
-    and is not a checker past 2^31: DESIGN.md section 6, tools/huge_frame_vs_oracle.py."""
+    and is not a checker past 2^31: profiles/HISTORY_r01.md, tools/huge_frame_vs_oracle.py."""
     w, h = 200, 120
     img = synth.g_struct(w, h, 2468)
     stride = 40 * 1000 * 1000 + 16                 # row 54 starts beyond 2^31, row 108 beyond 2^32

@@ -1,7 +1,7 @@
 """First probe of frames beyond 2^32 bytes of pixels.  KEPT FOR THE RECORD, NOT A VALID CHECK: it
 compares with the real reference, which addresses MCUs with 32-bit ints (src/encoders.cc:171,207,
 240) and is undefined once the source offset passes 2^31 -- its "MISMATCH" lines are the
-reference overflowing, see DESIGN.md section 6.  Use tools/huge_frame_vs_oracle.py instead.
+reference overflowing, see profiles/HISTORY_r01.md.  Use tools/huge_frame_vs_oracle.py instead.
 Usage: python tools/huge_frame_check.py [max]"""
 import hashlib
 import os
