@@ -365,6 +365,7 @@ def main():
                        "yuv_mode": "420", "parallelism": f"frame-sharded x{world}, no data-path collective"},
             "bit_exact": bool(parity),
             "bytes_per_frame": int(sz[0]),
+            "engine_scratch_bytes": eng.scratch_bytes(),
             "roofline": roof,
         }
         res["config"]["pipelined"] = bool(args.pipelined)

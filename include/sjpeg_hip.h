@@ -416,6 +416,12 @@ int sjpeg_hip_engine_set_timing(sjpeg_hip_engine* engine, int enable);
 float sjpeg_hip_engine_last_scan_ms(sjpeg_hip_engine* engine);
 float sjpeg_hip_engine_last_total_ms(sjpeg_hip_engine* engine);
 
+/* Device memory the engine currently holds (it grows to what the largest call needed and is released
+ * by sjpeg_hip_engine_destroy).  The segment scratch of an encode call is sized from the caller's
+ * out_stride: per frame about 3.5 x out_stride (segment slots + pool + the un-stuffed stream), capped at
+ * the worst case of the geometry -- not the worst case itself. */
+size_t sjpeg_hip_engine_scratch_bytes(sjpeg_hip_engine* engine);
+
 /* Measurement aids of bench.py (no counterpart in the reference, not part of the encode path).
  * sjpeg_hip_debug_stream_read: a read-only streaming kernel over `bytes` of d_buf -- what the device's
  * HBM delivers to the simplest possible reader, beside the 8 TB/s specification figure.

@@ -251,7 +251,7 @@ EXPORTED_C_SYMBOLS = [
     "sjpeg_hip_set_riskiness_table", "sjpeg_hip_has_riskiness_table", "sjpeg_hip_riskiness_sums",
     "sjpeg_hip_segment_count", "sjpeg_hip_band_bound", "sjpeg_hip_encode_band_src", "sjpeg_hip_stitch_bands",
     "sjpeg_hip_engine_set_timing", "sjpeg_hip_engine_last_scan_ms",
-    "sjpeg_hip_engine_last_total_ms", "sjpeg_hip_compact_streams",
+    "sjpeg_hip_engine_last_total_ms", "sjpeg_hip_engine_scratch_bytes", "sjpeg_hip_compact_streams",
     "sjpeg_hip_debug_stream_read", "sjpeg_hip_debug_valu_rate",
 ]
 
@@ -499,6 +499,13 @@ class Engine:
 
     def last_total_ms(self) -> float:
         return lib().sjpeg_hip_engine_last_total_ms(self._h)
+
+    def scratch_bytes(self) -> int:
+        """Device memory the engine holds right now (sjpeg_hip_engine_scratch_bytes)."""
+        f = lib().sjpeg_hip_engine_scratch_bytes
+        f.restype = C.c_size_t
+        f.argtypes = [C.c_void_p]
+        return int(f(self._h))
 
     @staticmethod
     def _stream():

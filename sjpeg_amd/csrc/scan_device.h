@@ -10,7 +10,6 @@ constexpr int kThreads = 256;        // stitch kernels (K2..K5): 4 waves
 constexpr int kScanThreads = 256;    // K1: 4 waves = 41 coded MCUs + 1 halo MCU in 4:2:0
 constexpr int kSlotBytes = 144;      // 64 int16 + 16 B pad: conflict-free ds_read_b128 per lane
 constexpr int kWinWords = 2048;       // LDS bit window, 32-bit MSB-first words (8 KiB)
-constexpr int kSpillWords = 64;      // per block: 16 words for each of the four parts (<= 496 bits)
 constexpr int kMaxBlockBits = 1728;  // 22 (DC) + 63*27 (AC) rounded up; reference bound enc.cc:206-209
 constexpr int kChunkWords = 1024;    // K3/K5 chunk: 4 KiB of un-stuffed stream
 constexpr int kChunkBytes = kChunkWords * 4;
@@ -62,10 +61,15 @@ struct ScanArgs {
   int seg_first;                // band mode: frame-level index of this launch's segment 0
   const DevTables* tables;
   int tables_stride;            // 0: every frame uses tables[0]; 1: frame f uses tables[f]
-  uint32_t* seg_words;     // [nframes*nseg][slot_words]
+  uint32_t* seg_words;     // [nframes*nseg][slot_words]: the first slot_words words of every segment
   uint32_t slot_words;
   uint32_t* seg_nbits;     // [nframes*nseg]
-  uint32_t* spill;         // [nframes*nseg][kScanThreads][kSpillWords]: words that cannot stay in the slot
+  // per-frame pool: what of a segment does not fit its slot (seg_xbase: word offset, ~0 = nothing or
+  // the pool was full), and the rows of the checked walk; pool_ctr[2f] = words taken, [2f + 1] = overran
+  uint32_t* pool;          // [nframes][pool_words]
+  uint32_t pool_words;
+  uint32_t* pool_ctr;      // [nframes][2]
+  uint32_t* seg_xbase;     // [nframes*nseg]
   uint32_t* replay;        // [nframes*nseg][kScanThreads][36]: quantized blocks kept by a statistics pass (or NULL)
   int16_t* coeffs;         // kKindTap: quantized coefficients
   uint32_t* partial;       // kKindHisto / kKindStats: per-workgroup partial statistics

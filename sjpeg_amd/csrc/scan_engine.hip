@@ -121,7 +121,7 @@ struct sjpeg_hip_engine {
   std::vector<uint8_t> header_held;
   const void* tables_held_at = nullptr; const void* header_held_at = nullptr;
   hipStream_t tables_stream = nullptr, header_stream = nullptr;
-  DevBuf<uint32_t> seg_words, seg_nbits, spill, ubuf, chunk_ff, partial, replay;
+  DevBuf<uint32_t> seg_words, seg_nbits, pool, pool_ctr, seg_xbase, ubuf, chunk_ff, partial, replay;
   int replay_w = 0, replay_h = 0, replay_mode = 0, replay_nframes = 0;   // what `replay` holds (0 = nothing)
   DevBuf<unsigned long long> seg_off, chunk_off, stamps;
   DevBuf<uint32_t> hdr_off;
@@ -142,7 +142,7 @@ struct sjpeg_hip_engine {
   hipEvent_t cross_ev = nullptr;
   bool pipelined = false;
   hipStream_t side = nullptr;
-  DevBuf<uint32_t> seg_words2, seg_nbits2;
+  DevBuf<uint32_t> seg_words2, seg_nbits2, pool2, pool_ctr2, seg_xbase2;
   int set = 0;                                   // buffer set of the NEXT call
   hipEvent_t k1_done = nullptr, side_done = nullptr, k3_done[2] = {nullptr, nullptr};
   bool k3_pending[2] = {false, false}, side_pending = false;
@@ -252,10 +252,37 @@ int order_on_stream(sjpeg_hip_engine* e, hipStream_t st) {
   return 0;
 }
 
+// Segment scratch of an encode call, sized from the bytes the caller gives every frame (out_stride)
+// instead of for the worst case: a frame's un-stuffed stream is never longer than its stuffed one, so
+// `budget` words hold it whenever the frame fits its output slot -- and a frame that does not fit
+// reports size 0 anyway.  Every segment has a slot of about half its share of the budget (the
+// ordinary segment fits; K3 reads it without indirection); what a longer segment has beyond that, and
+// the rows of the checked walk (scan_segments.h), come out of a per-frame pool.  Both are at most as
+// long as the stream, hence 2 x budget.  budget_bytes == SIZE_MAX: worst case (bands, which have no
+// output slot to go by).
+struct SegPlan { uint32_t slot_words, pool_words; size_t ubuf_words; };
+SegPlan seg_plan(const FrameGeo& g, size_t budget_bytes) {
+  const size_t worst_total = static_cast<size_t>(g.nseg) * g.slot_words;
+  size_t budget = budget_bytes == SIZE_MAX ? worst_total : budget_bytes / 4 + 16;
+  if (budget > worst_total) budget = worst_total;
+  SegPlan p;
+  size_t sw = (budget / static_cast<size_t>(g.nseg) / 2 + 63) & ~size_t(63);
+  const size_t floor_words = g.slot_words < 1024u ? g.slot_words : 1024u;
+  if (sw < floor_words) sw = floor_words;
+  if (sw > g.slot_words || budget >= worst_total) sw = g.slot_words;   // (worst-case budget: no segment is ever longer than its slot)
+  p.slot_words = static_cast<uint32_t>(sw);
+  size_t pool = (sw == g.slot_words ? budget : 2 * budget) + 64;
+  if (pool > 0xfffffff0u) pool = 0xfffffff0u;      // (word offsets are 32 bit: 16 GiB per frame)
+  p.pool_words = static_cast<uint32_t>(pool);
+  p.ubuf_words = (budget + kChunkWords + 3) & ~size_t(3);
+  return p;
+}
+
 int prepare_scan(sjpeg_hip_engine* e, const sjpeg_hip_source* src,
                  int W, int H, int mode, int nframes, const sjpeg_hip_scan_tables* tables,
                  hipStream_t st, FrameGeo* g, ScanArgs* a, int* src_class, bool per_frame_tables = false,
-                 bool piped_encode = false) {
+                 bool piped_encode = false, size_t seg_budget_bytes = 0 /* 0: not an encode, no segment scratch */,
+                 SegPlan* plan_out = nullptr) {
   if (e == nullptr || src == nullptr || src->plane[0] == nullptr || tables == nullptr || nframes <= 0) {
     return fail(SJPEG_HIP_EINVAL, "null argument or nframes <= 0");
   }
@@ -311,9 +338,16 @@ int prepare_scan(sjpeg_hip_engine* e, const sjpeg_hip_source* src,
   const int ntab = per_frame_tables ? nframes : 1;
   if ((rc = e->tables.ensure(ntab))) return rc;
   const size_t total_segs = static_cast<size_t>(nframes) * g->nseg;
-  if ((rc = e->seg_words.ensure(total_segs * g->slot_words))) return rc;
   if ((rc = e->seg_nbits.ensure(total_segs))) return rc;
-  if ((rc = e->spill.ensure(total_segs * kScanThreads * kSpillWords))) return rc;
+  SegPlan plan = {0, 0, 0};
+  if (seg_budget_bytes != 0) {
+    plan = seg_plan(*g, seg_budget_bytes);
+    if ((rc = e->seg_words.ensure(total_segs * plan.slot_words))) return rc;
+    if ((rc = e->pool.ensure(static_cast<size_t>(nframes) * plan.pool_words))) return rc;
+    if ((rc = e->pool_ctr.ensure(static_cast<size_t>(nframes) * 2))) return rc;
+    if ((rc = e->seg_xbase.ensure(total_segs))) return rc;
+  }
+  if (plan_out != nullptr) *plan_out = plan;
   {
     // (pageable source: the copy has left the host buffer when the call returns)
     std::vector<DevTables> host_tables(ntab);
@@ -338,9 +372,9 @@ int prepare_scan(sjpeg_hip_engine* e, const sjpeg_hip_source* src,
   a->tables = e->tables.p;
   a->tables_stride = per_frame_tables ? 1 : 0;
   a->seg_words = e->seg_words.p;
-  a->spill = e->spill.p;
+  a->pool = e->pool.p; a->pool_words = plan.pool_words; a->pool_ctr = e->pool_ctr.p; a->seg_xbase = e->seg_xbase.p;
   a->replay = nullptr;
-  a->slot_words = g->slot_words;
+  a->slot_words = plan.slot_words;
   a->seg_nbits = e->seg_nbits.p;
   a->coeffs = nullptr;
   a->partial = nullptr;
@@ -401,10 +435,10 @@ int sjpeg_hip_engine_create(int device, sjpeg_hip_engine** engine) {
 void sjpeg_hip_engine_destroy(sjpeg_hip_engine* e) {
   if (e == nullptr) return;
   (void)hipSetDevice(e->device);
-  e->tables.release(); e->header.release(); e->seg_words.release(); e->seg_nbits.release(); e->spill.release(); e->replay.release();
+  e->tables.release(); e->header.release(); e->seg_words.release(); e->seg_nbits.release(); e->pool.release(); e->pool_ctr.release(); e->seg_xbase.release(); e->replay.release();
   e->ubuf.release(); e->chunk_ff.release(); e->partial.release(); e->seg_off.release(); e->chunk_off.release(); e->hdr_off.release();
   for (auto& ev : e->ev) if (ev) (void)hipEventDestroy(ev);
-  e->seg_words2.release(); e->seg_nbits2.release();
+  e->seg_words2.release(); e->seg_nbits2.release(); e->pool2.release(); e->pool_ctr2.release(); e->seg_xbase2.release();
   if (e->side) { (void)hipStreamSynchronize(e->side); (void)hipStreamDestroy(e->side); }
   for (hipEvent_t ev : {e->k1_done, e->side_done, e->k3_done[0], e->k3_done[1], e->cross_ev}) if (ev) (void)hipEventDestroy(ev);
   delete e;
@@ -473,6 +507,14 @@ static float elapsed(sjpeg_hip_engine* e, int i0, int i1) {
 }
 float sjpeg_hip_engine_last_scan_ms(sjpeg_hip_engine* e) { return elapsed(e, 0, 1); }
 float sjpeg_hip_engine_last_total_ms(sjpeg_hip_engine* e) { return elapsed(e, 0, 2); }
+
+size_t sjpeg_hip_engine_scratch_bytes(sjpeg_hip_engine* e) {
+  if (e == nullptr) return 0;
+  auto b = [](const auto& buf) { return buf.cap * sizeof(*buf.p); };
+  return b(e->tables) + b(e->header) + b(e->seg_words) + b(e->seg_nbits) + b(e->pool) + b(e->pool_ctr) + b(e->seg_xbase) +
+         b(e->ubuf) + b(e->chunk_ff) + b(e->partial) + b(e->replay) + b(e->seg_off) + b(e->chunk_off) + b(e->stamps) +
+         b(e->hdr_off) + b(e->seg_words2) + b(e->seg_nbits2) + b(e->pool2) + b(e->pool_ctr2) + b(e->seg_xbase2);
+}
 
 int sjpeg_hip_scan_coeffs_src(sjpeg_hip_engine* e, const sjpeg_hip_source* src, int width, int height,
                               int yuv_mode, int nframes, const sjpeg_hip_scan_tables* tables,
@@ -624,7 +666,9 @@ static int encode_scan_impl(sjpeg_hip_engine* e, const sjpeg_hip_source* src, in
   ScanArgs a;
   int cls = 0;
   const bool piped = e->pipelined;
-  int rc = prepare_scan(e, src, width, height, yuv_mode, nframes, tables, st, &g, &a, &cls, multi, piped);
+  SegPlan plan;
+  int rc = prepare_scan(e, src, width, height, yuv_mode, nframes, tables, st, &g, &a, &cls, multi, piped,
+                        out_stride > 0 ? out_stride : 1, &plan);
   if (rc) return rc;
   hipStream_t hs = piped ? e->side : st;           // the stream of the stitch kernels and of what only they read
   size_t largest_header = header_size;
@@ -648,7 +692,7 @@ static int encode_scan_impl(sjpeg_hip_engine* e, const sjpeg_hip_source* src, in
   if (out_stride < largest_header + 2 + 64) {
     return fail(SJPEG_HIP_ECAPACITY, "out_stride " + std::to_string(out_stride) + " too small");
   }
-  const size_t ubuf_words = (static_cast<size_t>(g.nseg) * g.slot_words + kChunkWords + 3) & ~size_t(3);
+  const size_t ubuf_words = plan.ubuf_words;
   const uint32_t max_chunks = static_cast<uint32_t>((ubuf_words + kChunkWords - 1) / kChunkWords);
   if ((rc = e->seg_off.ensure(static_cast<size_t>(nframes) * (g.nseg + 1)))) return rc;
   if ((rc = e->ubuf.ensure(static_cast<size_t>(nframes) * ubuf_words))) return rc;
@@ -672,17 +716,23 @@ static int encode_scan_impl(sjpeg_hip_engine* e, const sjpeg_hip_source* src, in
   if (piped) {
     if (set == 1) {                                // the second set of what K1 writes and K2 / K3 read
       const size_t total_segs = static_cast<size_t>(nframes) * g.nseg;
-      if ((rc = e->seg_words2.ensure(total_segs * g.slot_words))) return rc;
+      if ((rc = e->seg_words2.ensure(total_segs * plan.slot_words))) return rc;
       if ((rc = e->seg_nbits2.ensure(total_segs))) return rc;
+      if ((rc = e->pool2.ensure(static_cast<size_t>(nframes) * plan.pool_words))) return rc;
+      if ((rc = e->pool_ctr2.ensure(static_cast<size_t>(nframes) * 2))) return rc;
+      if ((rc = e->seg_xbase2.ensure(total_segs))) return rc;
       a.seg_words = e->seg_words2.p; a.seg_nbits = e->seg_nbits2.p;
+      a.pool = e->pool2.p; a.pool_ctr = e->pool_ctr2.p; a.seg_xbase = e->seg_xbase2.p;
     }
     // this set was last read by the K3 of the call before the previous one
     if (e->k3_pending[set]) HIP_TRY(hipStreamWaitEvent(st, e->k3_done[set], 0));
   }
+  HIP_TRY(hipMemsetAsync(a.pool_ctr, 0, static_cast<size_t>(nframes) * 2 * sizeof(uint32_t), st));
   StitchArgs s;
   s.nseg = g.nseg; s.nframes = nframes;
   s.seg_nbits = a.seg_nbits; s.seg_off = e->seg_off.p;
-  s.seg_words = a.seg_words; s.slot_words = g.slot_words;
+  s.seg_words = a.seg_words; s.slot_words = plan.slot_words;
+  s.pool = a.pool; s.pool_words = plan.pool_words; s.seg_xbase = a.seg_xbase; s.pool_ctr = a.pool_ctr;
   s.ubuf = e->ubuf.p; s.ubuf_words = ubuf_words;
   s.chunk_ff = e->chunk_ff.p; s.chunk_off = e->chunk_off.p; s.max_chunks = max_chunks;
   s.header = e->header.p; s.header_size = static_cast<uint32_t>(header_size);
@@ -791,9 +841,11 @@ int sjpeg_hip_encode_band_src(sjpeg_hip_engine* e, const sjpeg_hip_source* src, 
   FrameGeo g;
   ScanArgs a;
   int cls = 0;
-  int rc = prepare_scan(e, src, width, height, yuv_mode, 1, tables, st, &g, &a, &cls);
+  SegPlan plan;
+  int rc = prepare_scan(e, src, width, height, yuv_mode, 1, tables, st, &g, &a, &cls, false, false, SIZE_MAX, &plan);
   if (rc) return rc;
   if (seg_begin < 0 || seg_end > g.nseg || seg_begin >= seg_end) return fail(SJPEG_HIP_EINVAL, "bad segment range");
+  HIP_TRY(hipMemsetAsync(a.pool_ctr, 0, 2 * sizeof(uint32_t), st));
   const int nloc = seg_end - seg_begin;
   const size_t need = sjpeg_hip_band_bound(width, height, yuv_mode, seg_begin, seg_end);
   if (cap_words < need) {
@@ -808,7 +860,8 @@ int sjpeg_hip_encode_band_src(sjpeg_hip_engine* e, const sjpeg_hip_source* src, 
   memset(&s, 0, sizeof(s));
   s.nseg = nloc; s.nframes = 1;
   s.seg_nbits = e->seg_nbits.p; s.seg_off = e->seg_off.p;
-  s.seg_words = e->seg_words.p; s.slot_words = g.slot_words;
+  s.seg_words = e->seg_words.p; s.slot_words = plan.slot_words;
+  s.pool = a.pool; s.pool_words = plan.pool_words; s.seg_xbase = a.seg_xbase; s.pool_ctr = a.pool_ctr;
   s.ubuf = d_words; s.ubuf_words = cap_words;
   s.chunk_ff = e->chunk_ff.p; s.max_chunks = max_chunks;
   s.total_bits_out = reinterpret_cast<unsigned long long*>(d_nbits);

@@ -276,6 +276,9 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
   int dc_val = 0;
   // some AC level of the block has more bits than the lean walk (P3) is provably in place for
   uint32_t unsafe = 0;
+  // the OR of the block's AC entries: what the test is made on -- kept with a replayed block, because
+  // the bound depends on the AC table of the pass that CODES it, not of the pass that quantized it
+  uint32_t any_ac = 0;
   // what a statistics pass keeps for the replay kind: the slot as P2 leaves it + masks + DC value
   uint4* const keep = (a.replay == nullptr) ? nullptr
       : reinterpret_cast<uint4*>(a.replay) + ((static_cast<size_t>(frame) * a.nseg + seg) * kScanThreads + tid) * 9;
@@ -285,7 +288,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
     const uint4 t = keep[8];
     nzq[0] = t.x & 0xffffu; nzq[1] = t.x >> 16; nzq[2] = t.y & 0xffffu; nzq[3] = t.y >> 16;
     dc_val = static_cast<int>(t.z);
-    unsafe = t.w;
+    any_ac = t.w;
   }
   if (!REPLAY) {
   // rows as packed int16 pairs, straight from the slot: p[r][c] = (s[r][2c], s[r][2c+1])
@@ -463,10 +466,9 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
     const int dc_mag = static_cast<int>(ent[0] & 0x7fffu);
     dc_val = (ent[0] & 0x8000u) ? -dc_mag : dc_mag;
     if (KIND == kKindEncode || KIND == kKindStats) {
-      uint32_t any = ent[0] & 0xffff0000u;         // (the DC entry is not an AC level)
+      any_ac = ent[0] & 0xffff0000u;               // (the DC entry is not an AC level)
 #pragma unroll
-      for (int i = 1; i < 32; ++i) any |= ent[i];
-      unsafe = (any & ldc[24 + tbl]) != 0u ? 1u : 0u;
+      for (int i = 1; i < 32; ++i) any_ac |= ent[i];
     }
   } else {
     // Trellis quantization (reference Encoder::TrellisQuantizeBlock + SearchBestPrev,
@@ -559,7 +561,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
         const uint32_t pos = (ci >> 12) & 63u;
         zzw[pos] = static_cast<uint16_t>((ci & 0x7ffu) | (((ci >> 11) & 1u) << 15));
         nzm |= 1ull << pos;
-        unsafe |= ((ci & 0x7ffu) & ldc[24 + tbl]) != 0u ? 1u : 0u;
+        any_ac |= ci & 0x7ffu;
       }
     } else {
 #pragma unroll
@@ -572,7 +574,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
   if (KIND == kKindStats && keep != nullptr) {   // leave the quantized block behind for the replay kind
 #pragma unroll
     for (int r = 0; r < 8; ++r) keep[r] = *reinterpret_cast<const uint4*>(slot + 16 * r);
-    keep[8] = make_uint4(nzq[0] | (nzq[1] << 16), nzq[2] | (nzq[3] << 16), static_cast<uint32_t>(dc_val), unsafe);
+    keep[8] = make_uint4(nzq[0] | (nzq[1] << 16), nzq[2] | (nzq[3] << 16), static_cast<uint32_t>(dc_val), any_ac);
   }
   }   // !REPLAY
   const uint32_t nz_lo = nzq[0] | (nzq[1] << 16), nz_hi = nzq[2] | (nzq[3] << 16);
@@ -640,6 +642,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
     dc_word = (((code & 0xffu) + n) << 24) | ((code >> 16) << n) | suffix;
   }
   // bit 29: the block takes the checked walk; bit 30: chroma tables (read by whoever codes a part of it)
+  unsafe = (any_ac & ldc[24 + tbl]) != 0u ? 1u : 0u;
   dc_word |= (unsafe << 29) | (static_cast<uint32_t>(tbl) << 30);
   tail[0] = nz_lo; tail[1] = nz_hi; tail[2] = dc_word;   // (the predictors live in tail[3])
 
@@ -737,101 +740,86 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
   }
 
   // the walk reads 16-bit entries and writes 32-bit words in the same slot: no type-based reordering
-  typedef uint16_t __attribute__((may_alias)) u16_alias;
   typedef uint32_t __attribute__((may_alias)) u32_alias;
-  constexpr int kEnd = 69;                         // "no more non-zeros": reads as a loaded frontier
-  constexpr uint32_t kNoSpill = 0xffffu;
-  uint32_t* const spill_wg = a.spill + (static_cast<size_t>(frame) * a.nseg + seg) * kScanThreads * kSpillWords;
+  constexpr uint32_t kNoRow = 0xffffffffu;
+  // this frame's pool (scan_device.h): the part of a segment that does not fit its slot, and the rows
+  // of the checked walk; one bump counter per frame, and a flag that says the frame overran it
+  uint32_t* const pool = a.pool + static_cast<size_t>(frame) * a.pool_words;
+  auto pool_take = [&](uint32_t nwords) -> uint32_t {          // word offset in the pool, kNoRow if it is full
+    const uint32_t at = atomicAdd(&a.pool_ctr[2 * frame], nwords);
+    if (at + nwords > a.pool_words) { atomicOr(&a.pool_ctr[2 * frame + 1], 1u); return kNoRow; }
+    return at;
+  };
 
-  // ONE walk codes a part.  The bits go, MSB-first, into the part's OWN quarter of the slot (8
-  // words over its 16 entries), over coefficients that were already consumed: word w replaces
-  // entries 2w and 2w + 1 and is only written once every entry up to 2w + 1 has been loaded.
-  // The rare word that would overtake the reader, or leave the quarter, goes to a global spill
-  // row instead, and so does everything after it.  The walk is software-pipelined by hand: the
-  // entry of the NEXT non-zero position and the Huffman word of the CURRENT one are in flight
-  // while the previous symbol is appended; unrolled by two with swapped roles so that an
-  // in-flight LDS value is never copied (a copy forces a wait).
-  auto walk = [&](uint32_t unit, unsigned long long m_all, uint32_t b_dc, uint32_t& len_out, uint32_t& spill_out) {
-    const int blk = static_cast<int>(unit & 255u), q = static_cast<int>(unit >> 8);
-    unsigned char* const bslot = smem + blk * kSlotBytes;
-    const int b_k = blk % BPM;
-    const int b_tbl = (MODE == SJPEG_HIP_YUV420) ? (b_k >= 4) : (MODE == SJPEG_HIP_YUV444 ? (b_k >= 1) : 0);
+  // The CHECKED walk codes the parts of a block with an AC level of more than n_safe bits (none in
+  // ordinary pictures; the q >= 97 noise tests).  Nothing bounds the bits such a part makes per
+  // entry, so it first reads its 16 entries into registers -- then every word up to the eighth can
+  // be stored over them in place -- and takes a row of 8 words from the frame's pool for words
+  // 8 .. 15 when it gets that far (a part is shorter than 496 bits).  A row is only taken by a part
+  // that has already produced 32 bytes, so the rows of a frame never add up to more than its
+  // output.  Plain and slow: picks an entry out of the registers by a chain of selects.
+  auto walk_checked = [&](uint32_t unit, uint4 bt, uint32_t& rec_out, uint32_t& row_out) {
+    const uint32_t blk = unit & 255u, q = unit >> 8;
+    const uint32_t b_tbl = (bt.z >> 30) & 1u;
     const uint32_t* const ac = lac + b_tbl * 256;
-    const u16_alias* const zz = reinterpret_cast<const u16_alias*>(bslot);   // bit 15 = negative, 14..0 = level
-    u32_alias* const bw = reinterpret_cast<u32_alias*>(bslot) + 8 * q;
-    uint32_t* const spill = spill_wg + blk * kSpillWords + 16 * q;
-    const uint32_t zrl = ac[0xf0], eob = ac[0x00];
-    const uint32_t zl = zrl & 0xffu;
-    const int sh = 16 * q;
-    uint32_t m = static_cast<uint32_t>(m_all >> sh) & 0xffffu;   // the part's own 16 positions
-    const unsigned long long below = m_all & ((1ull << sh) - 1ull);
-    const bool is_last = (q == 3) || ((m_all >> (sh + 16)) == 0ull);
-    int prev = below ? 64 - __builtin_clzll(below) : 1;       // position after the previous non-zero
-    unsigned long long acc = 0;                    // pending bits, right-aligned (upper bits stale)
-    uint32_t nacc = 0, wr = 0;                     // pending bit count (< 32), words produced
-    uint32_t wr_lim = 8;                           // words [0, wr_lim) may stay in the slot
-    const uint32_t wabs = 16u * static_cast<uint32_t>(q) + 1u;   // entry 2 * (8q + wr) + 1
-    auto next_pos = [&]() -> int { if (!m) return kEnd; const int i = __builtin_ctz(m); m &= m - 1; return sh + i; };
-    // branch-free but for the two predicated stores: most appends of a wave complete a word in
-    // some lane anyway
-    auto append = [&](uint32_t bits, uint32_t nb, int frontier) {   // 1 <= nb <= 31
-      acc = (acc << nb) | bits;
-      nacc += nb;
-      const bool full = nacc >= 32u;
-      nacc &= 31u;
-      const uint32_t word = static_cast<uint32_t>(acc >> nacc);
-      const bool in_place = (wr < wr_lim) & (2u * wr + wabs <= static_cast<uint32_t>(frontier));
-      if (full) {
-        if (in_place) bw[wr] = word; else spill[wr] = word;
+    const uint32_t wp0 = blk * kSlotBytes + 32u * q;
+    const uint4 e0 = *reinterpret_cast<const uint4*>(smem + wp0), e1 = *reinterpret_cast<const uint4*>(smem + wp0 + 16);
+    const uint32_t ent[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
+    const uint32_t lo = bt.x, hi = bt.y;
+    const uint32_t mw = (q & 2u) ? hi : lo;
+    uint32_t m = (q & 1u) ? (mw >> 16) : (mw & 0xffffu);
+    const uint32_t below_lo = q >= 2u ? lo : (q == 1u ? (lo & 0xffffu) : 0u);
+    const uint32_t below_hi = q == 3u ? (hi & 0xffffu) : 0u;
+    const uint32_t prev0 = below_hi ? 64u - __clz(below_hi) : 32u - __clz(below_lo | 1u);
+    const uint32_t above = q == 0u ? ((lo >> 16) | hi) : (q == 1u ? hi : (q == 2u ? (hi >> 16) : 0u));
+    int prevl = static_cast<int>(prev0) - static_cast<int>(16u * q);
+    uint32_t acc = 0, fill = 0, wr = 0, row = kNoRow;
+    bool lost = false;                             // the pool is full: the frame reports size 0 anyway
+    auto put_word = [&](uint32_t word) {
+      if (wr < 8u) {
+        *reinterpret_cast<u32_alias*>(smem + wp0 + 4u * wr) = word;
+      } else {
+        if (wr == 8u) { row = pool_take(8u); lost = (row == kNoRow); }
+        if (!lost) pool[row + wr - 8u] = word;
       }
-      wr_lim = (full & !in_place) ? (wr < wr_lim ? wr : wr_lim) : wr_lim;
-      wr += full ? 1u : 0u;
+      ++wr;
     };
-    // stage A of entry (iC, eC): indices + issue the table read (codeOut); fetch next entry;
-    // stage B of the symbol before it (sIn = n | zr << 8 | suffix << 16, codeIn in flight).
-    auto step = [&](int iC, uint32_t eC, int& iN, uint32_t& eN,
-                    uint32_t codeIn, uint32_t sIn, bool vIn, uint32_t& codeOut, uint32_t& sOut) {
-      iN = next_pos();
-      eN = zz[iN];
-      const uint32_t mag = eC & 0x7fffu;
-      const int run = iC - prev;
-      prev = iC + 1;
-      const uint32_t n = 32u - __clz(mag);
-      const uint32_t ones = (1u << n) - 1u;
-      const uint32_t suffix = (eC & 0x8000u) ? (mag ^ ones) : mag;      // negative: ~mag on n bits
-      codeOut = ac[((run & 15) << 4) | n];
-      sOut = n | ((static_cast<uint32_t>(run) >> 4) << 8) | (suffix << 16);
-      if (vIn) {
-        const uint32_t pn = sIn & 0xffu;
-        for (uint32_t z = (sIn >> 8) & 0xffu; z > 0; --z) append(zrl >> 16, zl, iN);
-        append(((codeIn >> 16) << pn) | (sIn >> 16), (codeIn & 0xffu) + pn, iN);
-      }
+    auto append = [&](uint32_t bits, uint32_t nb) {                  // 1 <= nb <= 31
+      const uint32_t t = fill + nb;
+      const uint32_t s5 = t & 31u;
+      const uint32_t P = __builtin_amdgcn_alignbit(bits, 0u, s5);
+      if (t >= 32u) { put_word(acc | (bits >> s5)); acc = P; } else { acc |= P; }
+      fill = s5;
     };
-    int iA = next_pos(), iB = kEnd;
-    uint32_t eA = zz[iA], eB = 0, cA = 0, cB = 0, sA = 0, sB = 0;
-    if (q == 0) append(b_dc & 0xffffffu, (b_dc >> 24) & 31u, iA);
-    bool pend = false;                             // a symbol waits for stage B (in cA/sA)
-    while (iA != kEnd) {
-      step(iA, eA, iB, eB, cA, sA, pend, cB, sB);
-      if (iB == kEnd) { cA = cB; sA = sB; pend = true; break; }
-      step(iB, eB, iA, eA, cB, sB, true, cA, sA);
-      pend = true;
+    if (q == 0u) append(bt.z & 0xffffffu, (bt.z >> 24) & 31u);
+    const uint32_t zrl = ac[0xf0];
+    while (m) {
+      const int i = __builtin_ctz(m);
+      m &= m - 1u;
+      uint32_t d = ent[0];
+#pragma unroll
+      for (int k = 1; k < 8; ++k) d = (i >> 1) == k ? ent[k] : d;
+      const uint32_t e = (i & 1) ? (d >> 16) : (d & 0xffffu);
+      int run = i - prevl;
+      prevl = i + 1;
+      for (; run >= 16; run -= 16) append(zrl >> 16, zrl & 0xffu);
+      const uint32_t mag = e & 0x7fffu;
+      const uint32_t n = 32u - static_cast<uint32_t>(__clz(mag));
+      const uint32_t suffix = (e & 0x8000u) ? (mag ^ ((1u << n) - 1u)) : mag;
+      const uint32_t cw = ac[(static_cast<uint32_t>(run) << 4) | n];
+      append(((cw >> 16) << n) | suffix, (cw & 0xffu) + n);
     }
-    if (pend) {
-      const uint32_t pn = sA & 0xffu;
-      for (uint32_t z = (sA >> 8) & 0xffu; z > 0; --z) append(zrl >> 16, zl, kEnd);
-      append(((cA >> 16) << pn) | (sA >> 16), (cA & 0xffu) + pn, kEnd);
-    }
-    if (is_last && prev <= 63) append(eob >> 16, eob & 0xffu, kEnd);   // last non-zero index < 63
-    const uint32_t len = 32u * wr + nacc;
-    if (nacc != 0u) append(0u, 32u - nacc, kEnd);                        // left-align the last word
+    if (above == 0u && prevl + static_cast<int>(16u * q) <= 63) { const uint32_t eob = ac[0x00]; append(eob >> 16, eob & 0xffu); }
+    const uint32_t len = 32u * wr + fill;
+    if (fill != 0u) put_word(acc);                 // the last word, left-aligned, goes where the others are
     ulen[4 * blk + q] = static_cast<uint16_t>(len);
-    len_out = len;
-    spill_out = wr > wr_lim ? wr_lim : kNoSpill;
+    // (spill field: 8 = words 8.. are in the pool row, 31 = all in place)
+    rec_out = unit | ((wr > 8u ? 8u : 31u) << 10) | (len << 17) | (b_tbl << 28);
+    row_out = row;
   };
 
   // The LEAN walk codes every part of a block whose AC levels have at most n_safe bits (all of them in
-  // ordinary pictures; DevTables::safe_mask).  It has no stage pipeline, no spill row and no
+  // ordinary pictures; DevTables::safe_mask).  It reads no entry ahead, takes no pool row and needs no
   // frontier test: a finished word is stored over the part's own entries unconditionally, because
   // under the level bound it can never reach an entry that is still to be read.  Proof: let T(i) be
   // the bits produced once the entry at local position i (0..15) is coded.  A symbol of run r makes
@@ -939,9 +927,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
     if (un[r] != 0xffffffffu) {
       uint32_t rec, tw = 0;
       if ((bts[r].z >> 29) & 1u) {
-        uint32_t len, wsp;
-        walk(un[r], (static_cast<unsigned long long>(bts[r].y) << 32) | bts[r].x, bts[r].z, len, wsp);
-        rec = un[r] | ((wsp & 31u) << 10) | (len << 17) | (((bts[r].z >> 30) & 1u) << 28);   // spill index 0..15, 31 = none
+        walk_checked(un[r], bts[r], rec, tw);      // (tw: the part's pool row)
       } else {
         walk_lean(un[r], bts[r], rec, tw);
       }
@@ -981,7 +967,18 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
   // Stitch: every part's words are shifted to its bit offset and ORed into the LDS window,
   // round by round (one round unless the segment overflows the window); the window is flushed
   // coalesced to the segment's slot.
+  // Where the segment's words go: the first slot_words of them into its own slot, the rest into
+  // the frame's pool (one bump allocation, now that the length is known).  Slots are sized from the
+  // caller's out_stride, not for the worst case: see scan_engine.hip.
   uint32_t* const out_words = a.seg_words + (static_cast<size_t>(frame) * a.nseg + seg) * a.slot_words;
+  {
+    const uint32_t nw_seg = (total + 31u) >> 5;
+    if (tid == 0) {
+      const uint32_t xb = nw_seg > a.slot_words ? pool_take(nw_seg - a.slot_words) : kNoRow;
+      misc[9] = xb;
+      a.seg_xbase[static_cast<size_t>(frame) * a.nseg + seg] = xb;
+    }
+  }
   uint32_t base = 0;                               // bit position of window word 0, multiple of 32
   uint32_t carry = 0;
   auto place = [&](uint32_t rec, uint32_t pos, uint32_t tailw) {   // pos: bit position in the window
@@ -1014,15 +1011,15 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
       if (o + (len & 31u) > 32u) atomicOr(reinterpret_cast<uint32_t*>(smem + dst + 4u), tailw << (32u - o));
       return;
     }
-    const uint32_t wr_spill = ((rec >> 10) & 31u) == 31u ? kNoSpill : ((rec >> 10) & 31u);
+    // checked walk: all words in memory, the first eight in the part's quarter, the rest in its pool row
     const u32_alias* const bw = reinterpret_cast<const u32_alias*>(smem + blk * kSlotBytes) + 8 * q;
-    const uint32_t* const spill = spill_wg + blk * kSpillWords + 16 * q;
+    const bool rowed = ((rec >> 10) & 31u) == 8u;
     const uint32_t nw = (len + 31u) >> 5;          // words of the part, the last one left-aligned
     uint32_t* const dst = win + (pos >> 5);
     uint32_t before = 0;
     for (uint32_t j = 0; j <= nw; ++j) {
       uint32_t v = 0;
-      if (j < nw) v = (j < wr_spill) ? bw[j] : spill[j];
+      if (j < nw) v = (j < 8u) ? bw[j] : ((rowed && tailw != kNoRow) ? pool[tailw + j - 8u] : 0u);
       if (j < nw || o != 0u) atomicOr(dst + j, __builtin_amdgcn_alignbit(before, v, o));
       before = v;
     }
@@ -1073,7 +1070,14 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
     const uint32_t filled = limit - base;          // bits valid in the window
     const bool last = (limit == total);
     const uint32_t nfull = last ? (filled + 31) >> 5 : filled >> 5;
-    for (uint32_t i = tid; i < nfull; i += kScanThreads) out_words[(base >> 5) + i] = win[i];
+    {
+      const uint32_t xb = misc[9];                 // (written before the barriers above)
+      for (uint32_t i = tid; i < nfull; i += kScanThreads) {
+        const uint32_t j = (base >> 5) + i;
+        if (j < a.slot_words) out_words[j] = win[i];
+        else if (xb != kNoRow) pool[xb + (j - a.slot_words)] = win[i];
+      }
+    }
     if (last) break;
     carry = win[filled >> 5];                      // partial word carried into the next window
     base += filled & ~31u;

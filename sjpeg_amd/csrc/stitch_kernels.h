@@ -8,8 +8,12 @@ struct StitchArgs {
   int nseg, nframes;
   const uint32_t* seg_nbits;
   unsigned long long* seg_off;       // [nframes][nseg+1]
-  const uint32_t* seg_words;
+  const uint32_t* seg_words;         // [nframes][nseg][slot_words]: the first slot_words words of every segment ...
   uint32_t slot_words;
+  const uint32_t* pool;              // [nframes][pool_words]: ... the rest of it at seg_xbase[frame][seg] (NULL: slots hold everything)
+  uint32_t pool_words;
+  const uint32_t* seg_xbase;
+  const uint32_t* pool_ctr;          // [nframes][2]: [1] != 0: the frame overran its pool (reports size 0)
   uint32_t* ubuf;                    // [nframes][ubuf_words] un-stuffed stream, MSB-first words
   size_t ubuf_words;
   uint32_t* chunk_ff;                // [nframes][max_chunks]
@@ -50,7 +54,9 @@ __global__ __launch_bounds__(kThreads) void scan_seg_offsets(const StitchArgs a)
   }
   // K3 accumulates the 0xFF counts of the chunks with atomics: clear the ones this frame uses
   const unsigned long long U = (running + 7) >> 3;
-  const uint32_t nchunks = static_cast<uint32_t>((U + kChunkBytes - 1) / kChunkBytes);
+  unsigned long long nch64 = (U + kChunkBytes - 1) / kChunkBytes;
+  if (nch64 > a.max_chunks) nch64 = a.max_chunks;             // (such a frame is not stitched: K3, K4)
+  const uint32_t nchunks = static_cast<uint32_t>(nch64);
   uint32_t* ff = a.chunk_ff + static_cast<size_t>(frame) * a.max_chunks;
   for (uint32_t i = threadIdx.x; i < nchunks; i += kThreads) ff[i] = 0;
 }
@@ -106,6 +112,18 @@ __global__ __launch_bounds__(kThreads) void place_segments(const StitchArgs a) {
   const unsigned long long b0 = off[sc0], b1 = off[sc0 + 1];
   const unsigned long long T = off[a.nseg];                 // total bits
   const unsigned long long U = (T + 7) >> 3;                // bytes incl. 1-bit padding
+  // a frame whose stream is longer than the scratch sized from out_stride cannot fit its output slot
+  // either; one that overran its pool has words missing: K4 reports size 0 for both, nothing to place
+  if (((U + 3) >> 2) + 1 > a.ubuf_words || (a.pool_ctr != nullptr && a.pool_ctr[2 * frame + 1] != 0u)) return;
+  // word i of segment sc: in its slot, or (the rare long segment) in the frame's pool
+  const uint32_t* const pool_f = a.pool == nullptr ? nullptr : a.pool + static_cast<size_t>(frame) * a.pool_words;
+  const uint32_t* const xbase_f = a.seg_xbase == nullptr ? nullptr : a.seg_xbase + static_cast<size_t>(frame) * a.nseg;
+  auto seg_word = [&](int sc, uint32_t i) -> uint32_t {
+    if (i < a.slot_words) return segw[static_cast<size_t>(sc) * a.slot_words + i];
+    if (xbase_f == nullptr) return 0u;
+    const uint32_t xb = xbase_f[sc];
+    return xb == 0xffffffffu ? 0u : pool_f[xb + (i - a.slot_words)];
+  };
   uint32_t* ub = a.ubuf + static_cast<size_t>(frame) * a.ubuf_words;
   uint32_t* cff = a.chunk_ff + static_cast<size_t>(frame) * a.max_chunks;
   const int lane = threadIdx.x & 63;
@@ -141,8 +159,7 @@ __global__ __launch_bounds__(kThreads) void place_segments(const StitchArgs a) {
           const unsigned long long avail = c_end - p;
           const int take = avail < static_cast<unsigned long long>(need) ? static_cast<int>(avail) : need;
           const uint32_t rr = static_cast<uint32_t>(p - c_beg);
-          const uint32_t* q = segw + static_cast<size_t>(sc) * a.slot_words + (rr >> 5);
-          const unsigned long long two = (static_cast<unsigned long long>(q[0]) << 32) | q[1];
+          const unsigned long long two = (static_cast<unsigned long long>(seg_word(sc, rr >> 5)) << 32) | seg_word(sc, (rr >> 5) + 1);
           const uint32_t bits = static_cast<uint32_t>((two << (rr & 31)) >> (64 - take));
           outw |= bits << (need - take);
           need -= take;
@@ -165,14 +182,26 @@ __global__ __launch_bounds__(kThreads) void place_segments(const StitchArgs a) {
     if (chunk == chunk0) ff_acc += ffs;
     else if (ffs != 0u) atomicAdd(&cff[chunk], ffs);
   };
+  // source words this wave reads: up to word `nwords` of its segment.  All inside the slot (every
+  // ordinary segment): the speculative loads are the data.  Otherwise every word goes through the
+  // slot / pool mapping (wave-uniform branch: the common path is the one without it).
+  const bool long_seg = ((len + lead + 31u) >> 5) + 2u > a.slot_words;
+  if (!long_seg) {
 #pragma unroll
-  for (int k = 0; k < kSpec; ++k) {
-    if (ibase + static_cast<uint32_t>(k) * kPlaceLanes < nwords) one(ibase + k * kPlaceLanes + lane, spec[k][0], spec[k][1]);
-  }
-  if (a.subs == 1u) {
-    for (uint32_t i0 = kSpec * kPlaceLanes; i0 < nwords; i0 += kPlaceLanes) {
+    for (int k = 0; k < kSpec; ++k) {
+      if (ibase + static_cast<uint32_t>(k) * kPlaceLanes < nwords) one(ibase + k * kPlaceLanes + lane, spec[k][0], spec[k][1]);
+    }
+    if (a.subs == 1u) {
+      for (uint32_t i0 = kSpec * kPlaceLanes; i0 < nwords; i0 += kPlaceLanes) {
+        const uint32_t i = i0 + lane;
+        one(i, src[i], src[i + 1]);
+      }
+    }
+  } else {
+    const uint32_t iend = a.subs == 1u ? nwords : min(nwords, ibase + kSpec * kPlaceLanes);
+    for (uint32_t i0 = ibase; i0 < iend; i0 += kPlaceLanes) {
       const uint32_t i = i0 + lane;
-      one(i, src[i], src[i + 1]);
+      one(i, seg_word(sc0, i), seg_word(sc0, i + 1));
     }
   }
   if (ff_chunk != 0xffffffffu) ff_flush();
@@ -186,7 +215,9 @@ __global__ __launch_bounds__(kThreads) void scan_chunk_offsets(const StitchArgs 
   const int frame = blockIdx.x;
   const unsigned long long T = a.seg_off[static_cast<size_t>(frame) * (a.nseg + 1) + a.nseg];
   const unsigned long long U = (T + 7) >> 3;
-  const uint32_t nchunks = static_cast<uint32_t>((U + kChunkBytes - 1) / kChunkBytes);
+  unsigned long long nch64 = (U + kChunkBytes - 1) / kChunkBytes;
+  if (nch64 > a.max_chunks) nch64 = a.max_chunks;             // (a frame longer than the scratch: size 0 below)
+  const uint32_t nchunks = static_cast<uint32_t>(nch64);
   const uint32_t* ff = a.chunk_ff + static_cast<size_t>(frame) * a.max_chunks;
   unsigned long long* co = a.chunk_off + static_cast<size_t>(frame) * a.max_chunks;
   unsigned long long running = 0;
@@ -203,7 +234,8 @@ __global__ __launch_bounds__(kThreads) void scan_chunk_offsets(const StitchArgs 
   const uint32_t hoff = a.hdr_off ? a.hdr_off[frame] : 0u;
   const uint32_t hsize = a.hdr_off ? a.hdr_off[frame + 1] - hoff : a.header_size;
   const unsigned long long size = hsize + body + (a.append_eoi ? 2 : 0);
-  const bool fits = size <= a.out_stride;
+  const bool fits = size <= a.out_stride && ((U + 3) >> 2) + 1 <= a.ubuf_words &&
+                    (a.pool_ctr == nullptr || a.pool_ctr[2 * frame + 1] == 0u);
   uint8_t* dst = a.out + static_cast<size_t>(frame) * a.out_stride;
   if (threadIdx.x == 0) {
     if (fits && a.append_eoi) {

@@ -895,3 +895,56 @@ def test_overlapped_steps_on_streams(engine):
         assert n.tolist() == want_sz.cpu().numpy().tolist(), s
         for k in range(nf):
             assert p[o[k]:o[k] + n[k]].tobytes() == bytes(want_out[k, :int(n[k])].cpu().numpy()), (s, k)
+
+
+def test_scratch_sized_from_out_stride(engine, oracle):
+    """The engine sizes its segment scratch from out_stride, not for the worst case: with a slot that is
+    just big enough, busy segments run over their segment slot into the frame's pool and the checked
+    walk takes its rows there -- same bytes as with worst-case scratch; one byte less and the frame
+    reports size 0 (never a truncated stream); a batch mixes frames that fit and frames that do not."""
+    cases = [(synth.g_noise(400, 304, 11), 99.0, 3), (synth.g_noise(640, 360, 12), 100.0, 1),
+             (synth.g_struct(1280, 720, 13), 75.0, 1), (synth.g_noise(97, 61, 14), 100.0, 4)]
+    for img, q, mode in cases:
+        h, w = img.shape[:2]
+        want = oracle.encode(img, q, mode)
+        t, quant = sj.make_tables(quality=q)
+        header = sj.make_header(w, h, mode, quant)
+        for slack in (0, 16, 4096):
+            stride = len(want) + slack
+            out, sizes = engine.encode_frames(dev(img), t, header, mode, out_stride=stride)
+            torch.cuda.synchronize()
+            assert int(sizes[0]) == len(want) and bytes(out[0, :len(want)].cpu().numpy()) == want, (w, h, q, slack)
+        out, sizes = engine.encode_frames(dev(img), t, header, mode, out_stride=len(want) - 1)
+        torch.cuda.synchronize()
+        assert int(sizes[0]) == 0
+    # a batch in which only the busy frames overrun the common slot
+    calm, busy = synth.g_struct(320, 240, 21), synth.g_noise(320, 240, 22)
+    t, quant = sj.make_tables(quality=97.0)
+    header = sj.make_header(320, 240, 1, quant)
+    want = [oracle.encode(calm, 97.0, 1), oracle.encode(busy, 97.0, 1)]
+    assert len(want[1]) > len(want[0]) + 64
+    stride = (len(want[0]) + 64 + 15) & ~15
+    frames = torch.from_numpy(np.stack([calm, busy, calm, busy, busy, calm])).cuda()
+    out, sizes = engine.encode_frames(frames, t, header, 1, out_stride=stride)
+    torch.cuda.synchronize()
+    sz = sizes.cpu().numpy().tolist()
+    assert sz == [len(want[0]), 0, len(want[0]), 0, 0, len(want[0])]
+    for k in (0, 2, 5):
+        assert bytes(out[k, :sz[k]].cpu().numpy()) == want[0]
+
+
+def test_replayed_blocks_are_classified_by_the_coding_tables(oracle):
+    """Methods 7 / 8 quantize in the statistics pass and replay the kept blocks in the encode pass, which
+    codes them with OPTIMISED tables: whether a block may take the lean walk depends on those tables,
+    not on the ones the statistics pass ran with (found by tools/gpu_soak.py: q >= 97, trellis)."""
+    rng = np.random.RandomState(77)
+    for (w, h, q, method, mode) in ((215, 279, 100.0, 7, 1), (331, 257, 97.0, 8, 1), (260, 190, 100.0, 8, 3),
+                                   (300, 200, 100.0, 4, 1), (180, 260, 97.0, 1, 3)):
+        for img in (rng.randint(0, 256, (h, w, 3)).astype(np.uint8), synth.g_struct(w, h, 5 + w)):
+            got = sj.SjpegEncode(img, q, method, mode)
+            assert got == oracle.encode_method(img, q, mode, method), (w, h, q, method, mode)
+    # the batch path replays too (sjpeg_hip_encode_batch_src, default parameters = method 4)
+    frames = np.stack([rng.randint(0, 256, (120, 160, 3)).astype(np.uint8) for _ in range(3)])
+    got = sj.encode_device_method(torch.from_numpy(frames).cuda(), 100.0, 1, 4)
+    for k in range(3):
+        assert got[k] == oracle.encode_method(frames[k], 100.0, 1, 4), k
