@@ -81,6 +81,19 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
     }
   };
 
+  // Does the segment (its halo MCU included) touch a clipped MCU?  Uniform.  Interior segments run
+  // a clamp-free copy of P1 and skip the AverageExtraLuma fix-up of P2 with its two barriers.
+  bool interior = true;
+  if (a.has_clip) {
+    const int mcu0c = m_first - halo, mcu1 = m_first + n_coded - 1;   // first and last processed MCU
+    const int my0c = mcu0c / a.mb_w;
+    const int my1 = mcu1 / a.mb_w, mx1 = mcu1 - my1 * a.mb_w;
+    const int mb_h = a.n_mcus / a.mb_w;
+    const bool clip_row = (a.H % PX) != 0 && my1 == mb_h - 1;
+    const bool clip_col = (a.W % PX) != 0 && (my1 > my0c || mx1 == a.mb_w - 1);
+    interior = !(clip_row || clip_col);
+  }
+
   // ---- P1: colour conversion, strips of 8 pixels (x2 rows for 4:2:0) --------------------
   // local MCU index ml: 0 = halo, 1..n_coded = coded MCUs; block slot = ml*BPM + k
   if (REPLAY) stage_tables();
@@ -123,15 +136,6 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
     // most segments otherwise) runs a copy of the loop that has no clamped-coordinate path at all:
     // that path's address arithmetic is hoisted in front of the loop by the compiler, and its mere
     // presence turns the pixel loads into branches.
-    bool interior = true;                                       // uniform
-    if (a.has_clip) {
-      const int mcu1 = m_first + n_coded - 1;                   // last processed MCU
-      const int my1 = mcu1 / a.mb_w, mx1 = mcu1 - my1 * a.mb_w;
-      const int mb_h = a.n_mcus / a.mb_w;
-      const bool clip_row = (a.H % PX) != 0 && my1 == mb_h - 1;
-      const bool clip_col = (a.W % PX) != 0 && (my1 > my0 || mx1 == a.mb_w - 1);
-      interior = !(clip_row || clip_col);
-    }
     auto convert = [&](auto interior_tag) {
     constexpr bool INTERIOR = decltype(interior_tag)::value;
     bool tables_staged = false;
@@ -300,7 +304,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
     p[r][0] = q.x; p[r][1] = q.y; p[r][2] = q.z; p[r][3] = q.w;
   }
 
-  if (MODE == SJPEG_HIP_YUV420 && a.has_clip) {
+  if (MODE == SJPEG_HIP_YUV420 && !interior) {
     // AverageExtraLuma (src/encoders.cc:107-125): luma blocks wholly outside the picture
     // become flat at (sum + 32) >> 6 of a neighbouring real block.
     int sum = 0;
