@@ -159,6 +159,17 @@ def run_config(sj, torch, eng, frames_np, tile, q, mode, want_md5, reps=10):
             "bit_exact": bool(ok)}
 
 
+def emit(res):
+    """The ONE JSON line, last on stdout: RCCL prints a version banner through C stdio, which would
+    otherwise be flushed behind it at exit."""
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    print(json.dumps(res), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -305,32 +316,7 @@ def main():
         if args.input == "struct":
             parity = parity and hashlib.md5(coded[0]).hexdigest() == digests["struct4k|420|q75|m0"]["md5"]
 
-    # ---- N > 1: the same steps with the exchange step of config #4 inside the timed region ----
-    with_gather = None
-    if exchange:
-        from sjpeg_amd.dist import exchange_loop
-        ids = list(range(rank, F * world, world))
-        try:
-            fence()
-            exchange_loop(2, encode, outs, sizes_b, ids, F * world, use_streams=True)        # warm-up (buffers, RCCL channels)
-            fence()
-            g0 = time.perf_counter()
-            got = exchange_loop(args.steps, encode, outs, sizes_b, ids, F * world, use_streams=True)
-            fence()
-            gdt = max_over_ranks(time.perf_counter() - g0)
-            ok = True
-            if rank == 0:                          # the last step's gathered streams, brought to the host and checked
-                fr = got[-1].frames()
-                ok = all(fr[k] == coded[k // world] for k in ids) and all(f is not None and f[:2] == b"\xff\xd8" for f in fr)
-                parity = parity and ok
-            with_gather = {"value": round(W * H * F * world * args.steps / gdt / 1e6, 1), "unit": "Mpixels/s",
-                           "ms_per_step": round(gdt / args.steps * 1e3, 4), "verified": bool(ok),
-                           "what": "encode + device-side packing (sjpeg_hip_compact_streams) + all_gather of sizes + "
-                                   "RCCL gather of the packed streams into rank 0's HBM, the exchange of step s "
-                                   "under the kernels of step s + 1; host copy / concatenation not included"}
-        except Exception as exc:                 # the exchange is outside the headline metric: report, do not lose the line
-            with_gather = {"error": repr(exc)}
-
+    res = {}
     if rank == 0:
         mpix = W * H * F * world * args.steps / dt / 1e6
         roof = {"bound": "hbm", "achieved": round(achieved / 1e9, 1), "peak": HBM_PEAK / 1e9,
@@ -371,8 +357,49 @@ def main():
         res["config"]["pipelined"] = bool(args.pipelined)
         if piped_scan_ms is not None:
             res["roofline"]["kernel_ms_pipelined"] = round(piped_scan_ms, 4)
-        if with_gather is not None:
+        if not parity:
+            res["value"] = 0.0
+            res["error"] = "output differs from the reference: throughput not counted"
+    # ---- N > 1: the same steps with the exchange step of config #4 inside a second timed region ----
+    # The headline line is complete at this point.  A watchdog prints it anyway if the exchange (RCCL
+    # on a node this code has not met before) does not come back: the metric must not be lost with it.
+    if exchange:
+        import threading
+        from sjpeg_amd.dist import exchange_loop
+
+        def give_up():
+            if rank == 0:
+                res["with_gather"] = {"error": "the exchange region did not finish within 240 s"}
+                emit(res)
+            os._exit(0)
+
+        dog = threading.Timer(240.0, give_up)
+        dog.daemon = True
+        dog.start()
+        ids = list(range(rank, F * world, world))
+        try:
+            fence()
+            exchange_loop(2, encode, outs, sizes_b, ids, F * world, use_streams=True, keep="last")   # warm-up (buffers, RCCL channels)
+            fence()
+            g0 = time.perf_counter()
+            got = exchange_loop(args.steps, encode, outs, sizes_b, ids, F * world, use_streams=True, keep="last")
+            fence()
+            gdt = max_over_ranks(time.perf_counter() - g0)
+            ok = True
+            if rank == 0:                          # the last step's gathered streams, brought to the host and checked
+                fr = got[-1].frames()
+                ok = all(fr[k] == coded[k // world] for k in ids) and all(f is not None and f[:2] == b"\xff\xd8" for f in fr)
+            with_gather = {"value": round(W * H * F * world * args.steps / gdt / 1e6, 1), "unit": "Mpixels/s",
+                           "ms_per_step": round(gdt / args.steps * 1e3, 4), "verified": bool(ok),
+                           "what": "encode + device-side packing (sjpeg_hip_compact_streams) + all_gather of sizes + "
+                                   "RCCL gather of the packed streams into rank 0's HBM, the exchange of step s "
+                                   "under the kernels of step s + 1; host copy / concatenation not included"}
+        except Exception as exc:                 # the exchange is outside the headline metric: report, do not lose the line
+            with_gather = {"error": repr(exc)}
+        dog.cancel()
+        if rank == 0:
             res["with_gather"] = with_gather
+    if rank == 0:
         if world == 1 and not args.no_other_configs:
             del frames
             torch.cuda.empty_cache()
@@ -403,10 +430,14 @@ def main():
             res["value"] = 0.0
             res["bit_exact"] = False
             res["error"] = "output differs from the reference: throughput not counted"
-        print(json.dumps(res), flush=True)
     if exchange:
-        dist.barrier()
-        dist.destroy_process_group()
+        try:
+            dist.barrier()
+            dist.destroy_process_group()
+        except Exception:
+            pass
+    if rank == 0:
+        emit(res)
 
 
 if __name__ == "__main__":

@@ -86,14 +86,20 @@ def gather_streams(out: torch.Tensor, sizes: torch.Tensor, frame_ids: Sequence[i
     return got.frames() if to_host else got
 
 
-def overlapped_steps(nsteps: int, encode, exchange, use_streams: bool):
+def overlapped_steps(nsteps: int, encode, exchange, use_streams: bool, keep: str = "all"):
     """The multi-rank step loop of bench.py: step s is coded into buffer set s & 1 while the streams
     of step s - 1 are exchanged.  encode(buf) enqueues one encode call into set `buf`;
     exchange(buf) runs the exchange of that set (it may block the host: the next encode is
     already queued).  With use_streams the exchange runs on a side CUDA stream ordered behind the
     encode by an event, so that it overlaps the next step's kernels; on CPU (gloo tests) the
-    same order of calls runs inline.  Returns the results of the exchanges, in step order."""
-    results = []
+    same order of calls runs inline.  Returns the results of the exchanges, in step order
+    (keep="last": only the last one -- a result holds the gathered buffers of a whole step)."""
+    class _Results(list):
+        def append(self, x):
+            if keep == "last":
+                self.clear()
+            super().append(x)
+    results = _Results()
     if use_streams:
         main = torch.cuda.current_stream()
         side = torch.cuda.Stream()
@@ -128,7 +134,7 @@ def overlapped_steps(nsteps: int, encode, exchange, use_streams: bool):
 
 
 def exchange_loop(nsteps: int, encode, outs, sizes, frame_ids: Sequence[int], nframes: int,
-                  use_streams: bool, dst: int = 0, group=None, compact=None):
+                  use_streams: bool, dst: int = 0, group=None, compact=None, keep: str = "all"):
     """bench.py's timed multi-rank region, as a function so that the CPU/gloo test runs exactly
     this code: `nsteps` encode calls, double buffered (outs[b], sizes[b], b = 0 / 1), the streams
     of every step gathered to `dst` (device resident there) under the next step's kernels.
@@ -137,7 +143,7 @@ def exchange_loop(nsteps: int, encode, outs, sizes, frame_ids: Sequence[int], nf
         nsteps, encode,
         lambda b: gather_streams(outs[b], sizes[b], frame_ids, nframes, dst=dst, group=group,
                                  compact=compact, to_host=False),
-        use_streams)
+        use_streams, keep)
 
 
 # ---- one frame over several GPUs: bands of consecutive segments -------------
