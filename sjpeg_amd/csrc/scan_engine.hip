@@ -86,7 +86,7 @@ bool frame_geo(int W, int H, int mode, FrameGeo* g) {
   g->mb_h = (H + g->px - 1) / g->px;
   g->n_mcus = g->mb_w * g->mb_h;
   g->nseg = (g->n_mcus + g->seg_mcus - 1) / g->seg_mcus;
-  g->slot_words = (static_cast<uint32_t>(g->seg_mcus) * g->bpm * kMaxBlockBits + 31) / 32 + 2;
+  g->slot_words = ((static_cast<uint32_t>(g->seg_mcus) * g->bpm * kMaxBlockBits + 31) / 32 + 2 + 3) & ~3u;   // (whole 16-byte units)
   return true;
 }
 

@@ -91,6 +91,8 @@ __device__ __forceinline__ uint32_t count_ff(uint32_t w, int nbytes /*valid lead
 // search; per group of segments) spent 35-50 us in chains of 3-5 dependent loads.
 constexpr int kSpec = 12;                                   // speculative batches of 64 words: segments up to 3 KiB
 constexpr int kPlaceLanes = 64;                             // one WAVE per segment, four segments per workgroup
+constexpr int kWideSpec = 3;                                // wide form: speculative batches of 256 words
+struct __attribute__((packed, aligned(4))) Words4 { uint32_t w[4]; };   // 16 bytes at any word address
 __global__ __launch_bounds__(kThreads) void place_segments(const StitchArgs a) {
   const int frame = blockIdx.y;
   // a wave takes words [sub * kSpec * 64, ...) of one segment; normal segments have one wave
@@ -102,12 +104,29 @@ __global__ __launch_bounds__(kThreads) void place_segments(const StitchArgs a) {
   const unsigned long long* off = a.seg_off + static_cast<size_t>(frame) * (a.nseg + 1);
   const uint32_t* segw = a.seg_words + static_cast<size_t>(frame) * a.nseg * a.slot_words;
   const uint32_t* src = segw + static_cast<size_t>(sc0) * a.slot_words;
+  // Two forms of the same loads.  WIDE (every ordinary call): a lane takes 4 consecutive words per batch
+  // of 256 -- one 16-byte load plus the word behind them -- so that a segment costs 6 load and 2-3
+  // store instructions instead of 24 and 11: with one dword per lane the kernel was bound by the
+  // number of memory instructions, not by bytes.  NARROW (bands cut into sub-ranges, slots that are
+  // not a multiple of 16 bytes): one word per lane.
+  const bool wide = a.subs == 1u && (a.slot_words & 3u) == 0u && a.slot_words >= 776u;      // uniform
   uint32_t spec[kSpec][2];
+  uint4 wq[kWideSpec];
+  uint32_t wx[kWideSpec];
+  if (wide) {
 #pragma unroll
-  for (int k = 0; k < kSpec; ++k) {                          // inside the slot whatever the length
-    const uint32_t i = min(ibase + k * kPlaceLanes + (threadIdx.x & 63), a.slot_words - 2u);
-    spec[k][0] = src[i];
-    spec[k][1] = src[i + 1];
+    for (int k = 0; k < kWideSpec; ++k) {                    // words 0 .. 771: inside the slot whatever the length
+      const uint32_t i = 256u * k + 4u * (threadIdx.x & 63);
+      wq[k] = *reinterpret_cast<const uint4*>(src + i);
+      wx[k] = src[i + 4];
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < kSpec; ++k) {                        // inside the slot whatever the length
+      const uint32_t i = min(ibase + k * kPlaceLanes + (threadIdx.x & 63), a.slot_words - 2u);
+      spec[k][0] = src[i];
+      spec[k][1] = src[i + 1];
+    }
   }
   const unsigned long long b0 = off[sc0], b1 = off[sc0 + 1];
   const unsigned long long T = off[a.nseg];                 // total bits
@@ -186,7 +205,52 @@ __global__ __launch_bounds__(kThreads) void place_segments(const StitchArgs a) {
   // ordinary segment): the speculative loads are the data.  Otherwise every word goes through the
   // slot / pool mapping (wave-uniform branch: the common path is the one without it).
   const bool long_seg = ((len + lead + 31u) >> 5) + 2u > a.slot_words;
-  if (!long_seg) {
+  if (!long_seg && wide) {
+    // destination words that lie entirely inside the segment: the funnel shift is all there is to them
+    const uint32_t n_int = len >= lead + 32u ? (len - lead) >> 5 : 0u;
+    auto batch = [&](uint32_t i0, uint4 q, uint32_t x) {     // destination words i0 .. i0 + 255, four per lane
+      const uint32_t i = i0 + 4u * lane;
+      const uint32_t v[5] = {q.x, q.y, q.z, q.w, x};
+      if (i0 + 256u <= n_int) {                              // (uniform)
+        Words4 o;
+        uint32_t ffs = 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          o.w[u] = lead ? __builtin_amdgcn_alignbit(v[u], v[u + 1], 32u - lead) : v[u];
+          ffs += static_cast<uint32_t>(__popc(ff_bytes(o.w[u])));
+        }
+        *reinterpret_cast<Words4*>(dst + i) = o;
+        const uint32_t c_lo = (wbase + i) >> 10, c_hi = (wbase + i + 3u) >> 10;
+        const uint32_t chunk0 = __builtin_amdgcn_readfirstlane(c_lo);
+        if (chunk0 != ff_chunk) {                            // uniform
+          if (ff_chunk != 0xffffffffu) ff_flush();
+          ff_chunk = chunk0;
+        }
+        if (c_lo == chunk0 && c_hi == chunk0) {
+          ff_acc += ffs;
+        } else if (ffs != 0u) {                              // the lane's words straddle a chunk boundary, or lie behind it
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const uint32_t f = static_cast<uint32_t>(__popc(ff_bytes(o.w[u])));
+            const uint32_t c = (wbase + i + u) >> 10;
+            if (f != 0u) { if (c == chunk0) ff_acc += f; else atomicAdd(&cff[c], f); }
+          }
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) one(i + u, v[u], v[u + 1]);
+      }
+    };
+#pragma unroll
+    for (int k = 0; k < kWideSpec; ++k) {
+      if (256u * k < nwords) batch(256u * k, wq[k], wx[k]);
+    }
+    for (uint32_t i0 = 256u * kWideSpec; i0 < nwords; i0 += 256u) {
+      // (words behind the segment's last one are never used: the index only has to stay inside the slot)
+      const uint32_t i = min(i0 + 4u * lane, (a.slot_words - 8u) & ~3u);
+      batch(i0, *reinterpret_cast<const uint4*>(src + i), src[i + 4]);
+    }
+  } else if (!long_seg) {
 #pragma unroll
     for (int k = 0; k < kSpec; ++k) {
       if (ibase + static_cast<uint32_t>(k) * kPlaceLanes < nwords) one(ibase + k * kPlaceLanes + lane, spec[k][0], spec[k][1]);
