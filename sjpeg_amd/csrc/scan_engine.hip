@@ -143,6 +143,10 @@ struct sjpeg_hip_engine {
   bool pipelined = false;
   hipStream_t side = nullptr;
   DevBuf<uint32_t> seg_words2, seg_nbits2, pool2, pool_ctr2, seg_xbase2;
+  // K4 leaves the pool counters of the frames it saw at zero, so an encode call only clears them
+  // itself when the previous user of the set did not get that far (or was larger / another buffer)
+  const void* ctr_clean_at[2] = {nullptr, nullptr};
+  size_t ctr_clean_n[2] = {0, 0};
   int set = 0;                                   // buffer set of the NEXT call
   hipEvent_t k1_done = nullptr, side_done = nullptr, k3_done[2] = {nullptr, nullptr};
   bool k3_pending[2] = {false, false}, side_pending = false;
@@ -727,7 +731,10 @@ static int encode_scan_impl(sjpeg_hip_engine* e, const sjpeg_hip_source* src, in
     // this set was last read by the K3 of the call before the previous one
     if (e->k3_pending[set]) HIP_TRY(hipStreamWaitEvent(st, e->k3_done[set], 0));
   }
-  HIP_TRY(hipMemsetAsync(a.pool_ctr, 0, static_cast<size_t>(nframes) * 2 * sizeof(uint32_t), st));
+  if (e->ctr_clean_at[set] != a.pool_ctr || e->ctr_clean_n[set] < static_cast<size_t>(nframes)) {
+    HIP_TRY(hipMemsetAsync(a.pool_ctr, 0, static_cast<size_t>(nframes) * 2 * sizeof(uint32_t), st));
+  }
+  e->ctr_clean_at[set] = nullptr;                  // dirty from K1 on, until this call's K4 is in the queue
   StitchArgs s;
   s.nseg = g.nseg; s.nframes = nframes;
   s.seg_nbits = a.seg_nbits; s.seg_off = e->seg_off.p;
@@ -771,13 +778,14 @@ static int encode_scan_impl(sjpeg_hip_engine* e, const sjpeg_hip_source* src, in
   if (gx > max_chunks) gx = max_chunks;
   hipLaunchKernelGGL(place_segments, dim3((g.nseg + 3) / 4, nframes), dim3(kThreads), 0, hs, s);
   HIP_TRY(hipGetLastError());
-  if (piped) {
+  hipLaunchKernelGGL(scan_chunk_offsets, dim3(nframes), dim3(kThreads), 0, hs, s);
+  HIP_TRY(hipGetLastError());
+  e->ctr_clean_at[set] = a.pool_ctr; e->ctr_clean_n[set] = static_cast<size_t>(nframes);
+  if (piped) {                                     // (K4 is the last reader of this set: it looks at the pool's overrun flag)
     HIP_TRY(hipEventRecord(e->k3_done[set], hs));
     e->k3_pending[set] = true;
     e->set = set ^ 1;
   }
-  hipLaunchKernelGGL(scan_chunk_offsets, dim3(nframes), dim3(kThreads), 0, hs, s);
-  HIP_TRY(hipGetLastError());
   hipLaunchKernelGGL(stuff_chunks, dim3(gx, nframes), dim3(kThreads), 0, hs, s);
   HIP_TRY(hipGetLastError());
   if (piped) {
@@ -846,6 +854,7 @@ int sjpeg_hip_encode_band_src(sjpeg_hip_engine* e, const sjpeg_hip_source* src, 
   if (rc) return rc;
   if (seg_begin < 0 || seg_end > g.nseg || seg_begin >= seg_end) return fail(SJPEG_HIP_EINVAL, "bad segment range");
   HIP_TRY(hipMemsetAsync(a.pool_ctr, 0, 2 * sizeof(uint32_t), st));
+  e->ctr_clean_at[0] = nullptr;                    // (no K4 in this path)
   const int nloc = seg_end - seg_begin;
   const size_t need = sjpeg_hip_band_bound(width, height, yuv_mode, seg_begin, seg_end);
   if (cap_words < need) {

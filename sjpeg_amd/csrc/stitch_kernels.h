@@ -300,6 +300,12 @@ __global__ __launch_bounds__(kThreads) void scan_chunk_offsets(const StitchArgs 
   const unsigned long long size = hsize + body + (a.append_eoi ? 2 : 0);
   const bool fits = size <= a.out_stride && ((U + 3) >> 2) + 1 <= a.ubuf_words &&
                     (a.pool_ctr == nullptr || a.pool_ctr[2 * frame + 1] == 0u);
+  // last reader of the frame's pool counters: leave them at zero for the next call (scan_engine.hip)
+  __syncthreads();
+  if (a.pool_ctr != nullptr && threadIdx.x == 0) {
+    const_cast<uint32_t*>(a.pool_ctr)[2 * frame] = 0u;
+    const_cast<uint32_t*>(a.pool_ctr)[2 * frame + 1] = 0u;
+  }
   uint8_t* dst = a.out + static_cast<size_t>(frame) * a.out_stride;
   if (threadIdx.x == 0) {
     if (fits && a.append_eoi) {
