@@ -144,7 +144,11 @@ size_t sjpeg_hip_frame_bound(int width, int height, int yuv_mode, size_t header_
  *                 written by the host exactly like src/headers.cc); may be NULL/0, in which
  *                 case each stream starts directly with entropy data.
  *   append_eoi    non-zero: terminate each stream with FF D9 (src/headers.cc:262-268).
- *   d_out         device buffer, nframes*out_stride bytes, out_stride >= frame_bound.
+ *   d_out         device buffer, nframes*out_stride bytes.  out_stride >= frame_bound always
+ *                 suffices; a smaller slot is legal (the engine's scratch is sized from it, about
+ *                 3.5 x out_stride per frame instead of the worst case of the geometry): a frame
+ *                 whose stream does not fit its slot reports d_sizes[f] = 0 and is not written,
+ *                 the other frames of the batch are unaffected.
  *   d_sizes       device array of nframes uint64.
  *   stream        hipStream_t (as void*) on which everything is enqueued; NULL = default
  *                 stream.  The call is asynchronous: results are valid once the stream
