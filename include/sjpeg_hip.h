@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SJPEG_HIP_ABI_VERSION 12
+#define SJPEG_HIP_ABI_VERSION 13
 
 enum {
   SJPEG_HIP_OK = 0,
@@ -78,6 +78,15 @@ typedef struct sjpeg_hip_scan_tables {
  * where quantization is expensive: the host API uses it for the trellis methods. */
 #define SJPEG_HIP_QUANT_KEEP 2u
 #define SJPEG_HIP_QUANT_REPLAY 4u
+/* OPTIONAL restart-marker mode (encode calls).  NOT the reference's bytes -- it never writes DRI / RSTn
+ * (src/sjpegi.h:68-74) -- but the same picture: same tables, same coefficients, identical pixels
+ * after decoding.  Every segment of the engine (sjpeg_hip_restart_interval() MCUs) becomes a restart
+ * interval: its bits padded to a byte with 1-bits, RSTn (FF D0+(n & 7)) behind it, DC predictors
+ * reset (ITU-T T.81 B.2.4.4 / F.1.2.3).  The header passed to the call must carry the DRI segment:
+ * sjpeg_hip_header_add_restart().  What it is for: intervals are independently decodable and byte
+ * aligned, so a frame's intervals can be produced on different devices and concatenated by the host
+ * with no bit-level stitch. */
+#define SJPEG_HIP_RESTART_MARKERS 8u
 
 /* Pixel sources.  Packed colour and gray use plane[0]; planar YUV uses Y, U, V; NV12/NV21 use
  * Y and the interleaved chroma plane in plane[1].  Chroma planes of the 4:2:0 layouts are
@@ -399,6 +408,24 @@ typedef struct sjpeg_hip_metadata {
 size_t sjpeg_hip_make_header_meta(int width, int height, int yuv_mode, const uint8_t quant[2][64],
                                   const sjpeg_hip_huffman_spec* specs,
                                   const sjpeg_hip_metadata* meta, uint8_t* buf, size_t cap);
+
+/* Restart mode (SJPEG_HIP_RESTART_MARKERS): MCUs per restart interval for a colour mode (41 / 84 / 255),
+ * and the DRI segment (FF DD 00 04 Ri) inserted in front of the SOS segment of a header made by any of
+ * the builders above (in place; returns the new size, 0 if cap < size + 6 or no SOS is found). */
+int sjpeg_hip_restart_interval(int yuv_mode);
+size_t sjpeg_hip_header_add_restart(uint8_t* header, size_t size, size_t cap, int yuv_mode);
+
+/* Restart mode, one frame over several devices: codes the restart intervals [seg_begin, seg_end) of the
+ * frame (segments as counted by sjpeg_hip_segment_count()) into d_out: stuffed entropy bytes, RSTn
+ * between the intervals AND behind the last one unless it is the frame's last; no header, no EOI.
+ * Intervals are byte aligned and self-contained, so the file is
+ *   header with DRI | bytes of band 0 | bytes of band 1 | ... | FF D9
+ * put together by plain concatenation (host or device) in band order -- the "segmented at restart
+ * markers, gathered, concatenated" form; bit-identical to the one-device restart-mode stream.
+ * tables->flags must carry SJPEG_HIP_RESTART_MARKERS.  A band that does not fit out_cap reports size 0. */
+int sjpeg_hip_encode_intervals_src(sjpeg_hip_engine* engine, const sjpeg_hip_source* src, int width, int height,
+                                   int yuv_mode, const sjpeg_hip_scan_tables* tables, int seg_begin, int seg_end,
+                                   void* d_out, size_t out_cap, uint64_t* d_size, void* stream);
 
 /* Exchange step of the multi-device batch path (BASELINE.json config #4; the reference runs on one
  * thread and has no counterpart): packs the `nframes` coded streams an encode call left at

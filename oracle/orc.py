@@ -49,6 +49,9 @@ class Oracle:
         if not os.path.exists(ORC_SO):
             build()
         self.lib = lib = C.CDLL(ORC_SO, mode=os.RTLD_LOCAL | os.RTLD_NOW)
+        lib.orc_encode_rst.restype = C.c_size_t
+        lib.orc_encode_rst.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int,
+                                       C.POINTER(_u8p)]
         lib.orc_encode.restype = C.c_size_t
         lib.orc_encode.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int,
                                    C.POINTER(_u8p)]
@@ -133,6 +136,13 @@ class Oracle:
         rgb, w, h, stride = self._img(rgb, stride)
         out = _u8p()
         n = self.lib.orc_encode(rgb.ctypes.data, w, h, stride, quality, yuv_mode, C.byref(out))
+        return self._take(n, out)
+
+    def encode_rst(self, rgb, quality=75.0, yuv_mode=YUV_420, ri=41, stride=None):
+        """Restart-marker variant (not the reference's bytes; see sjpeg_oracle.c)."""
+        rgb, w, h, stride = self._img(rgb, stride)
+        out = _u8p()
+        n = self.lib.orc_encode_rst(rgb.ctypes.data, w, h, stride, quality, yuv_mode, ri, C.byref(out))
         return self._take(n, out)
 
     def encode_method(self, rgb, quality=75.0, yuv_mode=YUV_420, method=0, stride=None):

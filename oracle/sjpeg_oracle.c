@@ -1002,6 +1002,66 @@ size_t orc_encode_matrices(const uint8_t* rgb, int W, int H, int stride,
   return w.size;
 }
 
+/* ---------------------------------------------------------------- restart-marker variant
+ * NOT the reference's output (it never writes DRI / RSTn, src/sjpegi.h:68-74): the same picture,
+ * same tables, same coefficients, with the scan cut every `ri` MCUs the way ITU-T T.81 section B.2.4.4 /
+ * F.1.2.3 and libjpeg do it: the interval's bits padded to a byte with 1-bits (stuffed like any
+ * other byte), marker FF D0+(n & 7), DC predictors back to zero.  A DRI segment (FF DD 00 04 Ri)
+ * stands in front of SOS.  Used to check the GPU's optional restart mode byte for byte; that it
+ * decodes to the same pixels as the exact stream is checked with an independent decoder (tests). */
+size_t orc_encode_rst(const uint8_t* rgb, int W, int H, int stride, float quality, int yuv_mode,
+                      int ri, uint8_t** out) {
+  orc_scan s;
+  uint8_t m[2][64];
+  *out = NULL;
+  if (rgb == NULL || abs(stride) < 3 * W || ri <= 0 || ri > 65535) return 0;
+  orc_quality_matrices(quality, m);
+  if (!scan_init(&s, W, H, yuv_mode, m, NULL, 0x78)) return 0;
+  uint32_t dc[2][12], ac[2][256];
+  orc_default_codes(dc, ac);
+  orc_bw w, hdr;
+  memset(&w, 0, sizeof(w));
+  memset(&hdr, 0, sizeof(hdr));
+  write_headers(&hdr, &s, yuv_mode);
+  /* DRI in front of the SOS segment (the last FF DA of the header) */
+  size_t sos = hdr.size;
+  while (sos >= 2 && !(hdr.buf[sos - 2] == 0xff && hdr.buf[sos - 1] == 0xda)) --sos;
+  sos -= 2;
+  bw_raw(&w, hdr.buf, sos);
+  put16(&w, 0xffdd); put16(&w, 4); put16(&w, ri);
+  bw_raw(&w, hdr.buf + sos, hdr.size - sos);
+  free(hdr.buf);
+  const orc_source S = rgb_source(rgb, stride);
+  int pred[3] = {0, 0, 0};
+  int16_t in[6 * 64], zz[64];
+  int count = 0, nrst = 0;
+  const int n_mcus = s.mb_w * s.mb_h;
+  for (int my = 0; my < s.mb_h; ++my) {
+    for (int mx = 0; mx < s.mb_w; ++mx) {
+      orc_get_samples_src(&S, yuv_mode, s.W, s.H, mx, my, in);
+      orc_fdct(in, s.L.mcu_blocks);
+      const int16_t* blk = in;
+      for (int c = 0; c < s.L.nb_comps; ++c) {
+        const int t = s.L.quant_idx[c];
+        for (int i = 0; i < s.L.nb_blocks[c]; ++i, blk += 64) {
+          scan_quantize(&s, blk, t, zz);
+          code_block(&w, zz, &pred[c], dc[t], ac[t]);
+        }
+      }
+      ++count;
+      if (count % ri == 0 && count < n_mcus) {
+        bw_pad(&w);
+        bw_byte(&w, 0xff); bw_byte(&w, (uint8_t)(0xd0 + (nrst++ & 7)));
+        pred[0] = pred[1] = pred[2] = 0;
+      }
+    }
+  }
+  bw_pad(&w);
+  put16(&w, 0xffd9);
+  *out = w.buf;
+  return w.size;
+}
+
 size_t orc_encode(const uint8_t* rgb, int W, int H, int stride, float quality,
                   int yuv_mode, uint8_t** out) {
   uint8_t m[2][64];

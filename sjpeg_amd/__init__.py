@@ -36,6 +36,7 @@ class ScanTables(C.Structure):
 QUANT_TRELLIS = 1
 QUANT_KEEP = 2
 QUANT_REPLAY = 4
+RESTART_MARKERS = 8      # optional restart-marker mode (sjpeg_hip.h): not the reference's bytes, the same pixels
 
 
 SRC_RGB, SRC_BGRA, SRC_RGBA, SRC_GRAY, SRC_YUV444, SRC_YUV420, SRC_NV12, SRC_NV21 = range(8)
@@ -253,7 +254,24 @@ EXPORTED_C_SYMBOLS = [
     "sjpeg_hip_engine_set_timing", "sjpeg_hip_engine_last_scan_ms",
     "sjpeg_hip_engine_last_total_ms", "sjpeg_hip_engine_scratch_bytes", "sjpeg_hip_compact_streams",
     "sjpeg_hip_debug_stream_read", "sjpeg_hip_debug_valu_rate",
+    "sjpeg_hip_restart_interval", "sjpeg_hip_header_add_restart", "sjpeg_hip_encode_intervals_src",
 ]
+
+
+def restart_interval(yuv_mode: int) -> int:
+    """MCUs per restart interval of the optional restart mode (41 / 84 / 255)."""
+    return int(lib().sjpeg_hip_restart_interval(int(yuv_mode)))
+
+
+def header_add_restart(header: bytes, yuv_mode: int) -> bytes:
+    """The header with the DRI segment of the restart mode in front of SOS."""
+    buf = (C.c_uint8 * (len(header) + 6)).from_buffer_copy(header + b"\0" * 6)
+    f = lib().sjpeg_hip_header_add_restart
+    f.restype = C.c_size_t
+    n = f(buf, C.c_size_t(len(header)), C.c_size_t(len(header) + 6), int(yuv_mode))
+    if n == 0:
+        raise SjpegError("sjpeg_hip_header_add_restart failed")
+    return bytes(buf[:n])
 
 
 def compact_streams(out, sizes, nframes=None, capacity=None, packed=None, offsets=None):
@@ -652,6 +670,22 @@ class Engine:
                                                   nbits.data_ptr(), self._stream()),
                   "sjpeg_hip_encode_band_src")
         return words, nbits
+
+    def encode_intervals(self, src: Source, w, h, tables: ScanTables, yuv_mode, seg_begin, seg_end,
+                         out_cap=None, device="cuda"):
+        """Restart mode: the restart intervals [seg_begin, seg_end) of one frame as stuffed bytes with
+        their RSTn markers (sjpeg_hip_encode_intervals_src).  Returns (out uint8 [out_cap], size int64 [1])."""
+        import torch
+        if out_cap is None:
+            out_cap = 4 * band_bound(w, h, yuv_mode, seg_begin, seg_end) * 2 + 4096
+        out = torch.empty(int(out_cap), dtype=torch.uint8, device=device)
+        size = torch.zeros(1, dtype=torch.int64, device=device)
+        self._chk(lib().sjpeg_hip_encode_intervals_src(self._h, C.byref(src), w, h, yuv_mode, C.byref(tables),
+                                                       seg_begin, seg_end, C.c_void_p(out.data_ptr()),
+                                                       C.c_size_t(int(out_cap)), C.c_void_p(size.data_ptr()),
+                                                       self._stream()),
+                  "sjpeg_hip_encode_intervals_src")
+        return out, size
 
     def stitch_bands(self, words, nbits, header: bytes, append_eoi=True, out_cap=None):
         """words [nbands, stride] int32, nbits [nbands] int64 (this engine's device) -> JPEG bytes."""

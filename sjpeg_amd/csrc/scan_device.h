@@ -59,6 +59,7 @@ struct ScanArgs {
   int cstep, uoff, voff;        // kSrcPlanes: bytes per chroma sample (2 = interleaved) and U/V offsets
   int W, H, mb_w, n_mcus, nseg, has_clip;
   int seg_first;                // band mode: frame-level index of this launch's segment 0
+  int rst;                      // restart mode: segments are restart intervals (SJPEG_HIP_RESTART_MARKERS)
   const DevTables* tables;
   int tables_stride;            // 0: every frame uses tables[0]; 1: frame f uses tables[f]
   uint32_t* seg_words;     // [nframes*nseg][slot_words]: the first slot_words words of every segment

@@ -372,6 +372,7 @@ int prepare_scan(sjpeg_hip_engine* e, const sjpeg_hip_source* src,
   }
   a->W = W; a->H = H; a->mb_w = g->mb_w; a->n_mcus = g->n_mcus; a->nseg = g->nseg;
   a->seg_first = 0;
+  a->rst = (tables->flags & SJPEG_HIP_RESTART_MARKERS) ? 1 : 0;
   a->has_clip = (W % g->px != 0) || (H % g->px != 0);
   a->tables = e->tables.p;
   a->tables_stride = per_frame_tables ? 1 : 0;
@@ -660,7 +661,7 @@ static int encode_scan_impl(sjpeg_hip_engine* e, const sjpeg_hip_source* src, in
                             int yuv_mode, int nframes, const sjpeg_hip_scan_tables* tables,
                             const void* header, size_t header_size, const size_t* header_offsets,
                             int append_eoi, void* d_out, size_t out_stride, uint64_t* d_sizes,
-                            void* stream) {
+                            void* stream, const int* seg_range = nullptr /* restart mode: code only these segments */) {
   if (e == nullptr) return fail(SJPEG_HIP_EINVAL, "engine == NULL");
   if (d_out == nullptr || d_sizes == nullptr) return fail(SJPEG_HIP_EINVAL, "d_out/d_sizes == NULL");
   if (header == nullptr) header_size = 0;
@@ -674,11 +675,23 @@ static int encode_scan_impl(sjpeg_hip_engine* e, const sjpeg_hip_source* src, in
   int rc = prepare_scan(e, src, width, height, yuv_mode, nframes, tables, st, &g, &a, &cls, multi, piped,
                         out_stride > 0 ? out_stride : 1, &plan);
   if (rc) return rc;
+  int rst_tail = 0;
+  if (seg_range != nullptr) {                      // a band of restart intervals: segments [begin, end) of the one frame
+    if (nframes != 1 || multi || !a.rst) return fail(SJPEG_HIP_EINVAL, "a segment range needs one frame in restart mode");
+    if (seg_range[0] < 0 || seg_range[1] > g.nseg || seg_range[0] >= seg_range[1]) return fail(SJPEG_HIP_EINVAL, "bad segment range");
+    rst_tail = seg_range[1] < g.nseg ? 1 : 0;
+    a.seg_first = seg_range[0];
+    a.nseg = seg_range[1] - seg_range[0];
+    g.nseg = a.nseg;                               // (everything below works on the band)
+  }
   hipStream_t hs = piped ? e->side : st;           // the stream of the stitch kernels and of what only they read
   size_t largest_header = header_size;
   if (multi) {
     if (tables->flags & SJPEG_HIP_QUANT_REPLAY) {
       for (int f = 1; f < nframes; ++f) if (!(tables[f].flags & SJPEG_HIP_QUANT_REPLAY)) return fail(SJPEG_HIP_EINVAL, "flags must agree between the frames' tables");
+    }
+    for (int f = 1; f < nframes; ++f) {
+      if ((tables[f].flags ^ tables->flags) & SJPEG_HIP_RESTART_MARKERS) return fail(SJPEG_HIP_EINVAL, "flags must agree between the frames' tables");
     }
     largest_header = 0;
     std::vector<uint32_t> offs(static_cast<size_t>(nframes) + 1);
@@ -748,6 +761,7 @@ static int encode_scan_impl(sjpeg_hip_engine* e, const sjpeg_hip_source* src, in
   s.sizes = reinterpret_cast<unsigned long long*>(d_sizes);
   s.seg_nbits64 = nullptr; s.total_bits_out = nullptr; s.subs = 1;
   s.hdr_off = multi ? e->hdr_off.p : nullptr;
+  s.seg_first = a.seg_first; s.rst_tail = rst_tail;
 
   if (e->timing) HIP_TRY(hipEventRecord(e->ev[0], st));
   if (tables->flags & SJPEG_HIP_QUANT_REPLAY) {
@@ -788,6 +802,10 @@ static int encode_scan_impl(sjpeg_hip_engine* e, const sjpeg_hip_source* src, in
   }
   hipLaunchKernelGGL(stuff_chunks, dim3(gx, nframes), dim3(kThreads), 0, hs, s);
   HIP_TRY(hipGetLastError());
+  if (a.rst && g.nseg - 1 + rst_tail > 0) {
+    hipLaunchKernelGGL(patch_restart_markers, dim3((g.nseg - 1 + rst_tail + 3) / 4, nframes), dim3(kThreads), 0, hs, s);
+    HIP_TRY(hipGetLastError());
+  }
   if (piped) {
     HIP_TRY(hipEventRecord(e->side_done, hs));
     e->side_pending = true;
@@ -805,6 +823,17 @@ int sjpeg_hip_encode_scan_src(sjpeg_hip_engine* e, const sjpeg_hip_source* src, 
                               size_t out_stride, uint64_t* d_sizes, void* stream) {
   return encode_scan_impl(e, src, width, height, yuv_mode, nframes, tables, header, header_size, nullptr,
                           append_eoi, d_out, out_stride, d_sizes, stream);
+}
+
+int sjpeg_hip_encode_intervals_src(sjpeg_hip_engine* e, const sjpeg_hip_source* src, int width, int height,
+                                   int yuv_mode, const sjpeg_hip_scan_tables* tables, int seg_begin, int seg_end,
+                                   void* d_out, size_t out_cap, uint64_t* d_size, void* stream) {
+  if (tables == nullptr || !(tables->flags & SJPEG_HIP_RESTART_MARKERS)) {
+    return fail(SJPEG_HIP_EINVAL, "sjpeg_hip_encode_intervals_src needs tables with SJPEG_HIP_RESTART_MARKERS");
+  }
+  const int range[2] = {seg_begin, seg_end};
+  return encode_scan_impl(e, src, width, height, yuv_mode, 1, tables, nullptr, 0, nullptr, /*append_eoi=*/0,
+                          d_out, out_cap, d_size, stream, range);
 }
 
 int sjpeg_hip_encode_scan_multi(sjpeg_hip_engine* e, const sjpeg_hip_source* src, int width, int height,
@@ -833,6 +862,28 @@ int sjpeg_hip_segment_count(int width, int height, int yuv_mode) {
   return g.nseg;
 }
 
+int sjpeg_hip_restart_interval(int yuv_mode) {
+  switch (yuv_mode) {
+    case SJPEG_HIP_YUV420: return Geo<SJPEG_HIP_YUV420>::kSegMcus;
+    case SJPEG_HIP_YUV444: return Geo<SJPEG_HIP_YUV444>::kSegMcus;
+    case SJPEG_HIP_YUV400: return Geo<SJPEG_HIP_YUV400>::kSegMcus;
+    default: return 0;
+  }
+}
+
+size_t sjpeg_hip_header_add_restart(uint8_t* header, size_t size, size_t cap, int yuv_mode) {
+  const int ri = sjpeg_hip_restart_interval(yuv_mode);
+  if (header == nullptr || ri == 0 || size < 4 || cap < size + 6) return 0;
+  size_t sos = size;                               // the SOS segment: the last FF DA of the header
+  while (sos >= 2 && !(header[sos - 2] == 0xff && header[sos - 1] == 0xda)) --sos;
+  if (sos < 2) return 0;
+  sos -= 2;
+  memmove(header + sos + 6, header + sos, size - sos);
+  const uint8_t dri[6] = {0xff, 0xdd, 0x00, 0x04, static_cast<uint8_t>(ri >> 8), static_cast<uint8_t>(ri)};
+  memcpy(header + sos, dri, 6);
+  return size + 6;
+}
+
 size_t sjpeg_hip_band_bound(int width, int height, int yuv_mode, int seg_begin, int seg_end) {
   FrameGeo g;
   if (!frame_geo(width, height, yuv_mode, &g)) return 0;
@@ -853,6 +904,7 @@ int sjpeg_hip_encode_band_src(sjpeg_hip_engine* e, const sjpeg_hip_source* src, 
   int rc = prepare_scan(e, src, width, height, yuv_mode, 1, tables, st, &g, &a, &cls, false, false, SIZE_MAX, &plan);
   if (rc) return rc;
   if (seg_begin < 0 || seg_end > g.nseg || seg_begin >= seg_end) return fail(SJPEG_HIP_EINVAL, "bad segment range");
+  a.rst = 0;                                       // (bands are stitched at bit granularity: the exact mode)
   HIP_TRY(hipMemsetAsync(a.pool_ctr, 0, 2 * sizeof(uint32_t), st));
   e->ctr_clean_at[0] = nullptr;                    // (no K4 in this path)
   const int nloc = seg_end - seg_begin;

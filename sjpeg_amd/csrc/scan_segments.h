@@ -53,7 +53,8 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
   RACE_POINT(0);
   const int m_first = (seg + a.seg_first) * G::kSegMcus;       // first coded MCU of the segment
   const int n_coded = min(G::kSegMcus, a.n_mcus - m_first);
-  const int halo = m_first > 0 ? 1 : 0;                        // previous MCU: DC predictors only
+  // (restart mode: every segment is a restart interval, its DC predictors start at zero)
+  const int halo = (m_first > 0 && !a.rst) ? 1 : 0;            // previous MCU: DC predictors only
   const uint8_t* const frame_px = a.plane[0] + frame * a.frame_stride[0];
 
   // tables -> LDS; issued once the first pixel loads are in flight (see P1)
@@ -952,6 +953,14 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
     const uint32_t s0 = wg_exclusive_scan<kScanThreads, false>(l0 + l1 + l2 + l3, misc, &total);
     *reinterpret_cast<uint4*>(tail) = make_uint4(s0, s0 + l0, s0 + l0 + l1, s0 + l0 + l1 + l2);
   }
+  // Restart mode (optional, never the reference's bytes): the interval ends on a byte boundary,
+  // padded with 1-bits, and 16 zero bits hold the place of its RSTn marker -- zero bytes pass the
+  // byte stuffing untouched, a small kernel writes FF D0+n over them afterwards (stitch_kernels.h).
+  const uint32_t data_bits = total;
+  if (a.rst) {
+    const bool last_of_frame = (m_first + n_coded == a.n_mcus);
+    total = ((total + 7u) & ~7u) + (last_of_frame ? 0u : 16u);
+  }
   RACE_POINT(8);
   // every thread has read its part lengths (barrier inside the scan): the window can be cleared
   // for the stitch under the same barrier that publishes the offsets
@@ -1067,6 +1076,11 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
           pending &= ~(1u << r);
         }
       }
+    }
+    if (a.rst && tid == 0 && limit == total && (data_bits & 7u) != 0u) {
+      // the last window: 1-bits from the end of the data to the byte boundary (same word)
+      const uint32_t p = data_bits - base, pad = 8u - (data_bits & 7u);
+      atomicOr(&win[p >> 5], ((1u << pad) - 1u) << (32u - (p & 31u) - pad));
     }
     __syncthreads();
     stamp(6);

@@ -29,6 +29,8 @@ struct StitchArgs {
   const unsigned long long* seg_nbits64;   // band stitch: lengths as uint64 (else NULL)
   unsigned long long* total_bits_out;      // band encode: where the bit count of the band goes (else NULL)
   uint32_t subs;                           // K3: waves per segment (1 unless segments are whole bands)
+  int seg_first;                           // restart mode, band of a frame: frame-level index of segment 0 ...
+  int rst_tail;                            // ... and whether the band's last interval gets its marker too (it is not the frame's last)
 };
 
 __global__ __launch_bounds__(kThreads) void scan_seg_offsets(const StitchArgs a) {
@@ -409,3 +411,33 @@ __global__ __launch_bounds__(kThreads) void stuff_chunks(const StitchArgs a) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------
+// K6 (restart mode only): the RSTn markers.  K1 left 16 zero bits behind every restart interval but
+// the last; they went through the stitch as two 0x00 bytes.  One wave per marker finds where they
+// ended up -- their position in the un-stuffed stream plus the 0xFF bytes in front of it (the chunk's
+// offset from K4 plus a count over the part of the chunk in front of the marker) -- and writes FF D0+n.
+
+__global__ __launch_bounds__(kThreads) void patch_restart_markers(const StitchArgs a) {
+  const int frame = blockIdx.y;
+  const int s = static_cast<int>(blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6));
+  const int lane = threadIdx.x & 63;
+  if (s >= a.nseg - (a.rst_tail ? 0 : 1) || a.sizes[frame] == 0) return;
+  const unsigned long long end_bits = a.seg_off[static_cast<size_t>(frame) * (a.nseg + 1) + s + 1];
+  const unsigned long long p = (end_bits >> 3) - 2;          // byte position of the placeholder, un-stuffed stream
+  const unsigned long long chunk = p / kChunkBytes, cstart = chunk * kChunkBytes;
+  const uint32_t* ub = a.ubuf + static_cast<size_t>(frame) * a.ubuf_words;
+  uint32_t ffs = 0;
+  for (unsigned long long b = cstart + 4ull * lane; b < p; b += 256) {
+    const unsigned long long left = p - b;
+    ffs += count_ff(ub[b >> 2], left >= 4 ? 4 : static_cast<int>(left));
+  }
+  for (int d = 32; d > 0; d >>= 1) ffs += __shfl_down(ffs, d, 64);
+  if (lane == 0) {
+    const uint32_t hsize = a.hdr_off ? a.hdr_off[frame + 1] - a.hdr_off[frame] : a.header_size;
+    uint8_t* dst = a.out + static_cast<size_t>(frame) * a.out_stride + hsize + p +
+                   a.chunk_off[static_cast<size_t>(frame) * a.max_chunks + chunk] + ffs;
+    dst[0] = 0xff;
+    dst[1] = static_cast<uint8_t>(0xd0 + ((s + a.seg_first) & 7));
+  }
+}

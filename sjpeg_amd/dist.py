@@ -195,3 +195,31 @@ def encode_frame_banded(engine, src, w: int, h: int, tables, header: bytes, yuv_
     if rank != dst:
         return None
     return engine.stitch_bands(allw, alln, header)
+
+
+def encode_frame_restart_banded(engine, src, w: int, h: int, tables, header: bytes, yuv_mode: int,
+                                dst: int = 0, group=None) -> Optional[bytes]:
+    """One frame coded by all ranks of the group in the optional RESTART mode (sjpeg_hip.h): rank r codes
+    the restart intervals of its band into stuffed bytes with their RSTn markers
+    (sjpeg_hip_encode_intervals_src); the bands are gathered (gather_streams: one packed buffer per
+    rank) and the file is header-with-DRI + bands in order + EOI -- plain concatenation on the host,
+    no bit-level stitch.  Byte-identical to the one-device restart-mode stream; NOT the reference's
+    bytes (it writes no restart markers), the same pixels.  `tables.flags` must carry
+    RESTART_MARKERS, `header` the DRI segment (sjpeg_amd.header_add_restart).  Returns the JPEG on
+    `dst`, None elsewhere."""
+    import sjpeg_amd as sj
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    nseg = sj.segment_count(w, h, yuv_mode)
+    b, e = band_ranges(nseg, world)[rank]
+    dev = torch.device("cuda", torch.cuda.current_device())
+    if e > b:
+        out, size = engine.encode_intervals(src, w, h, tables, yuv_mode, b, e)
+        out = out[:(out.numel() // 16) * 16].reshape(1, -1)
+    else:                                     # fewer intervals than ranks: nothing from this rank
+        out = torch.zeros((1, 16), dtype=torch.uint8, device=dev)
+        size = torch.zeros(1, dtype=torch.int64, device=dev)
+    bands = gather_streams(out, size, [rank], world, dst=dst, group=group)
+    if rank != dst:
+        return None
+    return header + b"".join(bands) + b"\xff\xd9"

@@ -948,3 +948,67 @@ def test_replayed_blocks_are_classified_by_the_coding_tables(oracle):
     got = sj.encode_device_method(torch.from_numpy(frames).cuda(), 100.0, 1, 4)
     for k in range(3):
         assert got[k] == oracle.encode_method(frames[k], 100.0, 1, 4), k
+
+
+# ---- optional restart-marker mode (never the reference's bytes: same coefficients, same pixels) ----
+
+def test_restart_mode_equals_restatement_and_decodes_to_the_same_pixels(engine, oracle):
+    """SJPEG_HIP_RESTART_MARKERS: every engine segment a restart interval.  The bytes are compared with the
+    oracle's restatement of the standard's rule (oracle/sjpeg_oracle.c orc_encode_rst: not something the
+    reference writes) and, through an independent decoder, the pixels with those of the exact stream."""
+    Image = pytest.importorskip("PIL.Image")
+    cases = [(640, 360, 75.0, 1), (333, 211, 90.0, 3), (300, 260, 50.0, 4), (1920, 1080, 75.0, 1),
+             (17, 13, 75.0, 1), (16 * 41, 16, 60.0, 1), (16 * 41 + 1, 16, 60.0, 1), (700, 500, 99.0, 1)]
+    for (w, h, q, mode) in cases:
+        img = synth.g_noise(w, h, 3) if q > 95 else synth.g_struct(w, h, 9 + w)
+        t, quant = sj.make_tables(quality=q)
+        t.flags |= sj.RESTART_MARKERS
+        header = sj.header_add_restart(sj.make_header(w, h, mode, quant), mode)
+        out, sizes = engine.encode_frames(dev(img), t, header, mode)
+        torch.cuda.synchronize()
+        got = bytes(out[0, :int(sizes[0])].cpu().numpy())
+        want = oracle.encode_rst(img, q, mode, sj.restart_interval(mode))
+        assert got == want, (w, h, q, mode, len(got), len(want))
+        exact = oracle.encode(img, q, mode)
+        a = np.asarray(Image.open(io.BytesIO(got)).convert("RGB"))
+        b = np.asarray(Image.open(io.BytesIO(exact)).convert("RGB"))
+        assert np.array_equal(a, b), (w, h, q, mode)
+    # a batch, and the exact mode right after on the same engine (the flag must not stick)
+    frames = np.stack([synth.g_struct(320, 240, 70 + k) for k in range(4)])
+    t, quant = sj.make_tables(quality=75.0)
+    header = sj.make_header(320, 240, 1, quant)
+    t.flags |= sj.RESTART_MARKERS
+    out, sizes = engine.encode_frames(torch.from_numpy(frames).cuda(), t, sj.header_add_restart(header, 1), 1)
+    torch.cuda.synchronize()
+    for k in range(4):
+        assert bytes(out[k, :int(sizes[k])].cpu().numpy()) == oracle.encode_rst(frames[k], 75.0, 1, 41)
+    t.flags &= ~sj.RESTART_MARKERS
+    out, sizes = engine.encode_frames(torch.from_numpy(frames).cuda(), t, header, 1)
+    torch.cuda.synchronize()
+    for k in range(4):
+        assert bytes(out[k, :int(sizes[k])].cpu().numpy()) == oracle.encode(frames[k], 75.0, 1)
+
+
+def test_restart_bands_concatenate_to_the_one_device_stream(engine, oracle):
+    """The north star's literal form: a frame cut at restart markers into bands (one per device), every band
+    coded on its own (sjpeg_hip_encode_intervals_src), the bytes concatenated behind the header.  P bands
+    simulated on one GPU; equal to the one-device restart stream and to the oracle's restatement."""
+    for (w, h, q, mode) in ((1920, 1080, 75.0, 1), (640, 360, 90.0, 3), (333, 211, 60.0, 4), (4000, 48, 97.0, 1)):
+        img = synth.g_noise(w, h, 4) if q > 95 else synth.g_struct(w, h, 3 + h)
+        t, quant = sj.make_tables(quality=q)
+        t.flags |= sj.RESTART_MARKERS
+        header = sj.header_add_restart(sj.make_header(w, h, mode, quant), mode)
+        want = oracle.encode_rst(img, q, mode, sj.restart_interval(mode))
+        nseg = sj.segment_count(w, h, mode)
+        rows = dev(img).reshape(1, h, 3 * w)             # (kept alive: the source holds raw pointers)
+        src, _ = sj.make_source(sj.SRC_RGB, [rows])
+        from sjpeg_amd.dist import band_ranges
+        for P in (1, 2, 3, 8):
+            parts = []
+            for (b, e) in band_ranges(nseg, P):
+                if e > b:
+                    out, size = engine.encode_intervals(src, w, h, t, mode, b, e)
+                    torch.cuda.synchronize()
+                    assert int(size[0]) > 0
+                    parts.append(bytes(out[:int(size[0])].cpu().numpy()))
+            assert header + b"".join(parts) + b"\xff\xd9" == want, (w, h, q, mode, P)
