@@ -198,6 +198,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if rank != 0:
+        # only rank 0's stdout carries the JSON line: whatever the other ranks (or the libraries
+        # they load: RCCL prints a banner through C stdio at exit) write goes to stderr
+        os.dup2(2, 1)
     exchange = world > 1 or args.exchange
     if exchange:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
