@@ -448,10 +448,24 @@ float sjpeg_hip_engine_last_scan_ms(sjpeg_hip_engine* engine);
 float sjpeg_hip_engine_last_total_ms(sjpeg_hip_engine* engine);
 
 /* Device memory the engine currently holds (it grows to what the largest call needed and is released
- * by sjpeg_hip_engine_destroy).  The segment scratch of an encode call is sized from the caller's
+ * by sjpeg_hip_engine_trim / sjpeg_hip_engine_destroy).  The segment scratch of an encode call is sized from the caller's
  * out_stride: per frame about 3.5 x out_stride (segment slots + pool + the un-stuffed stream), capped at
  * the worst case of the geometry -- not the worst case itself. */
 size_t sjpeg_hip_engine_scratch_bytes(sjpeg_hip_engine* engine);
+
+/* Gives the engine's scratch back to the device (waits for the device's work first; the tables and the
+ * header buffer stay).  The next call allocates what it needs again -- for a service that has just coded
+ * an unusually large frame or batch and does not want to keep its high-water mark. */
+int sjpeg_hip_engine_trim(sjpeg_hip_engine* engine);
+
+/* The host API (include/sjpeg.h) keeps one device context per calling thread: pixel, stream and plane
+ * buffers plus an engine, grown on demand.  A context whose cached device memory exceeds
+ * SJPEG_HIP_HOST_CACHE_BYTES (environment, default 1 GiB) after a call releases it before returning;
+ * sjpeg_hip_host_trim() releases the calling thread's cache now and returns the bytes it held.
+ * The host API first codes against an output capacity of half a byte per sample (0.75 B per pixel in
+ * 4:2:0) and repeats the frame against sjpeg_hip_frame_bound() if that was too small
+ * (SJPEG_HIP_HOST_FIRST_CAPACITY=bound: worst case from the first pass). */
+size_t sjpeg_hip_host_trim(void);
 
 /* Measurement aids of bench.py (no counterpart in the reference, not part of the encode path).
  * sjpeg_hip_debug_stream_read: a read-only streaming kernel over `bytes` of d_buf -- what the device's

@@ -112,7 +112,7 @@ class Oracle:
     def _take(self, n, out):
         if n == 0:
             return None
-        data = C.string_at(out, n)
+        data = bytes((C.c_ubyte * n).from_address(C.addressof(out.contents)))   # (string_at: 2 GiB limit)
         self.lib.orc_free(out)
         return data
 

@@ -56,7 +56,7 @@ class Ref:
     def _take(self, n, out):
         if n == 0:
             return None
-        data = C.string_at(out, n)
+        data = bytes((C.c_ubyte * n).from_address(C.addressof(out.contents)))   # (string_at: 2 GiB limit)
         self.lib.ref_free(out)
         return data
 

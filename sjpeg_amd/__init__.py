@@ -245,6 +245,7 @@ EXPORTED_C_SYMBOLS = [
     "sjpeg_hip_adapt_sums", "sjpeg_hip_adapt_quant_sums",
     "sjpeg_hip_encode_scan_src", "sjpeg_hip_scan_coeffs_src", "sjpeg_hip_scan_histogram_src",
     "sjpeg_hip_scan_symbol_stats_src", "sjpeg_hip_scan_quant_error_src", "sjpeg_hip_engine_entropy_bits",
+    "sjpeg_hip_engine_trim", "sjpeg_hip_host_trim",
     "sjpeg_hip_encode_scan_multi", "sjpeg_hip_scan_symbol_stats_multi",
     "sjpeg_hip_engine_set_pipelined", "sjpeg_hip_engine_wait", "sjpeg_hip_encode_batch_src",
     "sjpeg_hip_optimize_huffman", "sjpeg_hip_make_header_ex", "sjpeg_hip_make_header_meta",
@@ -303,6 +304,15 @@ def last_error() -> str:
     return (lib().SjpegHipLastError() or b"").decode()
 
 
+def host_trim() -> int:
+    """Releases the device memory the host API caches for the calling thread (sjpeg_hip_host_trim);
+    returns the number of bytes given back."""
+    f = lib().sjpeg_hip_host_trim
+    f.restype = C.c_size_t
+    f.argtypes = []
+    return int(f())
+
+
 def set_riskiness_table(table: bytes) -> None:
     """Installs the reference's riskiness score table (117649 bytes) for SJPEG_YUV_AUTO."""
     buf = (C.c_uint8 * len(table)).from_buffer_copy(table)
@@ -341,7 +351,7 @@ def SjpegEncode(rgb: np.ndarray, quality: float = 75.0, method: int = 0,
     n = lib().SjpegEncode(base, w, h, stride, C.byref(out), quality, method, yuv_mode)
     if n == 0:
         return None
-    data = C.string_at(out, n)
+    data = bytes((C.c_ubyte * n).from_address(C.addressof(out.contents)))   # (string_at: 2 GiB limit)
     lib().SjpegFreeBuffer(out)
     return data
 
@@ -524,6 +534,14 @@ class Engine:
         f.restype = C.c_size_t
         f.argtypes = [C.c_void_p]
         return int(f(self._h))
+
+    def trim(self) -> None:
+        """Give the engine's scratch back to the device (sjpeg_hip_engine_trim); the next call
+        allocates what it needs again."""
+        f = lib().sjpeg_hip_engine_trim
+        f.restype = C.c_int
+        f.argtypes = [C.c_void_p]
+        self._chk(f(self._h), "sjpeg_hip_engine_trim")
 
     @staticmethod
     def _stream():

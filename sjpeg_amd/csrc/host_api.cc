@@ -252,6 +252,44 @@ struct DeviceContext {
     *mode = RiskVerdict(sums[0], sums[1], sums[2], W, H, risk);
     return true;
   }
+  // First capacity tried for a frame's stream: header + 1 byte per sample of the picture's planes
+  // / 2 (0.75 bytes per pixel in 4:2:0, 1.5 in 4:4:4 -- three to six times what photographs code
+  // to at q 75..90), never above the worst-case bound.  SJPEG_HIP_HOST_FIRST_CAPACITY=bound restores
+  // the worst case from the first pass on.
+  size_t FirstCapacity(int W, int H, int mode, size_t header, size_t bound) const {
+    static const bool worst = [] {
+      const char* v = getenv("SJPEG_HIP_HOST_FIRST_CAPACITY");
+      return v != nullptr && strcmp(v, "bound") == 0;
+    }();
+    if (worst) return bound;
+    const size_t px = static_cast<size_t>(W) * static_cast<size_t>(H);
+    const size_t samples = mode == SJPEG_HIP_YUV444 ? 3 * px : mode == SJPEG_HIP_YUV400 ? px : px + px / 2;
+    const size_t cap = header + 65536 + samples / 2;
+    return cap < bound ? cap : bound;
+  }
+  // Gives the device memory this thread's context caches (pixels, stream, planes, engine scratch)
+  // back; the next encode allocates what it needs again.
+  void Trim() {
+    if (engine == nullptr || hipSetDevice(device) != hipSuccess) return;
+    if (stream) (void)hipStreamSynchronize(stream);
+    void** const bufs[] = {&d_in, &d_out, &d_hist, &d_planes, &d_work};
+    size_t* const caps[] = {&in_cap, &out_cap, &hist_cap, &planes_cap, &work_cap};
+    for (int i = 0; i < 5; ++i) {
+      if (*bufs[i]) (void)hipFree(*bufs[i]);
+      *bufs[i] = nullptr; *caps[i] = 0;
+    }
+    (void)sjpeg_hip_engine_trim(engine);
+  }
+  void TrimIfOver() {
+    static const size_t limit = [] {
+      const char* v = getenv("SJPEG_HIP_HOST_CACHE_BYTES");
+      return v != nullptr ? static_cast<size_t>(strtoull(v, nullptr, 0)) : (static_cast<size_t>(1) << 30);
+    }();
+    if (engine != nullptr && CachedBytes() > limit) Trim();
+  }
+  size_t CachedBytes() const {
+    return in_cap + out_cap + hist_cap + planes_cap + work_cap + sjpeg_hip_engine_scratch_bytes(engine);
+  }
   bool Ensure(void** p, size_t* cap, size_t need) {
     if (need <= *cap) return true;
     if (*p) (void)hipFree(*p);
@@ -378,7 +416,11 @@ bool Encoder::RunImpl() {
   if (!ctx.Init()) return false;
   // the caller's pixels are read by stream-ordered copies: whatever way this call ends, nothing of
   // it is still in flight when it returns
-  struct SyncOnExit { hipStream_t s; ~SyncOnExit() { (void)hipStreamSynchronize(s); } } sync_on_exit{ctx.stream};
+  // ... and a context that grew past its cache limit (one very large frame) gives the memory back
+  struct SyncOnExit {
+    DeviceContext* c;
+    ~SyncOnExit() { (void)hipStreamSynchronize(c->stream); c->TrimIfOver(); }
+  } sync_on_exit{&ctx};
   if (hipSetDevice(ctx.device) != hipSuccess) return Fail("hipSetDevice failed");
 
   // pixels -> device, plane by plane.  Rows keep a 16-byte aligned pitch; a bottom-up plane
@@ -601,17 +643,19 @@ bool Encoder::RunImpl() {
         } else {
           // BitCounter (src/bit_writer.h:292-365): coded bits + 8 per 0xFF among COMPLETED bytes.
           // One real coding pass gives both: entropy bits, and the escapes through the size.
-          const size_t cap = sjpeg_hip_frame_bound(W_, H_, mode, 0);
-          if (cap == 0 || !ctx.Ensure(&ctx.d_out, &ctx.out_cap, cap)) return false;
-          if (sjpeg_hip_encode_scan_src(ctx.engine, &dsrc, W_, H_, mode, 1, &tables, nullptr, 0, 0,
-                                        ctx.d_out, cap, ctx.d_size, ctx.stream) != 0) {
-            return FailHip("sjpeg_hip_encode_scan");
-          }
+          const size_t bound = sjpeg_hip_frame_bound(W_, H_, mode, 0);
+          if (bound == 0) return false;
           uint64_t bits = 0, bytes = 0;
-          if (sjpeg_hip_engine_entropy_bits(ctx.engine, &bits, 1) != 0) return FailHip("entropy_bits");
-          if (!ctx.ToHost(&bytes, ctx.d_size, sizeof(bytes)) || bytes == 0) {
-            return Fail("size pass failed");
+          for (size_t cap = ctx.FirstCapacity(W_, H_, mode, 0, bound); bytes == 0; cap = bound) {
+            if (!ctx.Ensure(&ctx.d_out, &ctx.out_cap, cap)) return false;
+            if (sjpeg_hip_encode_scan_src(ctx.engine, &dsrc, W_, H_, mode, 1, &tables, nullptr, 0, 0,
+                                          ctx.d_out, cap, ctx.d_size, ctx.stream) != 0) {
+              return FailHip("sjpeg_hip_encode_scan");
+            }
+            if (!ctx.ToHost(&bytes, ctx.d_size, sizeof(bytes))) return Fail("size pass failed");
+            if (bytes == 0 && cap == bound) return Fail("size pass failed");
           }
+          if (sjpeg_hip_engine_entropy_bits(ctx.engine, &bits, 1) != 0) return FailHip("entropy_bits");
           uint64_t escapes = bytes - (bits + 7) / 8;
           if ((bits & 7) != 0 && bytes >= 2) {       // a padded last byte that became 0xFF is not counted
             uint8_t tail[2];
@@ -705,20 +749,26 @@ bool Encoder::RunImpl() {
   const size_t bound = sjpeg_hip_frame_bound(W_, H_, mode, header.size());
   if (bound == 0) return Fail("internal: no bound for this geometry");
   const bool mailed = bound <= DeviceContext::kMailData;          // small picture: straight into pinned memory
-  if (!mailed && !ctx.Ensure(&ctx.d_out, &ctx.out_cap, bound)) return false;
-  void* const d_stream = mailed ? static_cast<void*>(ctx.d_mail + 64) : ctx.d_out;
   volatile uint64_t* const h_size = reinterpret_cast<volatile uint64_t*>(ctx.h_mail);
-  *h_size = 0;
-  if (sjpeg_hip_encode_scan_src(ctx.engine, &dsrc, W_, H_, mode, 1, &tables,
-                            staged_header, header.size(), /*append_eoi=*/1, d_stream, bound,
-                            reinterpret_cast<uint64_t*>(ctx.d_mail), ctx.stream) != 0) {
-    return FailHip("sjpeg_hip_encode_scan");
+  uint64_t size = 0;
+  // The output buffer (and with it the engine's scratch, which follows out_stride) is sized for
+  // what pictures code to, not for the 6.75 bytes per pixel of the worst case; a frame that does not
+  // fit reports size 0 and is coded again against the bound (deterministic: same bytes either way).
+  for (size_t cap = mailed ? bound : ctx.FirstCapacity(W_, H_, mode, header.size(), bound); size == 0; cap = bound) {
+    if (!mailed && !ctx.Ensure(&ctx.d_out, &ctx.out_cap, cap)) return false;
+    void* const d_stream = mailed ? static_cast<void*>(ctx.d_mail + 64) : ctx.d_out;
+    *h_size = 0;
+    if (sjpeg_hip_encode_scan_src(ctx.engine, &dsrc, W_, H_, mode, 1, &tables,
+                                  staged_header, header.size(), /*append_eoi=*/1, d_stream, cap,
+                                  reinterpret_cast<uint64_t*>(ctx.d_mail), ctx.stream) != 0) {
+      return FailHip("sjpeg_hip_encode_scan");
+    }
+    if (hipStreamSynchronize(ctx.stream) != hipSuccess) {
+      return Fail(std::string("device execution failed: ") + hipGetErrorString(hipGetLastError()));
+    }
+    size = *h_size;
+    if (size == 0 && cap == bound) return Fail("internal: coded frame exceeded its bound");
   }
-  if (hipStreamSynchronize(ctx.stream) != hipSuccess) {
-    return Fail(std::string("device execution failed: ") + hipGetErrorString(hipGetLastError()));
-  }
-  const uint64_t size = *h_size;
-  if (size == 0) return Fail("internal: coded frame exceeded its bound");
 
   // device -> sink, straight into the sink's own storage
   uint8_t* dst = nullptr;
@@ -1131,6 +1181,14 @@ size_t sjpeg_hip_make_header_meta(int width, int height, int yuv_mode, const uin
   if (h.size() > cap) return 0;
   memcpy(buf, h.data(), h.size());
   return h.size();
+}
+
+size_t sjpeg_hip_host_trim(void) {
+  DeviceContext& ctx = g_ctx;
+  if (ctx.engine == nullptr) return 0;
+  const size_t held = ctx.CachedBytes();
+  ctx.Trim();
+  return held - ctx.CachedBytes();
 }
 
 }  // extern "C"

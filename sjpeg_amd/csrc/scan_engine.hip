@@ -441,12 +441,32 @@ void sjpeg_hip_engine_destroy(sjpeg_hip_engine* e) {
   if (e == nullptr) return;
   (void)hipSetDevice(e->device);
   e->tables.release(); e->header.release(); e->seg_words.release(); e->seg_nbits.release(); e->pool.release(); e->pool_ctr.release(); e->seg_xbase.release(); e->replay.release();
-  e->ubuf.release(); e->chunk_ff.release(); e->partial.release(); e->seg_off.release(); e->chunk_off.release(); e->hdr_off.release();
+  e->ubuf.release(); e->chunk_ff.release(); e->partial.release(); e->seg_off.release(); e->chunk_off.release(); e->hdr_off.release(); e->stamps.release();
   for (auto& ev : e->ev) if (ev) (void)hipEventDestroy(ev);
   e->seg_words2.release(); e->seg_nbits2.release(); e->pool2.release(); e->pool_ctr2.release(); e->seg_xbase2.release();
   if (e->side) { (void)hipStreamSynchronize(e->side); (void)hipStreamDestroy(e->side); }
   for (hipEvent_t ev : {e->k1_done, e->side_done, e->k3_done[0], e->k3_done[1], e->cross_ev}) if (ev) (void)hipEventDestroy(ev);
   delete e;
+}
+
+int sjpeg_hip_engine_trim(sjpeg_hip_engine* e) {
+  if (e == nullptr) return fail(SJPEG_HIP_EINVAL, "engine == NULL");
+  HIP_TRY(hipSetDevice(e->device));
+  // the engine does not own the streams its calls ran on: wait for the whole device
+  HIP_TRY(hipDeviceSynchronize());
+  e->seg_words.release(); e->seg_nbits.release(); e->pool.release(); e->pool_ctr.release(); e->seg_xbase.release();
+  e->seg_words2.release(); e->seg_nbits2.release(); e->pool2.release(); e->pool_ctr2.release(); e->seg_xbase2.release();
+  e->ubuf.release(); e->chunk_ff.release(); e->partial.release(); e->replay.release();
+  e->seg_off.release(); e->chunk_off.release(); e->hdr_off.release(); e->stamps.release();
+  e->replay_w = e->replay_h = e->replay_mode = e->replay_nframes = 0;
+  e->stamps_n = 0;
+  e->last_nseg = e->last_nframes = 0;
+  e->ctr_clean_at[0] = e->ctr_clean_at[1] = nullptr;
+  e->ctr_clean_n[0] = e->ctr_clean_n[1] = 0;
+  e->k3_pending[0] = e->k3_pending[1] = e->side_pending = false;
+  e->last_stream_valid = false;
+  e->ev_valid = false;
+  return 0;
 }
 
 int sjpeg_hip_engine_set_pipelined(sjpeg_hip_engine* e, int on) {

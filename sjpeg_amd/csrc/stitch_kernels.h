@@ -248,9 +248,12 @@ __global__ __launch_bounds__(kThreads) void place_segments(const StitchArgs a) {
       if (256u * k < nwords) batch(256u * k, wq[k], wx[k]);
     }
     for (uint32_t i0 = 256u * kWideSpec; i0 < nwords; i0 += 256u) {
-      // (words behind the segment's last one are never used: the index only has to stay inside the slot)
-      const uint32_t i = min(i0 + 4u * lane, (a.slot_words - 8u) & ~3u);
-      batch(i0, *reinterpret_cast<const uint4*>(src + i), src[i + 4]);
+      // A lane whose four words start inside the slot must get exactly those (a segment that is not
+      // `long_seg` has up to slot_words - 2 of them); only the fifth word of the slot's last lane,
+      // needed by destination word slot_words - 1 alone, and the lanes behind the slot, all of
+      // whose words are unused, are clamped.
+      const uint32_t i = min(i0 + 4u * lane, a.slot_words - 4u);
+      batch(i0, *reinterpret_cast<const uint4*>(src + i), src[min(i + 4u, a.slot_words - 1u)]);
     }
   } else if (!long_seg) {
 #pragma unroll

@@ -1012,3 +1012,79 @@ def test_restart_bands_concatenate_to_the_one_device_stream(engine, oracle):
                     assert int(size[0]) > 0
                     parts.append(bytes(out[:int(size[0])].cpu().numpy()))
             assert header + b"".join(parts) + b"\xff\xd9" == want, (w, h, q, mode, P)
+
+
+def test_host_api_codes_again_when_the_first_capacity_is_too_small(oracle):
+    """The host API sizes its output buffer for half a byte per sample and repeats a frame against the
+    worst-case bound if that was too small: dense pictures (noise at q 100: 3-5 bytes per pixel) give the
+    reference's bytes through the second pass, for the plain encode and for the size-search pass."""
+    for (w, h, q, mode) in ((512, 512, 100.0, 3), (640, 400, 100.0, 1), (333, 517, 99.0, 4)):
+        img = synth.g_noise(w, h, 100 + w)
+        want = oracle.encode(img, q, mode)
+        samples = w * h * (3 if mode == 3 else 1 if mode == 4 else 1.5)
+        assert len(want) > 65536 + 1024 + samples / 2, "picture too calm to need the second pass"
+        assert sj.SjpegEncode(img, q, 0, mode) == want, (w, h, q, mode)
+        # ... and a calm picture right after it, through the buffers the dense one left behind
+        calm = synth.g_struct(w, h, 3)
+        assert sj.SjpegEncode(calm, 75.0, 0, mode) == oracle.encode(calm, 75.0, mode)
+
+
+def test_trim_gives_scratch_back_and_the_next_call_allocates_again(engine, oracle):
+    img = synth.g_struct(1024, 768, 9)
+    want = oracle.encode(img, 80.0, 1)
+    t, quant = sj.make_tables(quality=80.0)
+    header = sj.make_header(1024, 768, 1, quant)
+    out, sizes = engine.encode_frames(dev(img), t, header, 1)
+    torch.cuda.synchronize()
+    before = engine.scratch_bytes()
+    engine.trim()
+    after = engine.scratch_bytes()
+    assert before > 1 << 20 and after < 1 << 16, (before, after)
+    for _ in range(2):
+        out, sizes = engine.encode_frames(dev(img), t, header, 1)
+        torch.cuda.synchronize()
+        assert bytes(out[0, :int(sizes[0])].cpu().numpy()) == want
+    # pipelined mode keeps two sets: both go, both come back
+    engine.set_pipelined(True)
+    try:
+        outs = [engine.encode_frames(dev(img), t, header, 1) for _ in range(3)]
+        engine.wait()
+        torch.cuda.synchronize()
+        engine.trim()
+        assert engine.scratch_bytes() < 1 << 16
+        outs = [engine.encode_frames(dev(img), t, header, 1) for _ in range(3)]
+        engine.wait()
+        torch.cuda.synchronize()
+        for out, sizes in outs:
+            assert bytes(out[0, :int(sizes[0])].cpu().numpy()) == want
+    finally:
+        engine.set_pipelined(False)
+    # the host API's per-thread cache
+    assert sj.SjpegEncode(img, 80.0, 0, 1) == want
+    assert sj.host_trim() > 1 << 20
+    assert sj.host_trim() < 1 << 16
+    assert sj.SjpegEncode(img, 80.0, 0, 1) == want
+
+
+def test_segments_of_every_length_around_the_slot_size(engine, oracle):
+    """One segment per MCU row (656 pixels = 41 MCUs), noise whose amplitude grows down the picture: the
+    segments' lengths sweep every word count from ~100 below to ~200 above a 1024-word slot, with every
+    bit alignment.  Slots of 1024 / 1088 / 1152 words (chosen through out_stride) put the boundary
+    between 'fits the slot' and 'continues in the pool' at three places of that sweep.  Found at
+    65535 x 65535 (tools/max_frame_check.py): a segment of slot_words - 3 words had its last word
+    placed from the wrong source words."""
+    nseg, rng = 2400, np.random.RandomState(2024)
+    amp = np.linspace(23.0, 30.0, nseg).repeat(16)[:, None, None]
+    img = np.clip(128 + rng.randint(-128, 128, (16 * nseg, 656, 3)) * amp / 128.0, 0, 255).astype(np.uint8)
+    want = oracle.encode(img, 90.0, 1)
+    assert 3900 * nseg < len(want) < 4900 * nseg
+    t, quant = sj.make_tables(quality=90.0)
+    header = sj.make_header(656, 16 * nseg, 1, quant)
+    d = dev(img)
+    for per_seg in (6000, 8640, 9152, 20000):
+        out, sizes = engine.encode_frames(d, t, header, 1, out_stride=per_seg * nseg)
+        torch.cuda.synchronize()
+        got = out[0, :int(sizes[0])].cpu().numpy()
+        assert len(got) == len(want), per_seg
+        diff = np.nonzero(got != np.frombuffer(want, np.uint8))[0]
+        assert len(diff) == 0, (per_seg, len(diff), int(diff[0]))
