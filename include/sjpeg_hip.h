@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SJPEG_HIP_ABI_VERSION 13
+#define SJPEG_HIP_ABI_VERSION 14
 
 enum {
   SJPEG_HIP_OK = 0,
