@@ -1066,25 +1066,37 @@ def test_trim_gives_scratch_back_and_the_next_call_allocates_again(engine, oracl
     assert sj.SjpegEncode(img, 80.0, 0, 1) == want
 
 
-def test_segments_of_every_length_around_the_slot_size(engine, oracle):
+def _sweep_segment_lengths(engine, oracle, q, amp_lo, amp_hi, nseg, per_seg_strides, lo, hi, seed):
     """One segment per MCU row (656 pixels = 41 MCUs), noise whose amplitude grows down the picture: the
-    segments' lengths sweep every word count from ~100 below to ~200 above a 1024-word slot, with every
-    bit alignment.  Slots of 1024 / 1088 / 1152 words (chosen through out_stride) put the boundary
-    between 'fits the slot' and 'continues in the pool' at three places of that sweep.  Found at
-    65535 x 65535 (tools/max_frame_check.py): a segment of slot_words - 3 words had its last word
-    placed from the wrong source words."""
-    nseg, rng = 2400, np.random.RandomState(2024)
-    amp = np.linspace(23.0, 30.0, nseg).repeat(16)[:, None, None]
+    segments' lengths sweep every word count of a range, with every bit alignment."""
+    rng = np.random.RandomState(seed)
+    amp = np.linspace(amp_lo, amp_hi, nseg).repeat(16)[:, None, None]
     img = np.clip(128 + rng.randint(-128, 128, (16 * nseg, 656, 3)) * amp / 128.0, 0, 255).astype(np.uint8)
-    want = oracle.encode(img, 90.0, 1)
-    assert 3900 * nseg < len(want) < 4900 * nseg
-    t, quant = sj.make_tables(quality=90.0)
+    want = oracle.encode(img, q, 1)
+    assert lo * nseg < len(want) < hi * nseg, len(want) / nseg
+    t, quant = sj.make_tables(quality=q)
     header = sj.make_header(656, 16 * nseg, 1, quant)
     d = dev(img)
-    for per_seg in (6000, 8640, 9152, 20000):
+    for per_seg in per_seg_strides:
         out, sizes = engine.encode_frames(d, t, header, 1, out_stride=per_seg * nseg)
         torch.cuda.synchronize()
         got = out[0, :int(sizes[0])].cpu().numpy()
-        assert len(got) == len(want), per_seg
+        assert len(got) == len(want), (q, per_seg)
         diff = np.nonzero(got != np.frombuffer(want, np.uint8))[0]
-        assert len(diff) == 0, (per_seg, len(diff), int(diff[0]))
+        assert len(diff) == 0, (q, per_seg, len(diff), int(diff[0]))
+
+
+def test_segments_of_every_length_around_the_slot_size(engine, oracle):
+    """Segment lengths from ~100 words below to ~200 above a 1024-word slot.  Slots of 1024 / 1088 / 1152
+    words (chosen through out_stride) put the boundary between 'fits the slot' and 'continues in the
+    pool' at three places of that sweep.  Found at 65535 x 65535 (tools/max_frame_check.py): a segment
+    of slot_words - 3 words had its last word placed from the wrong source words."""
+    _sweep_segment_lengths(engine, oracle, 90.0, 23.0, 30.0, 2400, (6000, 8640, 9152, 20000), 3900, 4900, 2024)
+
+
+def test_segments_of_every_length_around_the_stitch_window(engine, oracle):
+    """K1 stitches a segment through an 8 KiB window in LDS, in several rounds if it is longer: lengths
+    sweeping across one window (q 97: lean and checked parts mixed) and across two (q 100), with slots
+    that end before, inside and behind the window boundary."""
+    _sweep_segment_lengths(engine, oracle, 97.0, 24.0, 38.0, 1500, (12000, 17000, 40000), 7500, 10500, 7)
+    _sweep_segment_lengths(engine, oracle, 100.0, 48.0, 72.0, 1500, (24000, 33500, 80000), 15000, 18500, 8)

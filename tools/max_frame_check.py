@@ -1,7 +1,7 @@
 """Frames up to the reference's own limit of 65535 x 65535 (src/enc.cc:406) through the host API, against
 the plain-C oracle (the reference itself addresses MCUs with 32-bit ints and is undefined beyond 2^31
 source bytes -- profiles/HISTORY_r01.md).  12.9 GB of pixels for the largest: run on the GPU box only.
-Usage: python tools/max_frame_check.py [WxH:mode:q ...]"""
+Usage: python tools/max_frame_check.py [WxH:mode:q[:method] ...]"""
 import hashlib
 import os
 import sys
@@ -36,9 +36,9 @@ def frame(w, h):
 cases = sys.argv[1:] or ["40000x36000:1:75", "65535x65535:1:75"]
 o = orc.oracle()
 for c in cases:
-    dims, mode, q = c.split(":")
+    dims, mode, q, method = (c.split(":") + ["0"])[:4]
     w, h = (int(v) for v in dims.split("x"))
-    mode, q = int(mode), float(q)
+    mode, q, method = int(mode), float(q), int(method)
     need = 3 * w * h / 2**30
     avail = mem_available_gb()
     print(f"{c}: {need:.1f} GiB of pixels, {avail:.0f} GiB of host memory available", flush=True)
@@ -47,14 +47,14 @@ for c in cases:
         continue
     img = frame(w, h)
     t0 = time.time()
-    got = sj.SjpegEncode(img, q, 0, mode)
+    got = sj.SjpegEncode(img, q, method, mode)
     t1 = time.time()
     if got is None:
         print("  GPU path failed:", sj.last_error(), flush=True)
         continue
     print(f"  gpu {len(got)} bytes {hashlib.md5(got).hexdigest()[:12]} in {t1 - t0:.1f} s "
           f"(host buffers, copies included); cached {sj.host_trim() / 2**30:.1f} GiB released", flush=True)
-    want = o.encode(img, q, mode)
+    want = o.encode_method(img, q, mode, method) if method else o.encode(img, q, mode)
     t2 = time.time()
     print(f"  oracle {len(want)} bytes {hashlib.md5(want).hexdigest()[:12]} in {t2 - t1:.1f} s | "
           f"equal {got == want}", flush=True)
