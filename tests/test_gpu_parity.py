@@ -1066,24 +1066,63 @@ def test_trim_gives_scratch_back_and_the_next_call_allocates_again(engine, oracl
     assert sj.SjpegEncode(img, 80.0, 0, 1) == want
 
 
-def _sweep_segment_lengths(engine, oracle, q, amp_lo, amp_hi, nseg, per_seg_strides, lo, hi, seed):
-    """One segment per MCU row (656 pixels = 41 MCUs), noise whose amplitude grows down the picture: the
-    segments' lengths sweep every word count of a range, with every bit alignment."""
+_SEG_ROW = {1: (656, 16), 3: (672, 8), 4: (2040, 8)}      # one K1 segment (41 / 84 / 255 MCUs) per MCU row
+
+
+def _noise_rows(mode, amps, seed):
+    w, mh = _SEG_ROW[mode]
     rng = np.random.RandomState(seed)
-    amp = np.linspace(amp_lo, amp_hi, nseg).repeat(16)[:, None, None]
-    img = np.clip(128 + rng.randint(-128, 128, (16 * nseg, 656, 3)) * amp / 128.0, 0, 255).astype(np.uint8)
-    want = oracle.encode(img, q, 1)
-    assert lo * nseg < len(want) < hi * nseg, len(want) / nseg
+    amp = np.asarray(amps, np.float64).repeat(mh)[:, None, None]
+    return np.clip(128 + rng.randint(-128, 128, (mh * len(amps), w, 3)) * amp / 128.0, 0, 255).astype(np.uint8)
+
+
+def _amp_for_row_bytes(oracle, mode, q, nbytes):
+    """Noise amplitude at which one MCU row (= one segment) codes to about nbytes of entropy data."""
+    empty = len(oracle.encode(_noise_rows(mode, [0.0], 1), q, mode))
+    lo, hi = 0.0, 128.0
+    for _ in range(12):
+        mid = (lo + hi) / 2
+        if len(oracle.encode(_noise_rows(mode, [mid], 1), q, mode)) - empty < nbytes:
+            lo = mid
+        else:
+            hi = mid
+    return (lo + hi) / 2
+
+
+def _sweep_segment_lengths(engine, oracle, mode, q, words_lo, words_hi, nseg, per_seg_strides, seed):
+    """One segment per MCU row, noise whose amplitude grows down the picture: the segments' lengths
+    sweep every word count from words_lo to words_hi, with every bit alignment; out_stride (per
+    segment) chooses the slot size, i.e. where a segment stops fitting its slot and continues in the pool."""
+    a_lo, a_hi = (_amp_for_row_bytes(oracle, mode, q, 4 * n) for n in (words_lo, words_hi))
+    assert a_lo < a_hi < 127.0, (a_lo, a_hi)
+    img = _noise_rows(mode, np.linspace(a_lo, a_hi, nseg), seed)
+    h, w = img.shape[:2]
+    want = oracle.encode(img, q, mode)
+    assert 3.6 * words_lo * nseg < len(want) < 4.4 * words_hi * nseg, len(want) / nseg
     t, quant = sj.make_tables(quality=q)
-    header = sj.make_header(656, 16 * nseg, 1, quant)
+    header = sj.make_header(w, h, mode, quant)
     d = dev(img)
-    for per_seg in per_seg_strides:
-        out, sizes = engine.encode_frames(d, t, header, 1, out_stride=per_seg * nseg)
-        torch.cuda.synchronize()
+
+    def check(out, sizes, what):
         got = out[0, :int(sizes[0])].cpu().numpy()
-        assert len(got) == len(want), (q, per_seg)
+        assert len(got) == len(want), what
         diff = np.nonzero(got != np.frombuffer(want, np.uint8))[0]
-        assert len(diff) == 0, (q, per_seg, len(diff), int(diff[0]))
+        assert len(diff) == 0, (what, len(diff), int(diff[0]))
+
+    for per_seg in per_seg_strides:
+        out, sizes = engine.encode_frames(d, t, header, mode, out_stride=per_seg * nseg)
+        torch.cuda.synchronize()
+        check(out, sizes, (mode, q, per_seg))
+    # the second buffer set of the pipelined mode, with its own pool
+    engine.set_pipelined(True)
+    try:
+        outs = [engine.encode_frames(d, t, header, mode, out_stride=per_seg_strides[0] * nseg) for _ in range(3)]
+        engine.wait()
+        torch.cuda.synchronize()
+        for k, (out, sizes) in enumerate(outs):
+            check(out, sizes, (mode, q, "pipelined", k))
+    finally:
+        engine.set_pipelined(False)
 
 
 def test_segments_of_every_length_around_the_slot_size(engine, oracle):
@@ -1091,12 +1130,15 @@ def test_segments_of_every_length_around_the_slot_size(engine, oracle):
     words (chosen through out_stride) put the boundary between 'fits the slot' and 'continues in the
     pool' at three places of that sweep.  Found at 65535 x 65535 (tools/max_frame_check.py): a segment
     of slot_words - 3 words had its last word placed from the wrong source words."""
-    _sweep_segment_lengths(engine, oracle, 90.0, 23.0, 30.0, 2400, (6000, 8640, 9152, 20000), 3900, 4900, 2024)
+    _sweep_segment_lengths(engine, oracle, 1, 90.0, 940, 1230, 2400, (6000, 8640, 9152, 20000), 2024)
+    _sweep_segment_lengths(engine, oracle, 3, 90.0, 940, 1230, 1600, (6000, 8640, 9152, 20000), 2025)
+    _sweep_segment_lengths(engine, oracle, 4, 85.0, 940, 1230, 1600, (6000, 8640, 9152, 20000), 2026)
 
 
 def test_segments_of_every_length_around_the_stitch_window(engine, oracle):
     """K1 stitches a segment through an 8 KiB window in LDS, in several rounds if it is longer: lengths
     sweeping across one window (q 97: lean and checked parts mixed) and across two (q 100), with slots
     that end before, inside and behind the window boundary."""
-    _sweep_segment_lengths(engine, oracle, 97.0, 24.0, 38.0, 1500, (12000, 17000, 40000), 7500, 10500, 7)
-    _sweep_segment_lengths(engine, oracle, 100.0, 48.0, 72.0, 1500, (24000, 33500, 80000), 15000, 18500, 8)
+    _sweep_segment_lengths(engine, oracle, 1, 97.0, 1900, 2500, 1500, (12000, 17000, 40000), 7)
+    _sweep_segment_lengths(engine, oracle, 1, 100.0, 3800, 4500, 1500, (24000, 33500, 80000), 8)
+    _sweep_segment_lengths(engine, oracle, 3, 97.0, 1900, 2500, 1000, (12000, 17000, 40000), 9)
