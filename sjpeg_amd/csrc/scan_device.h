@@ -245,25 +245,27 @@ __device__ __forceinline__ int dot2z(s16x2 a, int klo, int khi) {
   return d;
 }
 
-// Row transform of one row held as 4 packed pairs; 32-bit wrap-around accumulation like
-// src/fdct.cc:174-209 (and pmaddwd in its SSE2 twin).  acc[i] >> 16 is coefficient i of the row.
+// Row transform of one row held as 4 packed pairs IN SLOT ORDER -- (x0,x1) (x3,x2) (x4,x5) (x7,x6):
+// P1 writes the second and fourth pair of every row with their halves exchanged, which costs it
+// nothing (operand order of the instruction that packs them) and leaves the butterflies below
+// without a single half-swap; the column pass works on each half by itself and does not care.
+// 32-bit wrap-around accumulation like src/fdct.cc:174-209 (and pmaddwd in its SSE2 twin).
+// acc[i] >> 16 is coefficient i of the row.
 template <int C1, int C2, int C3, int C4, int C5, int C6, int C7>
 __device__ __forceinline__ void fdct_row8_pk(const uint32_t* row, int* acc) {
-  const s16x2 p0 = as_pk(row[0]), p1 = as_pk(row[1]);
-  const s16x2 r3 = pk_swap(as_pk(row[3])), r2 = pk_swap(as_pk(row[2]));
-  const s16x2 A01 = p0 + r3, B01 = p0 - r3;       // (a0,a1), (b0,b1)
-  const s16x2 A23 = p1 + r2, B23 = p1 - r2;       // (a2,a3), (b2,b3)
+  const s16x2 p0 = as_pk(row[0]), q1 = as_pk(row[1]), q2 = as_pk(row[2]), q3 = as_pk(row[3]);
+  const s16x2 A01 = p0 + q3, B01 = p0 - q3;       // (a0,a1), (b0,b1)
+  const s16x2 A32 = q1 + q2, B32 = q1 - q2;       // (a3,a2), (b3,b2)
   // even part: (c0, c2) = (a0 + a3, a1 + a2), (c1, c3) = (a0 - a3, a1 - a2); one product pair per output
-  const s16x2 A32 = pk_swap(A23);
   const s16x2 C02 = A01 + A32, C13 = A01 - A32;
   acc[0] = dot2z(C02, C4, C4);
   acc[4] = dot2z(C02, C4, -C4);
   acc[2] = dot2z(C13, C2, C6);
   acc[6] = dot2z(C13, C6, -C2);
-  acc[1] = dot2(B23, C5, C7, dot2z(B01, C1, C3));
-  acc[3] = dot2(B23, -C1, -C5, dot2z(B01, C3, -C7));
-  acc[5] = dot2(B23, C7, C3, dot2z(B01, C5, -C1));
-  acc[7] = dot2(B23, C3, -C1, dot2z(B01, C7, -C5));
+  acc[1] = dot2(B32, C7, C5, dot2z(B01, C1, C3));
+  acc[3] = dot2(B32, -C5, -C1, dot2z(B01, C3, -C7));
+  acc[5] = dot2(B32, C3, C7, dot2z(B01, C5, -C1));
+  acc[7] = dot2(B32, -C1, C3, dot2z(B01, C7, -C5));
 }
 
 // D = a.u16[half] * b.u16[half] + c   (one VOP3 op on packed operands)
@@ -331,9 +333,9 @@ __device__ __forceinline__ void row_quant(const uint32_t* row, const uint4* qt, 
     const s16x2 c = as_pk(cp);
     const uint32_t ap = as_u32(__builtin_elementwise_max(c, pk_const(0, 0) - c));
     const uint4 t = qt[4 * ROW + k];
-    const uint32_t l0 = mad_u16_lo(ap, t.x, t.y) >> 20;
-    const uint32_t l1 = mad_u16_hi(ap, t.x, t.z) >> 20;
-    const uint32_t lv = l0 | (l1 << 16);
+    // both >> 20 at once: the upper halves of the two sums as a pair, then a packed >> 4
+    const u16x2 tops = __builtin_bit_cast(u16x2, pk_top(mad_u16_lo(ap, t.x, t.y), mad_u16_hi(ap, t.x, t.z)));
+    const uint32_t lv = __builtin_bit_cast(uint32_t, tops >> u16x2{4, 4});
     ent[k] = (cp & 0x80008000u) | lv;
     // non-zero flags: both at once (packed min), each dropped at its zig-zag position of the
     // 16-bit mask of its quarter by one multiply-add (every position is written exactly once)
@@ -470,20 +472,24 @@ __device__ __forceinline__ void unpack_px8(const ScanArgs& a, const uint32_t* w,
 // All sums are the reference's, modulo 2^32; the int16 results are read off the upper halves.
 constexpr uint32_t kLumaRG = 19595u | (38469u << 16);
 constexpr uint32_t kLumaRound = static_cast<uint32_t>(32768 - (128 << 16));
-// luma of pixels 2j and 2j + 1 as an int16 pair
+// luma of pixels 2j and 2j + 1 as an int16 pair; `swapped`: (2j + 1, 2j), the slot order of odd pairs
 __device__ __forceinline__ uint32_t luma_pair(uint32_t rg0, uint32_t rg1, uint32_t bbj, uint32_t k7471,
-                                              uint32_t rnd) {
+                                              uint32_t rnd, bool swapped) {
   const uint32_t y0 = udot2(rg0, kLumaRG, mad_u16_lo(bbj, k7471, rnd));
   const uint32_t y1 = udot2(rg1, kLumaRG, mad_u16_hl(bbj, k7471, rnd));
-  return pk_top(y0, y1);
+  return swapped ? pk_top(y1, y0) : pk_top(y0, y1);
 }
-// 32-bit Cb / Cr sums (before the final shift) of one (R | G << 16, B) triple; rnd = rounding term
-__device__ __forceinline__ uint32_t cb_sum(uint32_t RG, uint32_t B, uint32_t rnd) {
-  return sdot2u(RG, -11059, -21709, (B << 15) + rnd);
+// 32-bit Cb / Cr sums (before the final shift) from R | G << 16 and a PAIR of blue terms b | b' << 16
+// (src/colors_rgb.cc: Cb = -11059 R - 21709 G + 32768 B, Cr = 32768 R - 27439 G - 5329 B, + rounding;
+// everything modulo 2^32).  wb / wb': 1 for the blue terms that count (both for a 2x2 sum whose
+// blue halves were added pairwise, one of them for a single pixel).
+template <int WB0, int WB1>
+__device__ __forceinline__ uint32_t cb_sum(uint32_t RG, uint32_t BB, uint32_t rnd) {
+  return sdot2u(RG, -11059, -21709, udot2(BB, (WB0 ? 32768u : 0u) | (WB1 ? 32768u << 16 : 0u), rnd));
 }
-__device__ __forceinline__ uint32_t cr_sum(uint32_t RG, uint32_t B, uint32_t k32768, uint32_t rnd) {
-  const uint32_t GB = __builtin_amdgcn_perm(B, RG, 0x05040302u);     // G | B << 16
-  return sdot2u(GB, -27439, -5329, mad_u16_lo(RG, k32768, rnd));
+template <int WB0, int WB1>
+__device__ __forceinline__ uint32_t cr_sum(uint32_t RG, uint32_t BB, uint32_t k32768, uint32_t rnd) {
+  return sdot2u(BB, WB0 ? -5329 : 0, WB1 ? -5329 : 0, sdot2u(RG, 0, -27439, mad_u16_lo(RG, k32768, rnd)));
 }
 
 // 8 level-shifted samples of an 8-bit plane (sample pitch `step` bytes), clamped coordinates:

@@ -201,7 +201,7 @@ void digest_tables(const sjpeg_hip_scan_tables* t, DevTables* d) {
 template <int KIND, int SRC>
 int launch_scan_src(int mode, dim3 grid, hipStream_t st, const ScanArgs& a) {
   static const int kLdsPad = getenv("SJPEG_HIP_LDS_PAD") ? atoi(getenv("SJPEG_HIP_LDS_PAD")) : 0;  // occupancy experiments
-  const int lds = ((KIND == kKindStats || KIND == kKindStatsTrellis) ? kLdsBytesStats : kLdsBytes) + kLdsPad;
+  const int lds = kLdsPad;                        // (the kernel's own LDS is a static array)
   switch (mode) {
     case SJPEG_HIP_YUV420:
       hipLaunchKernelGGL((scan_segments<SJPEG_HIP_YUV420, KIND, SRC>), grid, dim3(kScanThreads), lds, st, a);

@@ -35,7 +35,9 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
   using G = Geo<MODE>;
   constexpr int BPM = G::kBpm;
   constexpr int PX = G::kMcuPx;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  // static, not `extern __shared__`: the address of a dynamic block is resolved after instruction
+  // selection and leaves a `+ 0` in ~65 address computations of this kernel
+  __shared__ __attribute__((aligned(16))) unsigned char smem[(KIND == kKindStats) ? kLdsBytesStats : kLdsBytes];
   uint32_t* const win = reinterpret_cast<uint32_t*>(smem + kOffWin);
   uint4* const lq = reinterpret_cast<uint4*>(smem + kOffQ);
   uint32_t* const lac = reinterpret_cast<uint32_t*>(smem + kOffAc);
@@ -188,24 +190,24 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
           const int row = (yp & 3) * 2;
           unsigned char* ys = smem + (ml * BPM + k) * kSlotBytes + row * 16;
           *reinterpret_cast<uint4*>(ys) =
-              make_uint4(pack16(ya[0], ya[1]), pack16(ya[2], ya[3]), pack16(ya[4], ya[5]), pack16(ya[6], ya[7]));
+              make_uint4(pack16(ya[0], ya[1]), pack16(ya[3], ya[2]), pack16(ya[4], ya[5]), pack16(ya[7], ya[6]));
           *reinterpret_cast<uint4*>(ys + 16) =
-              make_uint4(pack16(yb[0], yb[1]), pack16(yb[2], yb[3]), pack16(yb[4], yb[5]), pack16(yb[6], yb[7]));
+              make_uint4(pack16(yb[0], yb[1]), pack16(yb[3], yb[2]), pack16(yb[4], yb[5]), pack16(yb[7], yb[6]));
           unsigned char* us = smem + (ml * BPM + 4) * kSlotBytes + yp * 16 + xs * 8;
-          *reinterpret_cast<uint2*>(us) = make_uint2(pack16(U[0], U[1]), pack16(U[2], U[3]));
-          *reinterpret_cast<uint2*>(us + kSlotBytes) = make_uint2(pack16(V[0], V[1]), pack16(V[2], V[3]));
+          *reinterpret_cast<uint2*>(us) = make_uint2(pack16(U[0], U[1]), pack16(U[3], U[2]));
+          *reinterpret_cast<uint2*>(us + kSlotBytes) = make_uint2(pack16(V[0], V[1]), pack16(V[3], V[2]));
         } else {
           unsigned char* ys = smem + (ml * BPM) * kSlotBytes + yp * 16;
           *reinterpret_cast<uint4*>(ys) =
-              make_uint4(pack16(ya[0], ya[1]), pack16(ya[2], ya[3]), pack16(ya[4], ya[5]), pack16(ya[6], ya[7]));
+              make_uint4(pack16(ya[0], ya[1]), pack16(ya[3], ya[2]), pack16(ya[4], ya[5]), pack16(ya[7], ya[6]));
           if (MODE == SJPEG_HIP_YUV444) {
             int uv[8], vv[8];
             fetch_plane(a.plane[1] + frame * a.frame_stride[1], a.row_stride[1], 1, a.W, a.H, x0, y0, 8, uv);
             fetch_plane(a.plane[2] + frame * a.frame_stride[2], a.row_stride[2], 1, a.W, a.H, x0, y0, 8, vv);
             *reinterpret_cast<uint4*>(ys + kSlotBytes) =
-                make_uint4(pack16(uv[0], uv[1]), pack16(uv[2], uv[3]), pack16(uv[4], uv[5]), pack16(uv[6], uv[7]));
+                make_uint4(pack16(uv[0], uv[1]), pack16(uv[3], uv[2]), pack16(uv[4], uv[5]), pack16(uv[7], uv[6]));
             *reinterpret_cast<uint4*>(ys + 2 * kSlotBytes) =
-                make_uint4(pack16(vv[0], vv[1]), pack16(vv[2], vv[3]), pack16(vv[4], vv[5]), pack16(vv[6], vv[7]));
+                make_uint4(pack16(vv[0], vv[1]), pack16(vv[3], vv[2]), pack16(vv[4], vv[5]), pack16(vv[7], vv[6]));
           }
         }
         continue;
@@ -218,21 +220,22 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
         uint32_t ya[4], yb[4], us32[4], vs32[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-          ya[c] = luma_pair(rg0[2 * c], rg0[2 * c + 1], bb0[c], k7471, kLumaRound);
-          yb[c] = luma_pair(rg1[2 * c], rg1[2 * c + 1], bb1[c], k7471, kLumaRound);
-          // 2x2 sums: halves stay below 1021, plain 32-bit adds never carry across
+          // (slot order: the second and fourth pair of a row are stored with their halves exchanged)
+          ya[c] = luma_pair(rg0[2 * c], rg0[2 * c + 1], bb0[c], k7471, kLumaRound, c & 1);
+          yb[c] = luma_pair(rg1[2 * c], rg1[2 * c + 1], bb1[c], k7471, kLumaRound, c & 1);
+          // 2x2 sums: halves stay below 1021, plain 32-bit adds never carry across; the two blue
+          // halves of BB are added by the dot products themselves
           const uint32_t RG = (rg0[2 * c] + rg0[2 * c + 1]) + (rg1[2 * c] + rg1[2 * c + 1]);
           const uint32_t BB = bb0[c] + bb1[c];
-          const uint32_t B = (BB & 0xffffu) + (BB >> 16);
-          us32[c] = cb_sum(RG, B, 32768u << 2);
-          vs32[c] = cr_sum(RG, B, k32768, 32768u << 2);
+          us32[c] = cb_sum<1, 1>(RG, BB, 32768u << 2);
+          vs32[c] = cr_sum<1, 1>(RG, BB, k32768, 32768u << 2);
         }
         // (sum >> 16) >> 2 == sum >> 18 (floor of floor)
         const s16x2 two = pk_const(2, 2);
         const uint32_t u01 = as_u32(as_pk(pk_top(us32[0], us32[1])) >> two);
-        const uint32_t u23 = as_u32(as_pk(pk_top(us32[2], us32[3])) >> two);
+        const uint32_t u23 = as_u32(as_pk(pk_top(us32[3], us32[2])) >> two);
         const uint32_t v01 = as_u32(as_pk(pk_top(vs32[0], vs32[1])) >> two);
-        const uint32_t v23 = as_u32(as_pk(pk_top(vs32[2], vs32[3])) >> two);
+        const uint32_t v23 = as_u32(as_pk(pk_top(vs32[3], vs32[2])) >> two);
         const int k = (yp >> 2) * 2 + xs;
         const int row = (yp & 3) * 2;
         unsigned char* ys = smem + (ml * BPM + k) * kSlotBytes + row * 16;
@@ -245,11 +248,13 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
         uint32_t yv[4], uv[4], vv[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-          yv[c] = luma_pair(rg0[2 * c], rg0[2 * c + 1], bb0[c], k7471, kLumaRound);
+          yv[c] = luma_pair(rg0[2 * c], rg0[2 * c + 1], bb0[c], k7471, kLumaRound, c & 1);
           if (MODE == SJPEG_HIP_YUV444) {
-            const uint32_t b0 = bb0[c] & 0xffffu, b1 = bb0[c] >> 16;
-            uv[c] = pk_top(cb_sum(rg0[2 * c], b0, 32768u), cb_sum(rg0[2 * c + 1], b1, 32768u));
-            vv[c] = pk_top(cr_sum(rg0[2 * c], b0, k32768, 32768u), cr_sum(rg0[2 * c + 1], b1, k32768, 32768u));
+            const uint32_t u0 = cb_sum<1, 0>(rg0[2 * c], bb0[c], 32768u), u1 = cb_sum<0, 1>(rg0[2 * c + 1], bb0[c], 32768u);
+            const uint32_t v0 = cr_sum<1, 0>(rg0[2 * c], bb0[c], k32768, 32768u);
+            const uint32_t v1 = cr_sum<0, 1>(rg0[2 * c + 1], bb0[c], k32768, 32768u);
+            uv[c] = (c & 1) ? pk_top(u1, u0) : pk_top(u0, u1);
+            vv[c] = (c & 1) ? pk_top(v1, v0) : pk_top(v0, v1);
           }
         }
         unsigned char* ys = smem + (ml * BPM) * kSlotBytes + yp * 16;
@@ -296,7 +301,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
     any_ac = t.w;
   }
   if (!REPLAY) {
-  // rows as packed int16 pairs, straight from the slot: p[r][c] = (s[r][2c], s[r][2c+1])
+  // rows as packed int16 pairs, straight from the slot, in slot order: (s0,s1) (s3,s2) (s4,s5) (s7,s6)
   uint32_t p[8][4];
 #pragma unroll
   for (int r = 0; r < 8; ++r) {
@@ -838,7 +843,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
   // Code words come from the merged table (code << n | total length << 27), indexed by clz(level)
   // and run, so a symbol costs two LDS reads and about thirty simple instructions.
   const uint32_t acm_base = static_cast<uint32_t>(kOffAcm) - 22u * 64u;   // row = clz - 22, 64 bytes per row
-  typedef int16_t __attribute__((may_alias)) i16_alias2;
+  typedef uint16_t __attribute__((may_alias)) u16_alias2;
   auto walk_lean = [&](uint32_t unit, uint4 bt, uint32_t& rec_out, uint32_t& tail_out) {
     const uint32_t blk = unit & 255u, q = unit >> 8;
     const uint32_t slot_off = blk * kSlotBytes;
@@ -884,14 +889,14 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
     while (m) {
       const int i = __builtin_ctz(m);
       m &= m - 1u;
-      const int e = *reinterpret_cast<const i16_alias2*>(smem + wp0 + 2u * static_cast<uint32_t>(i));   // sign-extended: ds_read_i16
+      const uint32_t e = *reinterpret_cast<const u16_alias2*>(smem + wp0 + 2u * static_cast<uint32_t>(i));
       const uint32_t run = static_cast<uint32_t>(i - prevl);      // 0 .. 15
       prevl = i + 1;
-      const uint32_t mag = static_cast<uint32_t>(e) & 0x7fffu;    // 1 .. 1023
-      uint32_t nl;                                                 // 32 - n
-      asm("v_ffbh_u32 %0, %1" : "=v"(nl) : "v"(mag));
+      const uint32_t mag = e & 0x7fffu;                            // 1 .. 1023
+      const uint32_t nl = static_cast<uint32_t>(__builtin_clz(mag));   // 32 - n (mag != 0: a bare v_ffbh_u32)
       const uint32_t ones = 0xffffffffu >> nl;
-      const uint32_t sgn = static_cast<uint32_t>(e >> 31);
+      uint32_t sgn;                                // bit 15 over the whole word (asm: the builtin is turned into compare + select)
+      asm("v_bfe_i32 %0, %1, 15, 1" : "=v"(sgn) : "v"(e));
       const uint32_t cw = *reinterpret_cast<const uint32_t*>(smem + ((tb + nl * 64u) + run * 4u));
       append((cw & 0x07ffffffu) | (mag ^ (ones & sgn)), cw >> 27);
     }
