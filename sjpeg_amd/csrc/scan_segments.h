@@ -873,6 +873,8 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
       nzrl = static_cast<uint32_t>(__builtin_ctz(m) - prevl) >> 4;
       prevl += static_cast<int>(nzrl << 4);
     }
+    // (the two code words the end of the part may need: fetched here, under the symbols' round trips)
+    const uint32_t eob = ac[0x00], zrl = ac[0xf0];
     auto append = [&](uint32_t bits, uint32_t nb) {                  // 1 <= nb <= 27
       const uint32_t t = fill + nb;
       const uint32_t s5 = t & 31u;
@@ -886,23 +888,51 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
       }
       fill = s5;
     };
-    while (m) {
-      const int i = __builtin_ctz(m);
-      m &= m - 1u;
-      const uint32_t e = *reinterpret_cast<const u16_alias2*>(smem + wp0 + 2u * static_cast<uint32_t>(i));
-      const uint32_t run = static_cast<uint32_t>(i - prevl);      // 0 .. 15
-      prevl = i + 1;
+    // Software pipeline over the symbols, so that no LDS round trip is left in the dependent chain of
+    // a symbol: while symbol k is appended, the code word of symbol k + 1 and the entry of symbol
+    // k + 2 are in flight.  (Reading an entry earlier than the in-place argument assumes is always
+    // safe; behind the last symbol the fetch goes to position 16, the first bytes of the next
+    // quarter, and is not used.)
+    auto entry_at = [&](int pos) {
+      return static_cast<uint32_t>(*reinterpret_cast<const u16_alias2*>(smem + wp0 + 2u * static_cast<uint32_t>(pos)));
+    };
+    // first half of a symbol: its level bits and the address of its merged code word
+    auto stage = [&](int pos, uint32_t e, uint32_t& lv, uint32_t& cw_at) {
+      const uint32_t run = static_cast<uint32_t>(pos - prevl);      // 0 .. 15
+      prevl = pos + 1;
       const uint32_t mag = e & 0x7fffu;                            // 1 .. 1023
       const uint32_t nl = static_cast<uint32_t>(__builtin_clz(mag));   // 32 - n (mag != 0: a bare v_ffbh_u32)
       const uint32_t ones = 0xffffffffu >> nl;
       uint32_t sgn;                                // bit 15 over the whole word (asm: the builtin is turned into compare + select)
       asm("v_bfe_i32 %0, %1, 15, 1" : "=v"(sgn) : "v"(e));
-      const uint32_t cw = *reinterpret_cast<const uint32_t*>(smem + ((tb + nl * 64u) + run * 4u));
-      append((cw & 0x07ffffffu) | (mag ^ (ones & sgn)), cw >> 27);
+      lv = mag ^ (ones & sgn);
+      cw_at = (tb + nl * 64u) + run * 4u;
+    };
+    if (m) {
+      int i = __builtin_ctz(m);
+      uint32_t e = entry_at(i);
+      m &= m - 1u;
+      int i_next = __builtin_ctz(m | 0x10000u);
+      uint32_t e_next = entry_at(i_next);
+      uint32_t lv, cw_at;
+      stage(i, e, lv, cw_at);
+      uint32_t cw = *reinterpret_cast<const uint32_t*>(smem + cw_at);
+      while (m) {                                  // (i_next, e_next) is a symbol
+        m &= m - 1u;
+        const int i_after = __builtin_ctz(m | 0x10000u);
+        const uint32_t e_after = entry_at(i_after);
+        uint32_t lv_next, cw_at_next;
+        stage(i_next, e_next, lv_next, cw_at_next);
+        const uint32_t cw_next = *reinterpret_cast<const uint32_t*>(smem + cw_at_next);
+        append((cw & 0x07ffffffu) | lv, cw >> 27);
+        cw = cw_next; lv = lv_next;
+        i_next = i_after; e_next = e_after;
+      }
+      append((cw & 0x07ffffffu) | lv, cw >> 27);
     }
-    if (above == 0u && prevl + static_cast<int>(sh) <= 63) { const uint32_t eob = ac[0x00]; append(eob >> 16, eob & 0xffu); }
+    if (above == 0u && prevl + static_cast<int>(sh) <= 63) append(eob >> 16, eob & 0xffu);
     const uint32_t len = ((wp - wp0) << 3) + fill;
-    const uint32_t zl = ac[0xf0] & 0xffu;
+    const uint32_t zl = zrl & 0xffu;
     ulen[4 * blk + q] = static_cast<uint16_t>(len + nzrl * zl);
     rec_out = unit | (31u << 10) | (nzrl << 15) | (len << 17) | (1u << 27) | (b_tbl << 28);
     tail_out = acc;
