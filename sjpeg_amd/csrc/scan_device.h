@@ -93,8 +93,10 @@ constexpr int kOffTlen = kOffWin + 1152;                        // uint8[2][256]
 constexpr int kPartLens = 576;                                  // u16 [256][4]: bits per part (bytes 2304..4351)
 constexpr int kSortHist = 1100;                                 // u32 [32]: the sort's bins (bytes 4400..4527)
 constexpr int kPartList = 1168;                                 // u16 [1024]: block | quarter << 8 (bytes 4672..6719)
+constexpr int kDcVals = 1680;                                   // i32 [256]: quantized DC values, for the prediction (bytes 6720..7743)
 static_assert(kPartLens * 4 >= 1664 && kSortHist >= kPartLens + 512 && kPartList >= kSortHist + 32 &&
-              kPartList + 512 <= kWinWords, "bookkeeping behind the tables, inside the window");
+              kDcVals >= kPartList + 512 && kDcVals + kScanThreads <= kWinWords,
+              "bookkeeping behind the tables, inside the window");
 constexpr int kOffAc = kOffWin + kWinWords * 4 + 16;            // +1 spare word (16 B keeps alignment)
 constexpr int kOffAcm = kOffAc + 2 * 256 * 4;                   // uint32[2][10][16]: merged code words of the lean walk
 constexpr int kOffZrl = kOffAcm + 2 * 160 * 4;                  // uint4[2][4]: ZRL patterns

@@ -609,9 +609,12 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
   prio_stress<SJPEG_HIP_PRIO_STRESS>(1);
 #endif
   // ---- P3: entropy coding ----------------------------------------------------------------
-  // DC prediction (src/entropy.cc:133-150) through the 16 spare bytes of each slot.
+  // DC prediction (src/entropy.cc:133-150) through an array in the idle bit window; the 16 spare
+  // bytes of each slot (its tail) take what the block's parts need to know: masks, DC word, and what
+  // the masks say about every quarter (below).
   uint32_t* const tail = reinterpret_cast<uint32_t*>(slot + 128);
-  tail[3] = static_cast<uint32_t>(dc_val);
+  uint32_t* const dcv = win + kDcVals;
+  dcv[tid] = static_cast<uint32_t>(dc_val);
   // (sort bookkeeping that aliases nothing still in use is cleared under the same barrier)
   RACE_POINT(2);
   // The counting sort of the parts (below) starts here: the bins were cleared when the tables were
@@ -639,7 +642,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
     else prev = tid - BPM;
     const bool prev_in_halo = prev < BPM;
     if (emits && !(prev_in_halo && !halo)) {
-      pred = static_cast<int>(reinterpret_cast<const uint32_t*>(smem + prev * kSlotBytes + 128)[3]);
+      pred = static_cast<int>(dcv[prev]);
     }
   }
   uint32_t dc_word = 0;                            // dc_len << 24 | dc_bits (<= 22); 0 = emits nothing
@@ -654,7 +657,24 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
   // bit 29: the block takes the checked walk; bit 30: chroma tables (read by whoever codes a part of it)
   unsafe = (any_ac & ldc[24 + tbl]) != 0u ? 1u : 0u;
   dc_word |= (unsafe << 29) | (static_cast<uint32_t>(tbl) << 30);
-  tail[0] = nz_lo; tail[1] = nz_hi; tail[2] = dc_word;   // (the predictors live in tail[3])
+  // What a part's walk would otherwise work out of the two masks with its quarter as a run-time
+  // value (a dozen selects): per quarter q one byte = the run in front of its first symbol, ZRLs
+  // included (6 bits; the walk splits it into ZRL count and run), and bit 6 = "this part carries the
+  // EOB" (nothing non-zero above the quarter, and position 63 is zero).  Here q is a constant.
+  uint32_t part_info = 0;
+  if (KIND == kKindEncode) {
+    const uint32_t p1 = 32u - static_cast<uint32_t>(__clz(nzq[0] | 1u));            // position after the last non-zero below quarter 1 (1 = none)
+    const uint32_t p2 = 32u - static_cast<uint32_t>(__clz(nz_lo | 1u));
+    const uint32_t p3 = nzq[2] != 0u ? 64u - static_cast<uint32_t>(__clz(nzq[2])) : p2;
+    const uint32_t r0 = static_cast<uint32_t>(__builtin_ctz(nzq[0] | 0x10000u)) - 1u;
+    const uint32_t r1 = 16u + static_cast<uint32_t>(__builtin_ctz(nzq[1] | 0x10000u)) - p1;
+    const uint32_t r2 = 32u + static_cast<uint32_t>(__builtin_ctz(nzq[2] | 0x10000u)) - p2;
+    const uint32_t r3 = 48u + static_cast<uint32_t>(__builtin_ctz(nzq[3] | 0x10000u)) - p3;
+    const uint32_t e0 = ((nz_lo >> 16) | nz_hi) == 0u ? 0x40u : 0u, e1 = nz_hi == 0u ? 0x40u : 0u;
+    const uint32_t e2 = nzq[3] == 0u ? 0x40u : 0u, e3 = (nzq[3] >> 15) == 0u ? 0x40u : 0u;
+    part_info = ((r0 & 63u) | e0) | (((r1 & 63u) | e1) << 8) | (((r2 & 63u) | e2) << 16) | (((r3 & 63u) | e3) << 24);
+  }
+  *reinterpret_cast<uint4*>(tail) = make_uint4(nz_lo, nz_hi, dc_word, part_info);
 
   uint32_t* const lf = reinterpret_cast<uint32_t*>(smem + kOffStats);   // kKindStats: [2][272], 256 AC then 16 DC
   if (KIND == kKindStats) {
@@ -850,14 +870,10 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
     const uint32_t b_tbl = (bt.z >> 30) & 1u;
     const uint32_t* const ac = lac + b_tbl * 256;
     const uint32_t tb = acm_base + b_tbl * 640u;
-    const uint32_t lo = bt.x, hi = bt.y;
-    const uint32_t mw = (q & 2u) ? hi : lo;
+    const uint32_t mw = (q & 2u) ? bt.y : bt.x;
     uint32_t m = (q & 1u) ? (mw >> 16) : (mw & 0xffffu);           // the part's own 16 positions
-    const uint32_t below_lo = q >= 2u ? lo : (q == 1u ? (lo & 0xffffu) : 0u);
-    const uint32_t below_hi = q == 3u ? (hi & 0xffffu) : 0u;
-    uint32_t prev = below_hi ? 64u - __clz(below_hi) : 32u - __clz(below_lo | 1u);   // position after the previous non-zero (1 = none)
-    const uint32_t above = q == 0u ? ((lo >> 16) | hi) : (q == 1u ? hi : (q == 2u ? (hi >> 16) : 0u));
-    const uint32_t sh = 16u * q;
+    // the block's thread has read the masks for this quarter already (part_info, P3 start)
+    const uint32_t inf = (bt.w >> (8u * q)) & 0x7fu;
     uint32_t acc = 0, fill = 0;                    // bits of the word in the making, left-aligned; their number
     const uint32_t wp0 = slot_off + 32u * q;       // the quarter: 16 entries, then up to 8 words
     uint32_t wp = wp0;                             // byte offset of the next word
@@ -867,12 +883,8 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
     }
     // positions are local to the quarter from here on; the ZRLs of the first run are taken out of it
     // (only the first symbol of a part can have a run of 16 or more, and never in quarter 0)
-    uint32_t nzrl = 0;
-    int prevl = static_cast<int>(prev) - static_cast<int>(sh);       // may be negative
-    if (m) {
-      nzrl = static_cast<uint32_t>(__builtin_ctz(m) - prevl) >> 4;
-      prevl += static_cast<int>(nzrl << 4);
-    }
+    const uint32_t nzrl = (inf >> 4) & 3u;
+    int prevl = __builtin_ctz(m | 0x10000u) - static_cast<int>(inf & 15u);   // local position after the previous non-zero; may be negative
     // (the two code words the end of the part may need: fetched here, under the symbols' round trips)
     const uint32_t eob = ac[0x00], zrl = ac[0xf0];
     auto append = [&](uint32_t bits, uint32_t nb) {                  // 1 <= nb <= 27
@@ -930,7 +942,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
       }
       append((cw & 0x07ffffffu) | lv, cw >> 27);
     }
-    if (above == 0u && prevl + static_cast<int>(sh) <= 63) append(eob >> 16, eob & 0xffu);
+    if (inf & 0x40u) append(eob >> 16, eob & 0xffu);
     const uint32_t len = ((wp - wp0) << 3) + fill;
     const uint32_t zl = zrl & 0xffu;
     ulen[4 * blk + q] = static_cast<uint16_t>(len + nzrl * zl);
