@@ -1,0 +1,14 @@
+import hashlib, sys, os
+sys.path.insert(0, os.getcwd())
+import numpy as np
+import sjpeg_amd as sj
+img = np.fromfile("tests/golden/test128.rgb", np.uint8).reshape(128, 128, 3)
+bad = 0
+n = int(sys.argv[1])
+for i in range(n):
+    got = sj.SjpegCompress(img, 75.0)
+    if got is None or hashlib.md5(got).hexdigest() != "acc8ce8111f5ff4b32b3faa15ad5d994":
+        bad += 1
+        print("MISMATCH at", i, None if got is None else (len(got), hashlib.md5(got).hexdigest()), sj.last_error(), flush=True)
+        if bad > 5: break
+print("c1 loop", n, "bad", bad)
