@@ -1,3 +1,5 @@
+"""BASELINE config C1 (SjpegCompress of tests/golden/test128.rgb: AUTO -> sharp 4:2:0, method 4) repeated in one
+process, every result against the known MD5.  Usage (GPU box, repo root): python tools/c1_loop.py N"""
 import hashlib, sys, os
 sys.path.insert(0, os.getcwd())
 import numpy as np
