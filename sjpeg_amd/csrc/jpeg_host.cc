@@ -6,6 +6,8 @@
 #include <string.h>
 
 #include <algorithm>
+#include <queue>
+#include <vector>
 
 namespace sjpeg_host {
 
@@ -400,74 +402,96 @@ void AdaptSums(const uint32_t hist[64][128], const uint8_t quant[64], const uint
   }
 }
 
-// The float / double half of AnalyseHisto (src/histogram.cc:126-315) on those sums.
+// The float / double half of AnalyseHisto (src/histogram.cc:169-312) on those sums.  The expression
+// of every accumulated term and of the score is the reference's (operation order is normative for
+// the rounding); the structure is this library's: a weighted two-cloud line fit per coefficient
+// position, then one step choice per position.
+namespace {
+
+// Weighted moments of the clouds {step, distortion} and {step, rate} of one coefficient position.
+struct StepFit {
+  double w = 0., x = 0., xx = 0.;            // weights, steps
+  double d = 0., dd = 0., xd = 0.;           // distortion cloud
+  double r = 0., xr = 0.;                    // rate cloud
+  void Add(double weight, double step, double distortion, double rate) {
+    w += weight;
+    x += weight * step;
+    xx += weight * step * step;
+    d += weight * distortion;
+    dd += weight * distortion * distortion;
+    r += weight * rate;
+    xd += weight * distortion * step;
+    xr += weight * rate * step;
+  }
+  double CovDistortion() const { return w * xd - x * d; }
+  double CovRate() const { return w * xr - x * r; }
+  // is distortion a (nearly) linear function of the step?  r^2 >= limit, without the division
+  bool Correlated(double limit) const {
+    const double c = CovDistortion();
+    return !(c * c < limit * (w * xx - x * x) * (w * dd - d * d));
+  }
+};
+
+struct StepCosts {                            // per candidate step of one position
+  float distortion[kQSize];                   // FLT_MAX: not a candidate
+  float rate[kQSize];
+};
+
+}  // namespace
+
 void AdaptDecide(const int64_t sums[2][64][kAdaptDeltas][2], const int32_t totlast[2][64][2], int nb_comps,
                  uint8_t quant[2][64], int qdelta_max_luma, int qdelta_max_chroma) {
-  const double r_limit = 0.5;                       // kCorrelationThreshold
+  constexpr double kMinCorrelation = 0.5, kMinDensity = 0.5, kFallbackLambda = 0x80;
+  constexpr uint64_t kNeverTouched = 0x103ull;      // DC and its two neighbours
+  static thread_local StepCosts costs[64];
   for (int idx = (nb_comps > 1 ? 1 : 0); idx >= 0; --idx) {
-    const int delta_max = ((idx == 0) ? qdelta_max_luma : qdelta_max_chroma) - kQDeltaMin;
-    static thread_local float sizes[64][kQSize];
-    static thread_local float distortions[64][kQSize];
-    double num = 0., den = 0.;
-    uint64_t omit = 0x103ull;                       // DC and its two neighbours are never touched
+    uint64_t live = ~kNeverTouched;                 // positions that take part
+    double slope_distortion = 0., slope_rate = 0.;  // summed over the live positions
     for (int pos = 0; pos < 64; ++pos) {
-      if (omit & (1ull << pos)) continue;
-      const int total = totlast[idx][pos][0], last = totlast[idx][pos][1];
-      if (total < 0.5 * last) {                     // kDensityThreshold
-        omit |= 1ull << pos;
+      if (!((live >> pos) & 1u)) continue;
+      if (totlast[idx][pos][0] < kMinDensity * totlast[idx][pos][1]) {   // sparse histogram
+        live &= ~(1ull << pos);
         continue;
       }
-      double sw = 0., sx = 0., sxx = 0., syy1 = 0., sy1 = 0., sxy1 = 0., sy2 = 0., sxy2 = 0.;
-      for (int delta = 0; delta < kQSize; ++delta) {
-        if (sums[idx][pos][delta][1] != INT64_MIN) {
-          const double bsum = static_cast<double>(sums[idx][pos][delta][0]);
-          const double dsum = static_cast<double>(sums[idx][pos][delta][1]);
-          distortions[pos][delta] = static_cast<float>(dsum);
-          sizes[pos][delta] = static_cast<float>(bsum);
-          const double w = kDeltaWeight[delta];
-          if (w > 0.) {
-            const double x = static_cast<double>(delta + kQDeltaMin);
-            sw += w;
-            sx += w * x;
-            sxx += w * x * x;
-            sy1 += w * dsum;
-            syy1 += w * dsum * dsum;
-            sy2 += w * bsum;
-            sxy1 += w * dsum * x;
-            sxy2 += w * bsum * x;
-          }
-        } else {
-          distortions[pos][delta] = FLT_MAX;
-          sizes[pos][delta] = 0;
+      StepFit fit;
+      StepCosts& c = costs[pos];
+      for (int k = 0; k < kQSize; ++k) {
+        const int64_t* const s = sums[idx][pos][k];
+        if (s[1] == INT64_MIN) {                    // quantizer out of range
+          c.distortion[k] = FLT_MAX;
+          c.rate[k] = 0;
+          continue;
         }
+        const double rate = static_cast<double>(s[0]), distortion = static_cast<double>(s[1]);
+        c.distortion[k] = static_cast<float>(distortion);
+        c.rate[k] = static_cast<float>(rate);
+        if (kDeltaWeight[k] > 0.) fit.Add(kDeltaWeight[k], static_cast<double>(k + kQDeltaMin), distortion, rate);
       }
-      const double cov_xy1 = sw * sxy1 - sx * sy1;
-      if (cov_xy1 * cov_xy1 < r_limit * (sw * sxx - sx * sx) * (sw * syy1 - sy1 * sy1)) {
-        omit |= 1ull << pos;
+      if (!fit.Correlated(kMinCorrelation)) {
+        live &= ~(1ull << pos);
         continue;
       }
-      num += cov_xy1;
-      den += sw * sxy2 - sx * sy2;
+      slope_distortion += fit.CovDistortion();
+      slope_rate += fit.CovRate();
     }
-    double lambda = 0x80;                           // HLAMBDA
-    if (num > 1000. && den < -10.) {
-      lambda = -num / den;
+    // lambda = -d(distortion) / d(rate) around the current matrix, if the fit is well conditioned
+    double lambda = kFallbackLambda;
+    if (slope_distortion > 1000. && slope_rate < -10.) {
+      lambda = -slope_distortion / slope_rate;
       if (lambda < 1.) lambda = 1.;
     }
+    const int last_step = ((idx == 0) ? qdelta_max_luma : qdelta_max_chroma) - kQDeltaMin;
     for (int pos = 0; pos < 64; ++pos) {
-      if (omit & (1ull << pos)) continue;
-      float best_score = FLT_MAX;
-      int best_dq = 0;
-      for (int delta = 0; delta <= delta_max; ++delta) {
-        if (distortions[pos][delta] < FLT_MAX) {
-          const float score = distortions[pos][delta] + lambda * sizes[pos][delta];
-          if (score < best_score) {
-            best_score = score;
-            best_dq = delta + kQDeltaMin;
-          }
-        }
+      if (!((live >> pos) & 1u)) continue;
+      const StepCosts& c = costs[pos];
+      float best = FLT_MAX;
+      int step = 0;
+      for (int k = 0; k <= last_step; ++k) {
+        if (!(c.distortion[k] < FLT_MAX)) continue;
+        const float score = c.distortion[k] + lambda * c.rate[k];
+        if (score < best) { best = score; step = k + kQDeltaMin; }
       }
-      quant[idx][pos] = static_cast<uint8_t>(quant[idx][pos] + best_dq);
+      quant[idx][pos] = static_cast<uint8_t>(quant[idx][pos] + step);
     }
   }
 }
@@ -480,62 +504,106 @@ void AdaptQuantMatrices(const uint32_t hist[2][64][128], int nb_comps, uint8_t q
   AdaptDecide(sums, totlast, nb_comps, quant, qdelta_max_luma, qdelta_max_chroma);
 }
 
+// Optimised Huffman table for one alphabet (what src/entropy.cc:254-430 produces): code lengths from
+// Huffman's merging with a reserved leaf of weight 1 behind the real symbols (it ends up with the
+// all-ones code, which JPEG forbids for real symbols), the length histogram limited to 16 bits
+// (T.81 K.2), symbols listed by (length, value).  The reference keeps ties out of the merge order with
+// a combined key (weight << 9 | id), a merged node inheriting the id of its heavier child: the same
+// strict order is used here, on an explicit tree with a priority queue.
+namespace {
+
+struct TreeNode {
+  uint64_t weight;
+  int id;                                     // leaf: symbol value; inner node: id of its heavier child
+  int parent;                                 // index into the node array, -1 for the root
+};
+
+struct LighterFirst {                         // priority_queue keeps the LARGEST on top: invert
+  const std::vector<TreeNode>* nodes;
+  bool operator()(int a, int b) const {
+    const TreeNode& x = (*nodes)[a];
+    const TreeNode& y = (*nodes)[b];
+    return x.weight != y.weight ? x.weight > y.weight : x.id > y.id;
+  }
+};
+
+// T.81 K.2 (Figure K.3): no code longer than `limit` bits.  count[l] = codes of length l + 1.
+void LimitCodeLengths(uint8_t* count, int longest, int limit) {
+  for (int len = longest; len > limit; --len) {
+    while (count[len - 1] > 0) {
+      int shorter = len - 2;                  // a leaf at least two levels up becomes an inner node
+      while (shorter >= 1 && count[shorter - 1] == 0) --shorter;
+      // (only a histogram that is no prefix code any more gets here: depths beyond 32 bits were
+      // clamped, which takes Fibonacci-like counts over 33+ symbols; the reference reads in front
+      // of its array in that case, src/entropy.cc:396-398)
+      if (shorter < 1) return;
+      count[len - 1] -= 2;                    // a pair of deepest leaves: one moves up one level,
+      count[len - 2] += 1;
+      count[shorter - 1] -= 1;                // the other joins the split leaf one level below it
+      count[shorter] += 2;
+    }
+  }
+}
+
+}  // namespace
+
 void BuildOptimalSpec(const uint32_t* freq, int size, HuffSpec* out) {
-  enum { kMaxBits = 32, kMaxCodeSize = 16 };
-  int codesizes[257], chain[257], chain_end[257];   // chain_end: index of the tail of i's chain
-  uint64_t sorted[257];
-  int nb_syms = 0;
-  for (int i = 0; i < size; ++i) {
-    if (freq[i] > 0) sorted[nb_syms++] = (static_cast<uint64_t>(freq[i]) << 9) | static_cast<uint64_t>(i);
-    codesizes[i] = 0; chain[i] = -1; chain_end[i] = i;
-  }
-  out->nsyms = nb_syms;
-  // decreasing (frequency, symbol): keys are unique, so any correct sort gives the same order
-  std::sort(sorted, sorted + nb_syms, [](uint64_t a, uint64_t b) { return a > b; });
-  // pseudo symbol of lowest frequency: takes the all-ones code, which JPEG forbids
-  sorted[nb_syms++] = (1ull << 9) | static_cast<uint64_t>(size);
-  codesizes[size] = 0; chain[size] = -1; chain_end[size] = size;
-  for (int nb = nb_syms - 1; nb >= 1; --nb) {       // Huffman merging, least frequent pair first
-    const uint64_t s1 = sorted[nb - 1], s2 = sorted[nb];
-    int i = static_cast<int>(s1 & 0x1ff);
-    const int j = static_cast<int>(s2 & 0x1ff);
-    chain[chain_end[i]] = j;
-    chain_end[i] = chain_end[j];
-    for (int t = i; t >= 0; t = chain[t]) ++codesizes[t];
-    const uint64_t merged = s1 + (s2 & ~0x1ffull);
-    int k = nb - 1;
-    while (k > 0 && sorted[k - 1] < merged) { sorted[k] = sorted[k - 1]; --k; }
-    sorted[k] = merged;
-  }
-  uint8_t bits[kMaxBits];
-  memset(bits, 0, sizeof(bits));
-  int max_bits = 0;
-  for (int i = 0; i <= size; ++i) {
-    int s = codesizes[i];
-    if (s > 0) {
-      if (s > kMaxBits) { s = kMaxBits; codesizes[i] = kMaxBits; }
-      ++bits[s - 1];
-      if (s > max_bits) max_bits = s;
-    }
-  }
-  int start[kMaxBits], position = 0;
-  for (int i = 0; i < max_bits; ++i) { start[i] = position; position += bits[i]; }
+  constexpr int kLongest = 32, kLimit = 16;
   memset(out->syms, 0, sizeof(out->syms));
-  for (int sym = 0; sym < size; ++sym) {            // symbols by increasing code length
-    const int s = codesizes[sym];
-    if (s > 0) out->syms[start[s - 1]++] = static_cast<uint8_t>(sym);
+  memset(out->bits, 0, sizeof(out->bits));
+  std::vector<TreeNode> nodes;
+  nodes.reserve(2 * (size + 1));
+  for (int sym = 0; sym < size; ++sym) {
+    if (freq[sym] > 0) nodes.push_back(TreeNode{freq[sym], sym, -1});
   }
-  for (int l = max_bits - 1; l >= kMaxCodeSize; --l) {   // limit to 16 bits (Annex K.2 style)
-    while (bits[l] > 0) {
-      int k = l - 2;
-      while (bits[k] == 0) --k;
-      bits[l] -= 2; bits[l - 1] += 1; bits[k] -= 1; bits[k + 1] += 2;
+  const int used = static_cast<int>(nodes.size());
+  out->nsyms = used;
+  if (used == 0) return;
+  nodes.push_back(TreeNode{1, size, -1});     // the reserved leaf
+  const int leaves = used + 1;
+  {
+    std::priority_queue<int, std::vector<int>, LighterFirst> open(LighterFirst{&nodes});
+    for (int i = 0; i < used; ++i) open.push(i);
+    // (the reserved leaf is not ranked by its key: it is the lighter half of the FIRST merge whatever
+    // the weights, src/entropy.cc:304-305 appends it behind the sorted symbols)
+    for (int light = used; !open.empty(); light = -1) {
+      if (light < 0) {
+        if (open.size() == 1) break;
+        light = open.top(); open.pop();
+      }
+      const int heavy = open.top(); open.pop();
+      const int parent = static_cast<int>(nodes.size());
+      nodes.push_back(TreeNode{nodes[heavy].weight + nodes[light].weight, nodes[heavy].id, -1});
+      nodes[light].parent = nodes[heavy].parent = parent;
+      open.push(parent);
     }
   }
-  max_bits = kMaxCodeSize;
-  while (bits[--max_bits] == 0) {}
-  --bits[max_bits];                                 // drop the pseudo symbol
-  for (int i = 0; i < kMaxCodeSize; ++i) out->bits[i] = bits[i];
+  // depth of every node, root first (a parent is always created after its children)
+  std::vector<int> depth(nodes.size(), 0);
+  for (int i = static_cast<int>(nodes.size()) - 2; i >= 0; --i) depth[i] = depth[nodes[i].parent] + 1;
+  uint8_t count[kLongest];                    // count[l]: leaves with a code of l + 1 bits
+  memset(count, 0, sizeof(count));
+  int length_of[257];
+  for (int i = 0; i <= size; ++i) length_of[i] = 0;
+  int longest = 0;
+  for (int i = 0; i < leaves; ++i) {
+    const int len = depth[i] < kLongest ? depth[i] : kLongest;
+    length_of[nodes[i].id] = len;
+    ++count[len - 1];
+    if (len > longest) longest = len;
+  }
+  // the symbol list: by code length, then by value -- with the lengths of the unlimited tree
+  int fill = 0;
+  for (int len = 1; len <= longest; ++len) {
+    for (int sym = 0; sym < size; ++sym) {
+      if (length_of[sym] == len) out->syms[fill++] = static_cast<uint8_t>(sym);
+    }
+  }
+  LimitCodeLengths(count, longest, kLimit);
+  int last = kLimit;                          // the reserved leaf is the last code of the longest length
+  while (count[last - 1] == 0) --last;
+  --count[last - 1];
+  for (int l = 0; l < kLimit; ++l) out->bits[l] = count[l];
 }
 
 }  // namespace sjpeg_host

@@ -177,6 +177,35 @@ def test_optimal_huffman_matches_oracle(oracle):
                 assert sum(sp.bits) == n and all(b >= 0 for b in sp.bits)
 
 
+def test_optimal_huffman_ties_and_long_codes_match_oracle(oracle):
+    # equal counts everywhere (the merge order is decided by the reference's tie rule, and the reserved
+    # leaf is the lighter half of the first merge whatever its key), and power-of-two counts that make
+    # codes of up to ~20 bits for the 16-bit limiter
+    rng = np.random.RandomState(7)
+    for it in range(60):
+        f = np.zeros((2, 272), np.uint32)
+        kind = it % 4
+        if kind == 0:
+            f[:, :256] = rng.randint(0, 3, (2, 256))
+        elif kind == 1:
+            f[:, :256] = rng.randint(0, 2, (2, 256)) * rng.randint(1, 5, (2, 256))
+        elif kind == 2:
+            f[:, :256] = (rng.randint(0, 4, (2, 256)) == 0) * (1 << rng.randint(0, 20, (2, 256)).astype(np.int64))
+        else:
+            f[:, :256] = rng.randint(0, 1 << 31, (2, 256)) * (rng.randint(0, 8, (2, 256)) == 0)
+        f[:, 256:268] = rng.randint(0, 3, (2, 12))
+        f[:, 256] = 1
+        f[:, 0] = np.maximum(f[:, 0], 1)
+        t = sj.ScanTables()
+        specs = sj.optimize_huffman(f, 1, t)
+        for tbl in range(2):
+            for k, off, size in ((0, 256, 12), (2, 0, 256)):
+                bits, syms, n = oracle.build_optimal(f[tbl, off:off + size], size)
+                sp = specs[k + tbl]
+                assert sp.nsyms == n and list(sp.bits) == [int(b) for b in bits]
+                assert list(sp.syms[:n]) == [int(x) for x in syms][:n]
+
+
 def test_header_with_custom_tables_matches_golden(golden_small, oracle, img128):
     # method-1 golden stream: its header must be reproduced from oracle statistics
     want = golden_small["test128|128x128|420|q75|m1"]
