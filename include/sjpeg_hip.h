@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SJPEG_HIP_ABI_VERSION 14
+#define SJPEG_HIP_ABI_VERSION 15
 
 enum {
   SJPEG_HIP_OK = 0,
@@ -439,6 +439,50 @@ int sjpeg_hip_compact_streams(const void* d_out, size_t out_stride, const uint64
                               void* d_packed, size_t packed_capacity, uint64_t* d_offsets /* nframes + 1 */,
                               void* stream);
 
+/* The exchange itself, for a C / C++ caller with one process per GPU: gathers the packed streams of every
+ * rank (what sjpeg_hip_compact_streams left in d_packed / d_offsets) into the root's d_gathered over RCCL
+ * (xGMI inside a node).  RCCL is resolved at run time (librccl.so.1: the copy already loaded in the
+ * process, e.g. PyTorch's, else the one the loader finds, else /opt/rocm/lib): a process that never
+ * gathers never loads it.
+ *
+ * A communicator is either created here -- rank 0 calls sjpeg_hip_comm_unique_id() and hands the 128 bytes
+ * to the other ranks by whatever means the application has (MPI, a socket, torch.distributed's store),
+ * then every rank calls sjpeg_hip_comm_create() with its device current -- or adopted from an ncclComm_t
+ * the application already owns (sjpeg_hip_comm_adopt; not destroyed with the wrapper).
+ *
+ * sjpeg_hip_gather_streams(), called by every rank with the same frames_per_rank_max, root and
+ * gathered_capacity:
+ *   1. one ncclAllGather of a row of frames_per_rank_max + 2 uint64 per rank: the rank's packed bytes
+ *      (d_offsets[nframes_local], a multiple of 16), its number of frames and its frame sizes (d_sizes,
+ *      zero beyond nframes_local) -> d_rows [world][frames_per_rank_max + 2] on every rank;
+ *   2. ONE small device-to-host read per rank and call: the rows (8 x world x (frames_per_rank_max + 2)
+ *      bytes) -> h_rows, because RCCL's send / receive counts are host values; no per-frame
+ *      synchronisation;
+ *   3. grouped ncclSend / ncclRecv of EXACT lengths (no padding to the largest rank; RCCL has no
+ *      gatherv): rank r's bytes land at d_gathered + h_rank_offsets[r] on the root, in rank order, the
+ *      root's own by a device copy.
+ * h_rows (host, [world][frames_per_rank_max + 2]) and h_rank_offsets (host, [world + 1]) are filled on
+ * every rank; frame k of rank r is at h_rank_offsets[r] + the sum of the 16-aligned sizes of the rank's
+ * earlier frames.  Every rank sees the same rows and therefore takes the same decision: a frame of size
+ * 0 among the frames of some rank (it did not fit its slot), a rank whose packed total is not the sum of
+ * its frames (its d_packed was too small: size it for d_offsets[nframes], e.g. nframes x out_stride), or
+ * a total above gathered_capacity, makes the call return SJPEG_HIP_ECAPACITY on EVERY rank before anything is sent (never a hang).
+ * d_gathered is only used on the root.  Everything is enqueued on `stream`; the host read waits for that
+ * stream, the byte transfers do not.  Returns 0 or SJPEG_HIP_E*. */
+typedef struct sjpeg_hip_comm sjpeg_hip_comm;
+#define SJPEG_HIP_COMM_ID_BYTES 128
+int sjpeg_hip_comm_unique_id(uint8_t id[SJPEG_HIP_COMM_ID_BYTES]);
+int sjpeg_hip_comm_create(const uint8_t id[SJPEG_HIP_COMM_ID_BYTES], int rank, int world, sjpeg_hip_comm** comm);
+int sjpeg_hip_comm_adopt(void* nccl_comm /* ncclComm_t */, sjpeg_hip_comm** comm);
+void sjpeg_hip_comm_destroy(sjpeg_hip_comm* comm);
+int sjpeg_hip_comm_rank(const sjpeg_hip_comm* comm);
+int sjpeg_hip_comm_world(const sjpeg_hip_comm* comm);
+int sjpeg_hip_gather_streams(sjpeg_hip_comm* comm, int root, const void* d_packed, const uint64_t* d_offsets,
+                             const uint64_t* d_sizes, int nframes_local, int frames_per_rank_max,
+                             uint64_t* d_rows /* [world + 1][frames_per_rank_max + 2]: the last row is scratch */,
+                             void* d_gathered, size_t gathered_capacity,
+                             uint64_t* h_rows, uint64_t* h_rank_offsets /* [world + 1] */, void* stream);
+
 /* Duration in milliseconds of the dominant kernel (the fused colour+fDCT+quant+entropy
  * kernel) in the most recent sjpeg_hip_encode_scan() call on this engine, measured with
  * HIP events on the caller's stream.  Timing is recorded only after
@@ -460,7 +504,9 @@ int sjpeg_hip_engine_trim(sjpeg_hip_engine* engine);
 
 /* The host API (include/sjpeg.h) keeps one device context per calling thread: pixel, stream and plane
  * buffers plus an engine, grown on demand.  A context whose cached device memory exceeds
- * SJPEG_HIP_HOST_CACHE_BYTES (environment, default 1 GiB) after a call releases it before returning;
+ * SJPEG_HIP_HOST_CACHE_BYTES (environment, default 1 GiB) after a call that itself needed less than
+ * half of it releases it before returning (a steady stream of frames that need more than the limit
+ * keeps its buffers: set the limit to what the service may hold, not below what one frame needs);
  * sjpeg_hip_host_trim() releases the calling thread's cache now and returns the bytes it held.
  * The host API first codes against an output capacity of half a byte per sample (0.75 B per pixel in
  * 4:2:0) and repeats the frame against sjpeg_hip_frame_bound() if that was too small

@@ -196,19 +196,33 @@ struct DeviceContext {
     if (h_mail) (void)hipHostFree(h_mail);
     sjpeg_hip_engine_destroy(engine);
   }
+  bool ready = false;                                 // every resource below exists
   bool Init() {
-    if (engine != nullptr) return true;
-    const char* env = getenv("SJPEG_HIP_DEVICE");
-    device = env ? atoi(env) : 0;
-    if (sjpeg_hip_engine_create(device, &engine) != 0) return FailHip("sjpeg_hip_engine_create");
-    if (hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) return Fail("hipStreamCreate failed");
-    if (hipMalloc(reinterpret_cast<void**>(&d_size), sizeof(uint64_t)) != hipSuccess) {
+    if (ready) return true;
+    // (a failure leaves what was created to the destructor and is tried again by the next call:
+    // nothing runs on a half-built context -- no NULL stream, no missing mailbox)
+    if (engine == nullptr) {
+      const char* env = getenv("SJPEG_HIP_DEVICE");
+      device = env ? atoi(env) : 0;
+      if (sjpeg_hip_engine_create(device, &engine) != 0) { engine = nullptr; return FailHip("sjpeg_hip_engine_create"); }
+    }
+    if (hipSetDevice(device) != hipSuccess) return Fail("hipSetDevice failed");
+    if (stream == nullptr && hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) {
+      stream = nullptr;
+      return Fail("hipStreamCreate failed");
+    }
+    if (d_size == nullptr && hipMalloc(reinterpret_cast<void**>(&d_size), sizeof(uint64_t)) != hipSuccess) {
+      d_size = nullptr;
       return Fail("hipMalloc(size word) failed");
     }
-    if (hipHostMalloc(reinterpret_cast<void**>(&h_mail), 64 + kMailData + kMailIn, hipHostMallocMapped) != hipSuccess ||
-        hipHostGetDevicePointer(reinterpret_cast<void**>(&d_mail), h_mail, 0) != hipSuccess) {
+    if (h_mail == nullptr && hipHostMalloc(reinterpret_cast<void**>(&h_mail), 64 + kMailData + kMailIn, hipHostMallocMapped) != hipSuccess) {
+      h_mail = nullptr;
       return Fail("hipHostMalloc(mapped mailbox) failed");
     }
+    if (hipHostGetDevicePointer(reinterpret_cast<void**>(&d_mail), h_mail, 0) != hipSuccess) {
+      return Fail("hipHostGetDevicePointer(mapped mailbox) failed");
+    }
+    ready = true;
     return true;
   }
   // stream-ordered copies (device -> host ones wait for the stream: the data is needed right away)
@@ -280,17 +294,32 @@ struct DeviceContext {
     }
     (void)sjpeg_hip_engine_trim(engine);
   }
+  // What the call in progress asked its buffers to hold (the sizes passed to Ensure, grown or not).
+  size_t call_need = 0, call_out_need = 0;
+  void BeginCall() { call_need = 0; call_out_need = 0; }
+  // Over the cache limit (SJPEG_HIP_HOST_CACHE_BYTES, 1 GiB by default) the memory goes back -- but only
+  // when the call that just finished needed less than half of what is held (a very large frame followed
+  // by ordinary ones).  A steady stream of frames that need more than the limit themselves keeps its
+  // buffers: trimming after every call would cost a device synchronisation + hipFree + hipMalloc per frame.
   void TrimIfOver() {
     static const size_t limit = [] {
       const char* v = getenv("SJPEG_HIP_HOST_CACHE_BYTES");
       return v != nullptr ? static_cast<size_t>(strtoull(v, nullptr, 0)) : (static_cast<size_t>(1) << 30);
     }();
-    if (engine != nullptr && CachedBytes() > limit) Trim();
+    if (engine == nullptr) return;
+    const size_t held = CachedBytes();
+    if (held <= limit) return;
+    // (the engine's scratch follows the output capacity: about 3.5 x of it)
+    const size_t scratch = sjpeg_hip_engine_scratch_bytes(engine);
+    const size_t needed = call_need + (scratch < 4 * call_out_need ? scratch : 4 * call_out_need);
+    if (held / 2 > needed) Trim();
   }
   size_t CachedBytes() const {
     return in_cap + out_cap + hist_cap + planes_cap + work_cap + sjpeg_hip_engine_scratch_bytes(engine);
   }
   bool Ensure(void** p, size_t* cap, size_t need) {
+    call_need += need;
+    if (p == &d_out && need > call_out_need) call_out_need = need;
     if (need <= *cap) return true;
     if (*p) (void)hipFree(*p);
     *p = nullptr; *cap = 0;
@@ -421,6 +450,7 @@ bool Encoder::RunImpl() {
     DeviceContext* c;
     ~SyncOnExit() { (void)hipStreamSynchronize(c->stream); c->TrimIfOver(); }
   } sync_on_exit{&ctx};
+  ctx.BeginCall();
   if (hipSetDevice(ctx.device) != hipSuccess) return Fail("hipSetDevice failed");
 
   // pixels -> device, plane by plane.  Rows keep a 16-byte aligned pitch; a bottom-up plane

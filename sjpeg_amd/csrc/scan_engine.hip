@@ -400,6 +400,8 @@ extern "C" {
 int sjpeg_hip_abi_version(void) { return SJPEG_HIP_ABI_VERSION; }
 
 const char* sjpeg_hip_last_error(void) { return g_last_error.c_str(); }
+// (the other translation units of the C-ABI report through the same thread-local text)
+__attribute__((visibility("hidden"))) void sjpeg_hip_internal_set_last_error(const char* msg) { g_last_error = msg ? msg : ""; }
 
 int sjpeg_hip_device_count(void) {
   int n = 0;
@@ -511,7 +513,8 @@ size_t sjpeg_hip_frame_bound(int width, int height, int yuv_mode, size_t header_
   if (!frame_geo(width, height, yuv_mode, &g)) return 0;
   // un-stuffed worst case = slots; stuffing at most doubles it
   const size_t unstuffed = static_cast<size_t>(g.nseg) * g.slot_words * 4;
-  return header_size + 2 * unstuffed + 2 + 64;
+  // (a multiple of 16: the default out_stride of the bindings is what sjpeg_hip_compact_streams accepts)
+  return (header_size + 2 * unstuffed + 2 + 64 + 15) & ~size_t(15);
 }
 
 // profiling only (not in the public header): copies the per-workgroup cycle stamps of the last scan

@@ -383,6 +383,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
     for (int d = 32; d > 0; d >>= 1) e64 += __shfl_xor(e64, d, 64);
     unsigned long long* const we = reinterpret_cast<unsigned long long*>(misc);
     if ((tid & 63) == 0) we[tid >> 6] = e64;
+    RACE_POINT(19);
     __syncthreads();
     if (tid == 0) {
       unsigned long long sum = 0;
@@ -396,7 +397,9 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
     // natural position, histogram of |coefficient| >> 2 (bins < 128), one histogram per
     // quantizer table.  8-bit counters packed four to a word in LDS (a workgroup has at most
     // 252 blocks), flushed as this workgroup's partial; reduce_partials() sums them.
+    RACE_POINT(14);
     __syncthreads();                            // every thread holds its samples: slots are free
+    RACE_POINT(15);
     uint32_t* const lh = reinterpret_cast<uint32_t*>(smem);
     // Bins 0..3 (one word per position) take most of the hits and every lane of a wave hits the
     // SAME word: an LDS atomic serialises those lanes.  Eight replicas of that word, picked by
@@ -405,6 +408,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
     constexpr int kReps = 8;
     uint32_t* const rep = lh + kHistoWords;       // [2][64][kReps]
     for (int i = tid; i < kHistoWords + 2 * 64 * kReps; i += kScanThreads) lh[i] = 0;
+    RACE_POINT(16);
     __syncthreads();
     int acc[8];
     auto bump = [&](int row, const int* ac8) {
@@ -427,6 +431,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
     fdct_row8_pk<26722, 25172, 22654, 19266, 15137, 10426, 5315>(p[5], acc); bump(5, acc);
     fdct_row8_pk<29692, 27969, 25172, 21407, 16819, 11585, 5906>(p[6], acc); bump(6, acc);
     fdct_row8_pk<31521, 29692, 26722, 22725, 17855, 12299, 6270>(p[7], acc); bump(7, acc);
+    RACE_POINT(17);
     __syncthreads();
     if (tid < 128) {                               // fold the replicas into word 0 of their position
       uint32_t sum = 0;
@@ -434,6 +439,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
       for (int r = 0; r < kReps; ++r) sum += rep[tid * kReps + r];
       lh[tid * 32] += sum;
     }
+    RACE_POINT(18);
     __syncthreads();
     uint32_t* const dst = a.partial + (static_cast<size_t>(frame) * a.nseg + seg) * kHistoWords;
     for (int i = tid; i < kHistoWords; i += kScanThreads) dst[i] = lh[i];
@@ -763,6 +769,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
         if (is_last && prev <= 63) atomicAdd(&f[0x00], 1u);
       }
     }
+    RACE_POINT(20);
     __syncthreads();
     uint32_t* const dst = a.partial + (static_cast<size_t>(frame) * a.nseg + seg) * kStatsWords;
     for (int i = tid; i < kStatsWords; i += kScanThreads) dst[i] = lf[i];

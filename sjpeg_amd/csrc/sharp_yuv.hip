@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <mutex>
@@ -46,6 +47,7 @@ struct SharpArgs {
   int16_t* row_uv;                                // [nframes][3][uv_w]: chroma of the row pair in flight
   uint8_t* y; uint8_t* u; uint8_t* v;
   long long y_frame_stride, uv_frame_stride;
+  int stress;                                     // race stress builds only (SJPEG_HIP_ABLATE), else 0
 };
 
 __device__ __forceinline__ uint32_t lin2gamma(const uint32_t* l2g, uint32_t value) {   // :158-171
@@ -124,6 +126,21 @@ __global__ __launch_bounds__(256) void sharp_import(const SharpArgs a) {
   }
 }
 
+// Race stress build (make STRESS=1|2): SHARP_RACE_POINT(n) holds the waves w with (w & 3) == k of the
+// workgroup back at point n (or lets only them run on: bit 7) when SJPEG_HIP_ABLATE is
+// 0x5a000000 | count << 16 | n << 8 | k -- the code of K1's RACE_POINT (scan_segments.h), points 32..47
+// (tools/race_sweep.py).
+#ifdef SJPEG_HIP_PRIO_STRESS
+#define SHARP_RACE_POINT(n) sharp_race_point(a.stress, n)
+__device__ __forceinline__ void sharp_race_point(int code, int n) {
+  if ((code >> 24) == 0x5a && ((code >> 8) & 255) == n && ((((threadIdx.x >> 6) & 3) == (code & 3)) != ((code & 0x80) != 0))) {
+    for (int i = 0; i < ((code >> 16) & 255); ++i) __builtin_amdgcn_s_sleep(127);
+  }
+}
+#else
+#define SHARP_RACE_POINT(n)
+#endif
+
 // ---- the sweeps (:634-668): one workgroup per picture
 __global__ __launch_bounds__(kSweepThreads) void sharp_sweeps(const SharpArgs a) {
   __shared__ uint32_t g2l[kMaxY + 1];
@@ -141,10 +158,12 @@ __global__ __launch_bounds__(kSweepThreads) void sharp_sweeps(const SharpArgs a)
   const int w = a.w, h = a.h, uv_w = a.uv_w;
   const unsigned long long threshold = static_cast<unsigned long long>(3.0 * w * h);
   unsigned long long prev_diff = ~0ull;
+  SHARP_RACE_POINT(32);
   __syncthreads();
   for (int iter = 0; iter < 4; ++iter) {
     unsigned long long diff = 0;
     for (int j = 0; j < h; j += 2) {
+      SHARP_RACE_POINT(33);
       const int ry = j >> 1;
       const int16_t* const cur = best_uv + static_cast<size_t>(ry) * 3 * uv_w;
       const int16_t* const prev = best_uv + static_cast<size_t>(ry > 0 ? ry - 1 : 0) * 3 * uv_w;
@@ -186,7 +205,9 @@ __global__ __launch_bounds__(kSweepThreads) void sharp_sweeps(const SharpArgs a)
 #pragma unroll
         for (int k = 0; k < 3; ++k) row_uv[k * uv_w + c] = static_cast<int16_t>(uv[k]);
       }
+      SHARP_RACE_POINT(34);
       __syncthreads();                              // all neighbours have read this chroma row
+      SHARP_RACE_POINT(35);
       // SharpUpdateRGB (:187-193): the row becomes this sweep's
       for (int c = tid; c < uv_w; c += kSweepThreads) {
 #pragma unroll
@@ -195,6 +216,7 @@ __global__ __launch_bounds__(kSweepThreads) void sharp_sweeps(const SharpArgs a)
           best_uv[o] = static_cast<int16_t>(best_uv[o] + (target_uv[o] - row_uv[k * uv_w + c]));
         }
       }
+      SHARP_RACE_POINT(36);
       __syncthreads();
     }
     // exit test (:660-666): sum of |dW| over the picture
@@ -271,8 +293,10 @@ __global__ __launch_bounds__(kSweepThreads) void sharp_sweeps_fast(const SharpAr
 #pragma unroll
     for (int k = 0; k < 3; ++k) d.tuv[k] = t[k * uv_w + c];
   };
+  SHARP_RACE_POINT(40);
   __syncthreads();
   for (int iter = 0; iter < 4; ++iter) {
+    SHARP_RACE_POINT(41);
     unsigned long long diff = 0;
     RowData now[kFastCols], ahead[kFastCols];
     int nxt[kFastCols][3][3];                       // chroma row ry + 1 (last sweep's values)
@@ -287,9 +311,11 @@ __global__ __launch_bounds__(kSweepThreads) void sharp_sweeps_fast(const SharpAr
         for (int k = 0; k < 3; ++k) above[0][k][c] = static_cast<int16_t>(now[s].uv[k][1]);   // row pair 0: "above" is the row itself
       }
     }
+    SHARP_RACE_POINT(42);
     lds_barrier();
     for (int ry = 0; ry < uv_h; ++ry) {
       const int pp = ry & 1;
+      SHARP_RACE_POINT(43);
       // request what the NEXT row pair needs
 #pragma unroll
       for (int s = 0; s < kFastCols; ++s) {
@@ -349,7 +375,9 @@ __global__ __launch_bounds__(kSweepThreads) void sharp_sweeps_fast(const SharpAr
           }
         }
       }
+      SHARP_RACE_POINT(44);
       lds_barrier();
+      SHARP_RACE_POINT(45);
       // rotate: cur <- next (old values), next <- the row requested above
 #pragma unroll
       for (int s = 0; s < kFastCols; ++s) {
@@ -367,6 +395,7 @@ __global__ __launch_bounds__(kSweepThreads) void sharp_sweeps_fast(const SharpAr
     // what this one stored
     for (int d = 32; d > 0; d >>= 1) diff += __shfl_down(diff, d, 64);
     if ((tid & 63) == 0) red[tid >> 6] = diff;
+    SHARP_RACE_POINT(46);
     __syncthreads();
     if (tid == 0) {
       unsigned long long sum = 0;
@@ -377,6 +406,7 @@ __global__ __launch_bounds__(kSweepThreads) void sharp_sweeps_fast(const SharpAr
     __syncthreads();
     prev_diff = red[0];
     const int sflag = stop;
+    SHARP_RACE_POINT(47);
     __syncthreads();
     if (sflag) break;
   }
@@ -511,6 +541,9 @@ int sjpeg_hip_sharp_yuv(const sjpeg_hip_source* src, int width, int height, int 
   a.w = (width + 1) & ~1; a.h = (height + 1) & ~1; a.uv_w = a.w >> 1; a.uv_h = a.h >> 1;
   a.y = d_y; a.u = d_u; a.v = d_v;
   a.y_frame_stride = y_frame_stride; a.uv_frame_stride = uv_frame_stride;
+#ifdef SJPEG_HIP_PRIO_STRESS
+  if (const char* ab = getenv("SJPEG_HIP_ABLATE")) a.stress = atoi(ab);   // (read per call: the sweep changes it)
+#endif
   if (width <= 4 || height <= 4) {
     hipLaunchKernelGGL(sharp_small, dim3(nframes), dim3(64), 0, st, a);
     return hipGetLastError() == hipSuccess ? 0 : SJPEG_HIP_ERUNTIME;

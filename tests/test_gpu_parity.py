@@ -377,6 +377,25 @@ def test_c5_recompress_default_params(engine, digests):
     assert len(got) == d["size"] and hashlib.md5(got).hexdigest() == d["md5"]
 
 
+def test_c5_end_to_end_4k(engine, digests):
+    """BASELINE config C5 as the reference's CLI runs it (examples/sjpeg.cc:262-286), every step by the
+    product: encode the 4K source at q 92 with default parameters, read ITS quantizer back with
+    SjpegFindQuantizer, recompress the pixels at reduction 90 (SetQuantization + SetLimitQuantization)
+    with default parameters and with method 0 -- three known answers of SURVEY 8c."""
+    import ctypes as C
+    frames = dev(synth.g_struct(3840, 2160))
+    source = sj.encode_device_method(frames, quality=92.0, yuv_mode=1, method=4, engine=engine)[0]
+    d = digests["recompress|source_q92_default"]
+    assert len(source) == d["size"] and hashlib.md5(source).hexdigest() == d["md5"]
+    found = np.zeros((2, 64), np.uint8)
+    assert sj.lib().SjpegFindQuantizer(source, len(source), found.ctypes.data) == d["nq"]
+    assert found.reshape(-1).tolist() == digests["recompress|r90|m0"]["source_quant"]
+    quant = np.clip((found.astype(np.float64) * 100.0 / 90.0 + 0.5).astype(np.int64), 1, 255).astype(np.uint8)
+    for key, method in (("recompress|r90|default", 4), ("recompress|r90|m0", 0)):
+        got = sj.encode_device_method(frames, yuv_mode=1, method=method, engine=engine, quant=quant, min_quant=quant)[0]
+        assert len(got) == digests[key]["size"] and hashlib.md5(got).hexdigest() == digests[key]["md5"], key
+
+
 # ---- other input layouts: BGRA / RGBA / gray / planar YUV / NV12 / NV21 -------------------------
 
 def _random_planes(rng, fmt, w, h):
