@@ -18,7 +18,11 @@ ordered kernels, and `roofline.kernel_ms` the dominant kernel alone.
 Rank 0 prints ONE JSON line.
 * `roofline` prices the dominant kernel (scan_segments) against the HBM read roofline with
   ALGORITHMIC bytes = 3 B/pixel; its duration is measured live with HIP
-  events on the launch stream (engine timing API).  `roofline.valu` is the second roofline the
+  events on the launch stream (engine timing API) with strictly ordered kernels: `frac` is that
+  kernel ALONE; `frac_in_region` = the same bytes / `ms_per_step` / peak, i.e. the whole timed step
+  with the stitch kernels beside the dominant one -- the fraction `value` corresponds to.
+  `engine_scratch_bytes` is what the pipelined mode holds, `engine_scratch_bytes_ordered` what the
+  ordered mode (`ms_per_step_ordered`) needs.  `roofline.valu` is the second roofline the
   kernel actually runs into: VALU instructions per wave (from the committed PMC pass named in
   `source`) x the cycles a wave64 instruction occupies a SIMD, measured live by a
   microbenchmark of the two issue classes (tools/valu_rate.hip has the full table).
@@ -261,17 +265,8 @@ def main():
     sz = sizes.cpu().numpy()
     coded = [bytes(out[k, :int(sz[k])].cpu().numpy()) for k in range(F)]
 
-    piped_scan_ms = None
-    if args.pipelined:                            # K1 under the overlap, then back to ordered calls
-        eng.set_timing(True)
-        acc = []
-        for _ in range(4):                        # K1 of the LAST of four back-to-back steps: under the stitch of the third
-            for _ in range(4):
-                encode()
-            torch.cuda.synchronize()
-            acc.append(eng.last_scan_ms())
-        piped_scan_ms = float(np.mean(acc))
-        eng.set_timing(False)
+    scratch_piped = eng.scratch_bytes()
+    if args.pipelined:                            # back to ordered calls for the per-kernel figures
         eng.set_pipelined(False)
     # ---- dominant-kernel duration, HIP events on the launch stream -------------------------
     eng.set_timing(True)
@@ -340,6 +335,9 @@ def main():
         roof = {"bound": "hbm", "achieved": round(achieved / 1e9, 1), "peak": HBM_PEAK / 1e9,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK, 4), "traffic": traffic,
                 "traffic_source": PMC_SUMMARY if traffic is not None else None,
+                # the same algorithmic bytes over the whole timed step (K1 with the stitch kernels of the
+                # previous step beside it): what the headline `value` corresponds to
+                "frac_in_region": round(algo_bytes / (dt / args.steps) / HBM_PEAK, 4),
                 "kernel": "scan_segments<420>", "kernel_ms": round(scan_avg * 1e3, 4),
                 "all_kernels_ms": round(float(np.mean(total_ms)), 4),
                 "algorithmic_bytes_per_launch": int(algo_bytes),
@@ -369,13 +367,17 @@ def main():
                        "yuv_mode": "420", "parallelism": f"frame-sharded x{world}, no data-path collective"},
             "bit_exact": bool(parity),
             "bytes_per_frame": int(sz[0]),
-            "engine_scratch_bytes": eng.scratch_bytes(),
+            "engine_scratch_bytes": scratch_piped,
             "roofline": roof,
         }
         res["config"]["pipelined"] = bool(args.pipelined)
         res["ms_per_step_ordered"] = round(ordered_ms, 4)
-        if piped_scan_ms is not None:
-            res["roofline"]["kernel_ms_pipelined"] = round(piped_scan_ms, 4)
+        if args.pipelined:                        # what the strictly ordered mode holds (one set of segment buffers)
+            e2 = sj.Engine(local)
+            e2.encode_frames(frames, tables, header, sj.YUV_420, out=outs[0], sizes=sizes_b[0], out_stride=out_stride)
+            torch.cuda.synchronize()
+            res["engine_scratch_bytes_ordered"] = e2.scratch_bytes()
+            e2.close()
         if not parity:
             res["value"] = 0.0
             res["error"] = "output differs from the reference: throughput not counted"

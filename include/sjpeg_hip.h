@@ -477,6 +477,17 @@ int sjpeg_hip_comm_adopt(void* nccl_comm /* ncclComm_t */, sjpeg_hip_comm** comm
 void sjpeg_hip_comm_destroy(sjpeg_hip_comm* comm);
 int sjpeg_hip_comm_rank(const sjpeg_hip_comm* comm);
 int sjpeg_hip_comm_world(const sjpeg_hip_comm* comm);
+/* The two halves of sjpeg_hip_gather_streams() for a root that sizes its buffer from the ACTUAL total:
+ * steps 1-2 (every rank; h_rank_offsets[world] = bytes the root will receive; SJPEG_HIP_ECAPACITY on every
+ * rank for a frame of size 0), then step 3 (every rank; gathered_capacity is checked on the root only, and a
+ * root that passes less than the total it was just told is the one error here that leaves the peers' sends
+ * unmatched -- size the buffer first). */
+int sjpeg_hip_gather_rows(sjpeg_hip_comm* comm, const uint64_t* d_offsets, const uint64_t* d_sizes, int nframes_local,
+                          int frames_per_rank_max, uint64_t* d_rows, uint64_t* h_rows, uint64_t* h_rank_offsets,
+                          void* stream);
+int sjpeg_hip_gather_bytes(sjpeg_hip_comm* comm, int root, const void* d_packed, int frames_per_rank_max,
+                           const uint64_t* h_rows, const uint64_t* h_rank_offsets, void* d_gathered,
+                           size_t gathered_capacity, void* stream);
 int sjpeg_hip_gather_streams(sjpeg_hip_comm* comm, int root, const void* d_packed, const uint64_t* d_offsets,
                              const uint64_t* d_sizes, int nframes_local, int frames_per_rank_max,
                              uint64_t* d_rows /* [world + 1][frames_per_rank_max + 2]: the last row is scratch */,

@@ -256,6 +256,9 @@ EXPORTED_C_SYMBOLS = [
     "sjpeg_hip_engine_last_total_ms", "sjpeg_hip_engine_scratch_bytes", "sjpeg_hip_compact_streams",
     "sjpeg_hip_debug_stream_read", "sjpeg_hip_debug_valu_rate",
     "sjpeg_hip_restart_interval", "sjpeg_hip_header_add_restart", "sjpeg_hip_encode_intervals_src",
+    "sjpeg_hip_comm_unique_id", "sjpeg_hip_comm_create", "sjpeg_hip_comm_adopt", "sjpeg_hip_comm_destroy",
+    "sjpeg_hip_comm_rank", "sjpeg_hip_comm_world", "sjpeg_hip_gather_rows", "sjpeg_hip_gather_bytes",
+    "sjpeg_hip_gather_streams",
 ]
 
 
@@ -296,6 +299,55 @@ def compact_streams(out, sizes, nframes=None, capacity=None, packed=None, offset
     if rc != 0:
         raise SjpegError(f"sjpeg_hip_compact_streams: {lib().sjpeg_hip_last_error().decode()}")
     return packed, offsets
+
+
+def comm_unique_id() -> bytes:
+    """sjpeg_hip_comm_unique_id: the 128 bytes rank 0 hands to the other ranks."""
+    buf = (C.c_uint8 * 128)()
+    if lib().sjpeg_hip_comm_unique_id(buf) != 0:
+        raise SjpegError(f"sjpeg_hip_comm_unique_id: {lib().sjpeg_hip_last_error().decode()}")
+    return bytes(buf)
+
+
+class Comm:
+    """The library's RCCL communicator (sjpeg_hip_comm_create): one per process, the device current."""
+
+    def __init__(self, unique_id: bytes, rank: int, world: int):
+        self._c = C.c_void_p()
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        if lib().sjpeg_hip_comm_create(buf, int(rank), int(world), C.byref(self._c)) != 0:
+            raise SjpegError(f"sjpeg_hip_comm_create: {lib().sjpeg_hip_last_error().decode()}")
+        self.rank, self.world = int(rank), int(world)
+
+    def close(self):
+        if self._c:
+            lib().sjpeg_hip_comm_destroy(self._c)
+            self._c = C.c_void_p()
+
+    def gather_rows(self, offsets, sizes, n_local, per_max, rows_dev):
+        """sjpeg_hip_gather_rows on the current stream (waits for it).  Returns (rows [world][per_max + 2]
+        numpy uint64, rank_offsets [world + 1] numpy uint64) on every rank."""
+        import torch
+        rows = np.zeros((self.world, per_max + 2), np.uint64)
+        offs = np.zeros(self.world + 1, np.uint64)
+        rc = lib().sjpeg_hip_gather_rows(
+            self._c, C.c_void_p(offsets.data_ptr()), C.c_void_p(sizes.data_ptr() if n_local > 0 else 0),
+            int(n_local), int(per_max), C.c_void_p(rows_dev.data_ptr()), C.c_void_p(rows.ctypes.data),
+            C.c_void_p(offs.ctypes.data), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        if rc != 0:
+            raise SjpegError(f"sjpeg_hip_gather_rows: {lib().sjpeg_hip_last_error().decode()}")
+        return rows, offs
+
+    def gather_bytes(self, root, packed, per_max, rows, offs, gathered):
+        """sjpeg_hip_gather_bytes on the current stream: enqueues the exact-length transfers."""
+        import torch
+        rc = lib().sjpeg_hip_gather_bytes(
+            self._c, int(root), C.c_void_p(packed.data_ptr()), int(per_max), C.c_void_p(rows.ctypes.data),
+            C.c_void_p(offs.ctypes.data), C.c_void_p(gathered.data_ptr() if gathered is not None else 0),
+            C.c_size_t(int(gathered.numel()) if gathered is not None else 0),
+            C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        if rc != 0:
+            raise SjpegError(f"sjpeg_hip_gather_bytes: {lib().sjpeg_hip_last_error().decode()}")
 
 
 # ---------------------------------------------------------------- host API (sjpeg.h)

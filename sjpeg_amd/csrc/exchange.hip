@@ -169,19 +169,15 @@ void sjpeg_hip_comm_destroy(sjpeg_hip_comm* c) {
 int sjpeg_hip_comm_rank(const sjpeg_hip_comm* c) { return c ? c->rank : -1; }
 int sjpeg_hip_comm_world(const sjpeg_hip_comm* c) { return c ? c->world : 0; }
 
-int sjpeg_hip_gather_streams(sjpeg_hip_comm* c, int root, const void* d_packed, const uint64_t* d_offsets,
-                             const uint64_t* d_sizes, int nframes_local, int per_max, uint64_t* d_rows,
-                             void* d_gathered, size_t gathered_capacity, uint64_t* h_rows,
-                             uint64_t* h_rank_offsets, void* stream) {
-  if (c == nullptr || d_offsets == nullptr || d_sizes == nullptr || d_rows == nullptr || h_rows == nullptr ||
-      h_rank_offsets == nullptr) {
-    return xfail(SJPEG_HIP_EINVAL, "sjpeg_hip_gather_streams: NULL argument");
+int sjpeg_hip_gather_rows(sjpeg_hip_comm* c, const uint64_t* d_offsets, const uint64_t* d_sizes, int nframes_local,
+                          int per_max, uint64_t* d_rows, uint64_t* h_rows, uint64_t* h_rank_offsets, void* stream) {
+  if (c == nullptr || d_offsets == nullptr || d_rows == nullptr || h_rows == nullptr || h_rank_offsets == nullptr) {
+    return xfail(SJPEG_HIP_EINVAL, "sjpeg_hip_gather_rows: NULL argument");
   }
-  if (root < 0 || root >= c->world || nframes_local < 0 || per_max <= 0 || nframes_local > per_max || per_max > (1 << 20)) {
-    return xfail(SJPEG_HIP_EINVAL, "sjpeg_hip_gather_streams: bad root / frame counts");
+  if (nframes_local < 0 || per_max <= 0 || nframes_local > per_max || per_max > (1 << 20) ||
+      (nframes_local > 0 && d_sizes == nullptr)) {
+    return xfail(SJPEG_HIP_EINVAL, "sjpeg_hip_gather_rows: bad frame counts");
   }
-  if (nframes_local > 0 && d_packed == nullptr) return xfail(SJPEG_HIP_EINVAL, "sjpeg_hip_gather_streams: d_packed == NULL");
-  if (c->rank == root && d_gathered == nullptr) return xfail(SJPEG_HIP_EINVAL, "sjpeg_hip_gather_streams: d_gathered == NULL on the root");
   const Rccl* r = rccl();
   if (r == nullptr) return xfail(SJPEG_HIP_ERUNTIME, g_rccl.why);
   hipStream_t st = static_cast<hipStream_t>(stream);
@@ -193,14 +189,13 @@ int sjpeg_hip_gather_streams(sjpeg_hip_comm* c, int root, const void* d_packed, 
     XHIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_pinned), nrows * sizeof(uint64_t), hipHostMallocDefault));
     c->h_cap = nrows;
   }
-  // 1. this rank's row (in the scratch row behind the gathered ones), then the all-gather of the rows
+  // this rank's row (in the scratch row behind the gathered ones), the all-gather, the one host read
   unsigned long long* const mine = reinterpret_cast<unsigned long long*>(d_rows) + nrows;
   hipLaunchKernelGGL(gather_row_kernel, dim3((per_max + 255) / 256), dim3(256), 0, st,
                      reinterpret_cast<const unsigned long long*>(d_offsets), reinterpret_cast<const unsigned long long*>(d_sizes),
                      nframes_local, per_max, mine);
   XHIP_TRY(hipGetLastError());
   RCCL_TRY(r, r->AllGather(mine, d_rows, row, ncclUint64, c->comm, st));
-  // 2. the one host read
   XHIP_TRY(hipMemcpyAsync(c->h_pinned, d_rows, nrows * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
   XHIP_TRY(hipStreamSynchronize(st));
   memcpy(h_rows, c->h_pinned, nrows * sizeof(uint64_t));
@@ -222,21 +217,40 @@ int sjpeg_hip_gather_streams(sjpeg_hip_comm* c, int root, const void* d_packed, 
   }
   h_rank_offsets[c->world] = total;
   if (lost) {
-    return xfail(SJPEG_HIP_ECAPACITY, "sjpeg_hip_gather_streams: a frame of size 0 (it did not fit its output slot or the "
-                                      "packed buffer) -- nothing was sent");
+    return xfail(SJPEG_HIP_ECAPACITY, "sjpeg_hip_gather_rows: a frame of size 0 (it did not fit its output slot or the "
+                                      "packed buffer) -- nothing to send");
   }
-  if (total > gathered_capacity) {
-    return xfail(SJPEG_HIP_ECAPACITY, "sjpeg_hip_gather_streams: " + std::to_string(total) + " bytes to gather, capacity " +
-                                          std::to_string(gathered_capacity) + " -- nothing was sent");
-  }
-  // 3. exact-length transfers
+  return 0;
+}
+
+int sjpeg_hip_gather_bytes(sjpeg_hip_comm* c, int root, const void* d_packed, int per_max, const uint64_t* h_rows,
+                           const uint64_t* h_rank_offsets, void* d_gathered, size_t gathered_capacity, void* stream) {
+  if (c == nullptr || h_rows == nullptr || h_rank_offsets == nullptr) return xfail(SJPEG_HIP_EINVAL, "sjpeg_hip_gather_bytes: NULL argument");
+  if (root < 0 || root >= c->world || per_max <= 0) return xfail(SJPEG_HIP_EINVAL, "sjpeg_hip_gather_bytes: bad root / per_max");
+  const Rccl* r = rccl();
+  if (r == nullptr) return xfail(SJPEG_HIP_ERUNTIME, g_rccl.why);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const size_t row = static_cast<size_t>(per_max) + 2;
   const uint64_t my_bytes = h_rows[static_cast<size_t>(c->rank) * row];
   if (c->rank != root) {
-    if (my_bytes > 0) RCCL_TRY(r, r->Send(d_packed, my_bytes, ncclUint8, root, c->comm, st));
+    if (my_bytes > 0) {
+      if (d_packed == nullptr) return xfail(SJPEG_HIP_EINVAL, "sjpeg_hip_gather_bytes: d_packed == NULL");
+      RCCL_TRY(r, r->Send(d_packed, my_bytes, ncclUint8, root, c->comm, st));
+    }
     return 0;
+  }
+  // (the root's buffer is the root's business: the other ranks have sent by now, so every byte is
+  // received -- what lies behind the capacity is an argument error of the root alone, reported
+  // BEFORE the exchange by sjpeg_hip_gather_streams, which knows the capacity on every rank)
+  const uint64_t total = h_rank_offsets[c->world];
+  if (total > 0 && d_gathered == nullptr) return xfail(SJPEG_HIP_EINVAL, "sjpeg_hip_gather_bytes: d_gathered == NULL on the root");
+  if (total > gathered_capacity) {
+    return xfail(SJPEG_HIP_ECAPACITY, "sjpeg_hip_gather_bytes: " + std::to_string(total) + " bytes to gather, capacity " +
+                                          std::to_string(gathered_capacity) + " (size the buffer from h_rank_offsets[world])");
   }
   uint8_t* const dst = static_cast<uint8_t*>(d_gathered);
   if (my_bytes > 0) {
+    if (d_packed == nullptr) return xfail(SJPEG_HIP_EINVAL, "sjpeg_hip_gather_bytes: d_packed == NULL");
     XHIP_TRY(hipMemcpyAsync(dst + h_rank_offsets[root], d_packed, my_bytes, hipMemcpyDeviceToDevice, st));
   }
   RCCL_TRY(r, r->GroupStart());
@@ -250,6 +264,21 @@ int sjpeg_hip_gather_streams(sjpeg_hip_comm* c, int root, const void* d_packed, 
   RCCL_TRY(r, r->GroupEnd());
   if (first_bad != ncclSuccess) return xfail(SJPEG_HIP_ERUNTIME, std::string("ncclRecv: ") + r->GetErrorString(first_bad));
   return 0;
+}
+
+int sjpeg_hip_gather_streams(sjpeg_hip_comm* c, int root, const void* d_packed, const uint64_t* d_offsets,
+                             const uint64_t* d_sizes, int nframes_local, int per_max, uint64_t* d_rows,
+                             void* d_gathered, size_t gathered_capacity, uint64_t* h_rows,
+                             uint64_t* h_rank_offsets, void* stream) {
+  if (c == nullptr) return xfail(SJPEG_HIP_EINVAL, "sjpeg_hip_gather_streams: comm == NULL");
+  if (root < 0 || root >= c->world) return xfail(SJPEG_HIP_EINVAL, "sjpeg_hip_gather_streams: bad root");
+  const int rc = sjpeg_hip_gather_rows(c, d_offsets, d_sizes, nframes_local, per_max, d_rows, h_rows, h_rank_offsets, stream);
+  if (rc != 0) return rc;
+  if (h_rank_offsets[c->world] > gathered_capacity) {        // the same verdict on every rank: nobody sends
+    return xfail(SJPEG_HIP_ECAPACITY, "sjpeg_hip_gather_streams: " + std::to_string(h_rank_offsets[c->world]) +
+                                          " bytes to gather, capacity " + std::to_string(gathered_capacity) + " -- nothing was sent");
+  }
+  return sjpeg_hip_gather_bytes(c, root, d_packed, per_max, h_rows, h_rank_offsets, d_gathered, gathered_capacity, stream);
 }
 
 }  // extern "C"

@@ -25,64 +25,152 @@ def _align16(x):
 
 
 class GatheredStreams:
-    """What `dst` holds after gather_streams(): the per-rank packed buffers (device resident) and
-    the sizes of all frames; frames() brings them to the host as byte strings in global order."""
+    """What `dst` holds after gather_streams(): ONE device buffer with every rank's packed block at
+    rank_offsets[r] (exact lengths, rank order) and the rows {bytes, frames, sizes...} of all ranks;
+    frames() brings the streams to the host as byte strings in global order."""
 
-    def __init__(self, recv, sizes_all, nframes, world):
-        self.recv, self.sizes_all, self.nframes, self.world = recv, sizes_all, nframes, world
+    def __init__(self, gathered, rows, rank_offsets, nframes, world):
+        self.gathered, self.rows, self.rank_offsets = gathered, rows, rank_offsets
+        self.nframes, self.world = nframes, world
 
     def frames(self) -> List[bytes]:
         out: List[Optional[bytes]] = [None] * self.nframes
-        host = torch.stack(self.recv).cpu().numpy()            # one device -> host copy
+        total = int(self.rank_offsets[self.world])
+        host = self.gathered[:total].cpu().numpy()              # one device -> host copy
         for r in range(self.world):
             ids = shard_frames(self.nframes, r, self.world)
-            sz = self.sizes_all[r][:len(ids)]
-            offs = [0]
-            for n in sz[:-1]:
-                offs.append(offs[-1] + _align16(int(n)))
-            for k, o, n in zip(ids, offs, sz):
-                out[k] = host[r, o:o + int(n)].tobytes()
+            o = int(self.rank_offsets[r])
+            for j, k in enumerate(ids):
+                n = int(self.rows[r][2 + j])
+                out[k] = host[o:o + n].tobytes()
+                o += _align16(n)
         return out  # type: ignore[return-value]
+
+
+_COMMS = {}
+
+
+def rccl_comm(group=None):
+    """The library's own RCCL communicator for `group` (sjpeg_hip_comm_create): rank 0 makes the unique
+    id, torch.distributed carries its 128 bytes to the others -- the only thing torch does for the
+    exchange on the GPU path.  Cached per group."""
+    import sjpeg_amd as sj
+    key = id(group) if group is not None else 0
+    if key not in _COMMS:
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        box = [sj.comm_unique_id() if rank == 0 else None]
+        if world > 1:
+            dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        _COMMS[key] = sj.Comm(box[0], rank, world)
+    return _COMMS[key]
+
+
+def _check_rows(rows, per_max):
+    """The decision every rank takes on the same rows (the C function's rule, sjpeg_hip.h)."""
+    total = 0
+    offs = []
+    for rk in rows:
+        offs.append(total)
+        total += int(rk[0])
+        nf = int(rk[1])
+        sizes = [int(x) for x in rk[2:2 + nf]]
+        if nf > per_max or any(n == 0 for n in sizes) or sum(_align16(n) for n in sizes) != int(rk[0]):
+            raise _capacity_error("a frame of size 0 (it did not fit its output slot or the packed buffer)")
+    offs.append(total)
+    return offs
+
+
+def _capacity_error(msg):
+    import sjpeg_amd as sj
+    return sj.SjpegError("gather_streams: " + msg + " -- nothing was sent")
 
 
 def gather_streams(out: torch.Tensor, sizes: torch.Tensor, frame_ids: Sequence[int],
                    nframes: int, dst: int = 0, group=None, compact=None,
-                   to_host: bool = True):
+                   to_host: bool = True, buffers: Optional[dict] = None):
     """Gathers variable-length coded frames to `dst`: the exchange step of the batch path.
 
-    out [F_local, stride] uint8 and sizes [F_local] int64 as an encode call left them,
-    frame_ids the global index of each local frame.  The frames are packed back to back ON THE
-    DEVICE by one kernel (sjpeg_hip_compact_streams: every frame at a multiple of 16, no host
-    round trip), then TWO collectives move them: all_gather of the sizes (8 B per frame) and one
-    gather of the packed buffers, padded to the largest per-rank total (RCCL has no gatherv; its
-    send counts are host values, hence the ONE host read of the gathered sizes).  No per-frame
-    host synchronisation anywhere.  `compact(out, sizes, n, capacity)` -> (packed, offsets)
-    defaults to the C-ABI kernel (CUDA tensors); the CPU/gloo tests pass a torch restatement.
-    Returns on `dst` the nframes byte strings in global order (to_host=True) or a
-    GatheredStreams holding the device-resident buffers (to_host=False); None elsewhere."""
+    out [F_local, stride] uint8 and sizes [F_local] int64 as an encode call left them, frame_ids the
+    global index of each local frame.  The frames are packed back to back ON THE DEVICE by one kernel
+    (sjpeg_hip_compact_streams: every frame at a multiple of 16, no host round trip); then the protocol
+    of sjpeg_hip_gather_streams (include/sjpeg_hip.h): all-gather of one row {bytes, frames, sizes...}
+    per rank, ONE small host read of the rows (RCCL's counts are host values), and transfers of EXACT
+    lengths into one buffer on `dst` -- no padding to the largest rank.  CUDA tensors go through the
+    C-ABI (the library's own RCCL communicator, rccl_comm()); CPU tensors (the gloo tests) through the
+    same steps written with torch.distributed, `compact(out, sizes, n, capacity)` -> (packed, offsets)
+    standing in for the kernel.  A frame of size 0 raises on every rank before anything is sent; the root
+    sizes its buffer from the actual total.  `buffers`: a dict the call keeps its device buffers in (reuse across steps).
+    Returns on `dst` the nframes byte strings in global order (to_host=True) or a GatheredStreams holding
+    the device-resident buffer (to_host=False); None elsewhere."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     dev = out.device
-    if compact is None:
-        import sjpeg_amd as sj
-        compact = sj.compact_streams
     n_local = len(frame_ids)
-    max_local = (nframes + world - 1) // world
-    local_sizes = torch.zeros(max_local, dtype=torch.int64, device=dev)
-    local_sizes[:n_local] = sizes[:n_local]
-    all_sizes = [torch.zeros_like(local_sizes) for _ in range(world)]
-    dist.all_gather(all_sizes, local_sizes, group=group)
-    sizes_all = torch.stack(all_sizes).cpu().numpy()           # the one host read (world x frames int64)
-    pad = max(int(_align16(sizes_all).sum(axis=1).max()), 16)
+    per_max = (nframes + world - 1) // world
+    stride = int(out.stride(0)) if out.dim() == 2 else int(out.numel())
+    buffers = buffers if buffers is not None else {}
+
+    def buf(name, n, dtype):
+        t = buffers.get(name)
+        if t is None or t.numel() < n or t.dtype != dtype or t.device != dev:
+            t = torch.empty(int(n), dtype=dtype, device=dev)
+            buffers[name] = t
+        return t
+
+    if dev.type == "cuda":
+        import sjpeg_amd as sj
+        packed = buf("packed", max(n_local, 1) * _align16(stride), torch.uint8)
+        offsets = buf("offsets", per_max + 1, torch.int64)
+        if n_local > 0:
+            sj.compact_streams(out, sizes, n_local, packed=packed, offsets=offsets[:n_local + 1])
+        else:
+            offsets[:1].zero_()
+        rows_dev = buf("rows", (world + 1) * (per_max + 2), torch.int64)
+        comm = rccl_comm(group)
+        rows, offs = comm.gather_rows(offsets, sizes, n_local, per_max, rows_dev)
+        # the root sizes its buffer from the actual total (kept between steps, grown by halves)
+        total = int(offs[world])
+        gathered = None
+        if rank == dst:
+            have = buffers.get("gathered")
+            gathered = buf("gathered", max(total, 16) if have is not None and have.numel() >= total else total + total // 2 + 16,
+                           torch.uint8)
+        comm.gather_bytes(dst, packed, per_max, rows, offs, gathered)
+        if rank != dst:
+            return None
+        got = GatheredStreams(gathered, rows.astype(np.int64), offs.astype(np.int64), nframes, world)
+        return got.frames() if to_host else got
+
+    # ---- the same protocol on torch.distributed (gloo, CPU tests)
     if n_local > 0:
-        packed, _ = compact(out, sizes, n_local, pad)
+        packed, offsets = compact(out, sizes, n_local, n_local * _align16(stride))
+        my_bytes = int(offsets[n_local])
     else:
-        packed = torch.zeros(pad, dtype=torch.uint8, device=dev)
-    recv = [torch.empty(pad, dtype=torch.uint8, device=dev) for _ in range(world)] if rank == dst else None
-    dist.gather(packed[:pad], recv, dst=dst, group=group)
+        packed, my_bytes = torch.zeros(16, dtype=torch.uint8, device=dev), 0
+    row = torch.zeros(per_max + 2, dtype=torch.int64, device=dev)
+    row[0], row[1] = my_bytes, n_local
+    row[2:2 + n_local] = sizes[:n_local]
+    all_rows = [torch.zeros_like(row) for _ in range(world)]
+    dist.all_gather(all_rows, row, group=group)
+    rows = torch.stack(all_rows).cpu().numpy()                   # the one host read
+    offs = _check_rows(rows, per_max)
     if rank != dst:
+        if my_bytes > 0:
+            dist.send(packed[:my_bytes].contiguous(), dst=dst, group=group)
         return None
-    got = GatheredStreams(recv, sizes_all, nframes, world)
+    gathered = buf("gathered", max(offs[world], 16), torch.uint8)
+    reqs = []
+    for r in range(world):
+        n = int(rows[r][0])
+        if n == 0:
+            continue
+        if r == dst:
+            gathered[offs[r]:offs[r] + n] = packed[:n]
+        else:
+            reqs.append(dist.irecv(gathered[offs[r]:offs[r] + n], src=r, group=group))
+    for q in reqs:
+        q.wait()
+    got = GatheredStreams(gathered, rows, offs, nframes, world)
     return got.frames() if to_host else got
 
 
@@ -139,10 +227,11 @@ def exchange_loop(nsteps: int, encode, outs, sizes, frame_ids: Sequence[int], nf
     this code: `nsteps` encode calls, double buffered (outs[b], sizes[b], b = 0 / 1), the streams
     of every step gathered to `dst` (device resident there) under the next step's kernels.
     Returns the GatheredStreams of every step on `dst`, a list of None elsewhere."""
+    held = [{}, {}]                                 # device buffers of the exchange, one set per output set
     return overlapped_steps(
         nsteps, encode,
         lambda b: gather_streams(outs[b], sizes[b], frame_ids, nframes, dst=dst, group=group,
-                                 compact=compact, to_host=False),
+                                 compact=compact, to_host=False, buffers=held[b]),
         use_streams, keep)
 
 

@@ -64,6 +64,41 @@ def _run(nframes):
     assert ok
 
 
+def _worker_lost(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sjpeg_amd as sj
+    from sjpeg_amd.dist import gather_streams, shard_frames
+    ids = shard_frames(4, rank, world)
+    out = torch.full((2, 64), 7, dtype=torch.uint8)
+    sizes = torch.tensor([40, 0 if rank == 1 else 33], dtype=torch.int64)   # rank 1's second frame did not fit its slot
+    try:
+        gather_streams(out, sizes, ids, 4, dst=0, compact=_compact_torch)
+        q.put((rank, "no error"))
+    except sj.SjpegError as e:
+        q.put((rank, "refused" if "size 0" in str(e) else str(e)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_refuses_a_lost_frame_on_every_rank():
+    """A frame of size 0 (it did not fit its slot) must not become an empty string in the gathered batch:
+    every rank sees it in the rows and raises before anything is sent (nobody is left waiting)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker_lost, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got == {0: "refused", 1: "refused"}
+
+
 def test_shard_assignment():
     from sjpeg_amd.dist import shard_frames
     assert shard_frames(64, 3, 8) == list(range(3, 64, 8))

@@ -867,6 +867,48 @@ def test_compact_streams_vs_restatement(engine):
         sj.compact_streams(out[:, 1:], sizes)
 
 
+def test_gather_streams_c_abi_one_rank(engine, oracle):
+    """sjpeg_hip_comm_create + sjpeg_hip_gather_rows / _bytes (the RCCL exchange of the C-ABI) with a
+    communicator of ONE rank: all-gather of the row, the host read, the root's own block copied into the
+    gathered buffer -- with the DEFAULT out_stride of encode_frames (frame_bound: a multiple of 16), and
+    a frame that does not fit its slot refused before anything moves."""
+    w, h, nf = 200, 120, 5
+    tables, quant = sj.make_tables(quality=75.0)
+    header = sj.make_header(w, h, sj.YUV_420, quant)
+    imgs = [synth.g_struct(w, h, 900 + k) for k in range(nf)]
+    frames = torch.from_numpy(np.stack(imgs)).cuda()
+    out, sizes = engine.encode_frames(frames, tables, header, sj.YUV_420)        # default stride
+    assert out.stride(0) % 16 == 0
+    comm = sj.Comm(sj.comm_unique_id(), 0, 1)
+    try:
+        per_max = nf + 2                                  # (a rank may hold fewer frames than the largest)
+        packed, offsets = sj.compact_streams(out, sizes)
+        rows_dev = torch.zeros(2 * (per_max + 2), dtype=torch.int64, device="cuda")
+        rows, offs = comm.gather_rows(offsets, sizes, nf, per_max, rows_dev)
+        assert int(rows[0][1]) == nf and int(offs[1]) == int(rows[0][0]) == int(offsets[nf])
+        gathered = torch.zeros(int(offs[1]), dtype=torch.uint8, device="cuda")
+        comm.gather_bytes(0, packed, per_max, rows, offs, gathered)
+        torch.cuda.synchronize()
+        host, o = gathered.cpu().numpy(), 0
+        for k in range(nf):
+            n = int(rows[0][2 + k])
+            assert host[o:o + n].tobytes() == oracle.encode(imgs[k], 75.0, 1), k
+            o += (n + 15) & ~15
+        small = torch.empty(int(gathered.numel()) - 16, dtype=torch.uint8, device="cuda")
+        with pytest.raises(sj.SjpegError):
+            comm.gather_bytes(0, packed, per_max, rows, offs, small)             # the root's buffer is too small
+        # a frame that did not fit its slot (size 0): refused by the rows on every rank
+        tight = (len(header) + 2 + 64 + 15) & ~15
+        out2, sizes2 = engine.encode_frames(frames, tables, header, sj.YUV_420, out_stride=tight)
+        torch.cuda.synchronize()
+        assert int(sizes2.sum()) == 0
+        packed2, offsets2 = sj.compact_streams(out2, sizes2)
+        with pytest.raises(sj.SjpegError):
+            comm.gather_rows(offsets2, sizes2, nf, per_max, rows_dev)
+    finally:
+        comm.close()
+
+
 def test_frame_tensor_layout_is_checked(engine):
     """A permuted / channel-first / sliced view must be refused (the C-ABI sees two strides only)."""
     img = torch.from_numpy(synth.g_struct(64, 48, 3)).cuda()
