@@ -259,7 +259,7 @@ int order_on_stream(sjpeg_hip_engine* e, hipStream_t st) {
 // Segment scratch of an encode call, sized from the bytes the caller gives every frame (out_stride)
 // instead of for the worst case: a frame's un-stuffed stream is never longer than its stuffed one, so
 // `budget` words hold it whenever the frame fits its output slot -- and a frame that does not fit
-// reports size 0 anyway.  Every segment has a slot of about half its share of the budget (the
+// reports size 0 anyway.  Every segment has a slot of about three quarters of its share of the budget (the
 // ordinary segment fits; K3 reads it without indirection); what a longer segment has beyond that, and
 // the rows of the checked walk (scan_segments.h), come out of a per-frame pool.  Both are at most as
 // long as the stream, hence 2 x budget.  budget_bytes == SIZE_MAX: worst case (bands, which have no
@@ -270,7 +270,9 @@ SegPlan seg_plan(const FrameGeo& g, size_t budget_bytes) {
   size_t budget = budget_bytes == SIZE_MAX ? worst_total : budget_bytes / 4 + 16;
   if (budget > worst_total) budget = worst_total;
   SegPlan p;
-  size_t sw = (budget / static_cast<size_t>(g.nseg) / 2 + 63) & ~size_t(63);
+  // (three quarters of a segment's share: at half of it the segments of an 8K 4:4:4 q90 frame -- 0.77 B per
+  // pixel against slots of 0.75 -- went through the pool, K3's slow path, every other time)
+  size_t sw = (budget * 3 / static_cast<size_t>(g.nseg) / 4 + 63) & ~size_t(63);
   const size_t floor_words = g.slot_words < 1024u ? g.slot_words : 1024u;
   if (sw < floor_words) sw = floor_words;
   if (sw > g.slot_words || budget >= worst_total) sw = g.slot_words;   // (worst-case budget: no segment is ever longer than its slot)

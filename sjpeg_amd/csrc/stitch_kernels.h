@@ -38,17 +38,46 @@ __global__ __launch_bounds__(kThreads) void scan_seg_offsets(const StitchArgs a)
   const int frame = blockIdx.x;
   const uint32_t* nb = a.seg_nbits + static_cast<size_t>(frame) * a.nseg;
   unsigned long long* off = a.seg_off + static_cast<size_t>(frame) * (a.nseg + 1);
+  // (a band is shorter than 2^32 bits: sjpeg_hip_stitch_bands checks its capacity)
+  auto len_of = [&](int i) -> uint32_t {
+    return a.seg_nbits64 != nullptr ? static_cast<uint32_t>(a.seg_nbits64[static_cast<size_t>(frame) * a.nseg + i]) : nb[i];
+  };
+  // A thread owns a RUN of consecutive segments (8 at most per round; one round up to 2048 segments, i.e.
+  // every frame but the very large ones): it adds them up, the workgroup scans the 256 sums, and the
+  // thread writes the offsets of its run -- one scan (two barriers) per 2048 segments instead of one
+  // per 256 (an 8K 4:4:4 frame has 6172 segments: 13.8 us with a scan per 256).
+  constexpr int kRun = 8;
   unsigned long long running = 0;
-  for (int base = 0; base < a.nseg; base += kThreads) {
-    const int i = base + threadIdx.x;
-    // (a band is shorter than 2^32 bits: sjpeg_hip_stitch_bands checks its capacity)
-    const uint32_t x = i >= a.nseg ? 0u
-                     : a.seg_nbits64 != nullptr ? static_cast<uint32_t>(a.seg_nbits64[static_cast<size_t>(frame) * a.nseg + i])
-                                                : nb[i];
-    uint32_t total;
-    const uint32_t ex = wg_exclusive_scan<kThreads>(x, scratch, &total);
-    if (i < a.nseg) off[i] = running + ex;
-    running += total;
+  for (int base = 0; base < a.nseg; base += kThreads * kRun) {
+    const int i0 = base + static_cast<int>(threadIdx.x) * kRun;
+    uint32_t v[kRun];
+    unsigned long long mine = 0;
+#pragma unroll
+    for (int j = 0; j < kRun; ++j) {
+      v[j] = (i0 + j < a.nseg) ? len_of(i0 + j) : 0u;
+      mine += v[j];
+    }
+    // (a segment has at most 425 000 bits: the 2048 of a round stay below 2^32; bands may be 2^32 - 1
+    // bits each: their sums are scanned as two halves)
+    unsigned long long at, round_total;
+    if (a.seg_nbits64 == nullptr) {
+      uint32_t total;
+      const uint32_t ex = wg_exclusive_scan<kThreads>(static_cast<uint32_t>(mine), scratch, &total);
+      at = running + ex;
+      round_total = total;
+    } else {
+      uint32_t total_lo, total_hi;
+      const uint32_t ex_lo = wg_exclusive_scan<kThreads>(static_cast<uint32_t>(mine & 0xffffffu), scratch, &total_lo);
+      const uint32_t ex_hi = wg_exclusive_scan<kThreads>(static_cast<uint32_t>(mine >> 24), scratch, &total_hi);
+      at = running + ex_lo + (static_cast<unsigned long long>(ex_hi) << 24);
+      round_total = total_lo + (static_cast<unsigned long long>(total_hi) << 24);
+    }
+#pragma unroll
+    for (int j = 0; j < kRun; ++j) {
+      if (i0 + j < a.nseg) off[i0 + j] = at;
+      at += v[j];
+    }
+    running += round_total;
   }
   if (threadIdx.x == 0) {
     off[a.nseg] = running;
@@ -130,7 +159,12 @@ __global__ __launch_bounds__(kThreads) void place_segments(const StitchArgs a) {
       spec[k][1] = src[i + 1];
     }
   }
+  // what the segment's LAST word needs, requested with everything else: the first word of the segment
+  // behind it, and where that one ends (is it long enough to fill the word?)
+  const bool has_next = sc0 + 1 < a.nseg;                   // uniform
+  const uint32_t next_first = has_next ? src[a.slot_words] : 0u;
   const unsigned long long b0 = off[sc0], b1 = off[sc0 + 1];
+  const unsigned long long b2 = off[has_next ? sc0 + 2 : sc0 + 1];
   const unsigned long long T = off[a.nseg];                 // total bits
   const unsigned long long U = (T + 7) >> 3;                // bytes incl. 1-bit padding
   // a frame whose stream is longer than the scratch sized from out_stride cannot fit its output slot
@@ -163,6 +197,26 @@ __global__ __launch_bounds__(kThreads) void place_segments(const StitchArgs a) {
     if (lane == 0 && sum != 0u) atomicAdd(&cff[ff_chunk], sum);
     ff_acc = 0;
   };
+  // destination word i of this segment, bit by bit from wherever its bits are: the word that runs over the
+  // end of the segment is finished from the following ones, and from 1-bits behind the frame's last
+  auto gather_word = [&](uint32_t i) -> uint32_t {
+    uint32_t outw = 0;
+    int need = 32, sc = sc0;
+    unsigned long long p = (wbeg + i) * 32, c_beg = b0, c_end = b1;
+    while (need > 0 && p < T) {
+      while (p >= c_end) { ++sc; c_beg = c_end; c_end = off[sc + 1]; }
+      const unsigned long long avail = c_end - p;
+      const int take = avail < static_cast<unsigned long long>(need) ? static_cast<int>(avail) : need;
+      const uint32_t rr = static_cast<uint32_t>(p - c_beg);
+      const unsigned long long two = (static_cast<unsigned long long>(seg_word(sc, rr >> 5)) << 32) | seg_word(sc, (rr >> 5) + 1);
+      const uint32_t bits = static_cast<uint32_t>((two << (rr & 31)) >> (64 - take));
+      outw |= bits << (need - take);
+      need -= take;
+      p += take;
+    }
+    if (need > 0) outw |= (need == 32) ? 0xffffffffu : ((1u << need) - 1u);   // past the end: 1-bits
+    return outw;
+  };
   auto one = [&](uint32_t i, uint32_t v0, uint32_t v1) {
     uint32_t ffs = 0;
     if (i < nwords) {
@@ -171,22 +225,7 @@ __global__ __launch_bounds__(kThreads) void place_segments(const StitchArgs a) {
       if (r + 32u <= len) {
         outw = lead ? __builtin_amdgcn_alignbit(v0, v1, 32u - lead) : v0;   // (v0:v1) >> (32 - lead)
       } else {
-        // the word that runs over the end of the segment: finish it from the next ones
-        outw = 0;
-        int need = 32, sc = sc0;
-        unsigned long long p = (wbeg + i) * 32, c_beg = b0, c_end = b1;
-        while (need > 0 && p < T) {
-          while (p >= c_end) { ++sc; c_beg = c_end; c_end = off[sc + 1]; }
-          const unsigned long long avail = c_end - p;
-          const int take = avail < static_cast<unsigned long long>(need) ? static_cast<int>(avail) : need;
-          const uint32_t rr = static_cast<uint32_t>(p - c_beg);
-          const unsigned long long two = (static_cast<unsigned long long>(seg_word(sc, rr >> 5)) << 32) | seg_word(sc, (rr >> 5) + 1);
-          const uint32_t bits = static_cast<uint32_t>((two << (rr & 31)) >> (64 - take));
-          outw |= bits << (need - take);
-          need -= take;
-          p += take;
-        }
-        if (need > 0) outw |= (need == 32) ? 0xffffffffu : ((1u << need) - 1u);   // past the end: 1-bits
+        outw = gather_word(i);
       }
       dst[i] = outw;
       const unsigned long long byte0 = (wbeg + i) * 4;
@@ -210,50 +249,83 @@ __global__ __launch_bounds__(kThreads) void place_segments(const StitchArgs a) {
   if (!long_seg && wide) {
     // destination words that lie entirely inside the segment: the funnel shift is all there is to them
     const uint32_t n_int = len >= lead + 32u ? (len - lead) >> 5 : 0u;
+    // At most ONE word of a segment runs over its end (index n_int): its low bits are the first bits of
+    // the segment behind (or the 1-bit padding behind the frame's last segment).  Both are at hand
+    // (next_first above) unless the segment behind is shorter than what the word lacks -- tiny
+    // segments of tiny pictures, empty bands -- which takes the general path of one().
+    const uint32_t edge_bits = len > lead ? (len - lead) & 31u : 0u;      // bits of the edge word that are this segment's
+    const bool edge_easy = !has_next || (b2 - b1) >= 32u - edge_bits;
+    const uint32_t last_valid = (sc0 == a.nseg - 1) ? static_cast<uint32_t>(U - (wend - 1) * 4) : 4u;   // bytes of the frame's last word
     auto batch = [&](uint32_t i0, uint4 q, uint32_t x) {     // destination words i0 .. i0 + 255, four per lane
       const uint32_t i = i0 + 4u * lane;
       const uint32_t v[5] = {q.x, q.y, q.z, q.w, x};
-      if (i0 + 256u <= n_int) {                              // (uniform)
-        Words4 o;
-        uint32_t ffs = 0;
+      const bool full = i0 + 256u <= n_int;                  // (uniform) all of them inside the segment
+      Words4 o;
+      uint32_t f[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        o.w[u] = lead ? __builtin_amdgcn_alignbit(v[u], v[u + 1], 32u - lead) : v[u];
+        f[u] = static_cast<uint32_t>(__popc(ff_bytes(o.w[u])));
+      }
+      if (full) {
+        *reinterpret_cast<Words4*>(dst + i) = o;
+      } else {
+        const bool edge_here = n_int < nwords && n_int >= i0 && n_int < i0 + 256u;      // uniform
+        // (general form: every lane works the same word out of the same addresses -- no divergence in
+        // front of the wave-wide accounting below -- and the lane that owns it keeps it)
+        const uint32_t gathered = (edge_here && !edge_easy) ? gather_word(n_int) : 0u;
+        const uint32_t hi_mask = edge_bits ? ~(0xffffffffu >> edge_bits) : 0u;
+        const uint32_t tail = (has_next ? next_first : 0xffffffffu) >> edge_bits;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          o.w[u] = lead ? __builtin_amdgcn_alignbit(v[u], v[u + 1], 32u - lead) : v[u];
-          ffs += static_cast<uint32_t>(__popc(ff_bytes(o.w[u])));
-        }
-        *reinterpret_cast<Words4*>(dst + i) = o;
-        const uint32_t c_lo = (wbase + i) >> 10, c_hi = (wbase + i + 3u) >> 10;
-        const uint32_t chunk0 = __builtin_amdgcn_readfirstlane(c_lo);
-        if (chunk0 != ff_chunk) {                            // uniform
-          if (ff_chunk != 0xffffffffu) ff_flush();
-          ff_chunk = chunk0;
-        }
-        if (c_lo == chunk0 && c_hi == chunk0) {
-          ff_acc += ffs;
-        } else if (ffs != 0u) {                              // the lane's words straddle a chunk boundary, or lie behind it
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const uint32_t f = static_cast<uint32_t>(__popc(ff_bytes(o.w[u])));
-            const uint32_t c = (wbase + i + u) >> 10;
-            if (f != 0u) { if (c == chunk0) ff_acc += f; else atomicAdd(&cff[c], f); }
+          const uint32_t idx = i + u;
+          if (edge_here && idx == n_int) {
+            o.w[u] = edge_easy ? ((o.w[u] & hi_mask) | tail) : gathered;
+            f[u] = (sc0 == a.nseg - 1) ? count_ff(o.w[u], static_cast<int>(last_valid))
+                                      : static_cast<uint32_t>(__popc(ff_bytes(o.w[u])));
           }
+          if (idx < nwords) dst[idx] = o.w[u]; else f[u] = 0;
         }
-      } else {
+      }
+      const uint32_t ffs = f[0] + f[1] + f[2] + f[3];
+      const uint32_t c_lo = (wbase + i) >> 10, c_hi = (wbase + i + 3u) >> 10;
+      const uint32_t chunk0 = __builtin_amdgcn_readfirstlane(c_lo);
+      if (chunk0 != ff_chunk) {                              // uniform
+        if (ff_chunk != 0xffffffffu) ff_flush();
+        ff_chunk = chunk0;
+      }
+      if (c_lo == chunk0 && c_hi == chunk0) {
+        ff_acc += ffs;
+      } else if (ffs != 0u) {                                // the lane's words straddle a chunk boundary, or lie behind it
 #pragma unroll
-        for (int u = 0; u < 4; ++u) one(i + u, v[u], v[u + 1]);
+        for (int u = 0; u < 4; ++u) {
+          const uint32_t c = (wbase + i + u) >> 10;
+          if (f[u] != 0u) { if (c == chunk0) ff_acc += f[u]; else atomicAdd(&cff[c], f[u]); }
+        }
       }
     };
 #pragma unroll
     for (int k = 0; k < kWideSpec; ++k) {
       if (256u * k < nwords) batch(256u * k, wq[k], wx[k]);
     }
-    for (uint32_t i0 = 256u * kWideSpec; i0 < nwords; i0 += 256u) {
-      // A lane whose four words start inside the slot must get exactly those (a segment that is not
-      // `long_seg` has up to slot_words - 2 of them); only the fifth word of the slot's last lane,
-      // needed by destination word slot_words - 1 alone, and the lanes behind the slot, all of
-      // whose words are unused, are clamped.
+    // longer segments: the words of batch k + 1 are requested before batch k is worked on
+    // A lane whose four words start inside the slot must get exactly those (a segment that is not
+    // `long_seg` has up to slot_words - 2 of them); only the fifth word of the slot's last lane,
+    // needed by destination word slot_words - 1 alone, and the lanes behind the slot, all of
+    // whose words are unused, are clamped.
+    auto fetch = [&](uint32_t i0, uint4* q, uint32_t* x) {
       const uint32_t i = min(i0 + 4u * lane, a.slot_words - 4u);
-      batch(i0, *reinterpret_cast<const uint4*>(src + i), src[min(i + 4u, a.slot_words - 1u)]);
+      *q = *reinterpret_cast<const uint4*>(src + i);
+      *x = src[min(i + 4u, a.slot_words - 1u)];
+    };
+    uint4 qn = make_uint4(0, 0, 0, 0);
+    uint32_t xn = 0;
+    if (256u * kWideSpec < nwords) fetch(256u * kWideSpec, &qn, &xn);
+    for (uint32_t i0 = 256u * kWideSpec; i0 < nwords; i0 += 256u) {
+      const uint4 qc = qn;
+      const uint32_t xc = xn;
+      if (i0 + 256u < nwords) fetch(i0 + 256u, &qn, &xn);
+      batch(i0, qc, xc);
     }
   } else if (!long_seg) {
 #pragma unroll
@@ -289,13 +361,25 @@ __global__ __launch_bounds__(kThreads) void scan_chunk_offsets(const StitchArgs 
   const uint32_t nchunks = static_cast<uint32_t>(nch64);
   const uint32_t* ff = a.chunk_ff + static_cast<size_t>(frame) * a.max_chunks;
   unsigned long long* co = a.chunk_off + static_cast<size_t>(frame) * a.max_chunks;
+  // (runs of eight chunks per thread, like K2: one scan per 2048 chunks = 8 MiB of stream)
+  constexpr uint32_t kRun = 8;
   unsigned long long running = 0;
-  for (uint32_t base = 0; base < nchunks; base += kThreads) {
-    const uint32_t i = base + threadIdx.x;
-    const uint32_t x = i < nchunks ? ff[i] : 0u;
+  for (uint32_t base = 0; base < nchunks; base += kThreads * kRun) {
+    const uint32_t i0 = base + threadIdx.x * kRun;
+    uint32_t v[kRun], mine = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < kRun; ++j) {
+      v[j] = (i0 + j < nchunks) ? ff[i0 + j] : 0u;           // (at most 4096 each)
+      mine += v[j];
+    }
     uint32_t total;
-    const uint32_t ex = wg_exclusive_scan<kThreads>(x, scratch, &total);
-    if (i < nchunks) co[i] = running + ex;
+    const uint32_t ex = wg_exclusive_scan<kThreads>(mine, scratch, &total);
+    unsigned long long at = running + ex;
+#pragma unroll
+    for (uint32_t j = 0; j < kRun; ++j) {
+      if (i0 + j < nchunks) co[i0 + j] = at;
+      at += v[j];
+    }
     running += total;
   }
   // a frame that does not fit the caller's slot reports size 0 and is not written
@@ -328,11 +412,17 @@ __global__ __launch_bounds__(kThreads) void scan_chunk_offsets(const StitchArgs 
 // ------------------------------------------------------------------------------------
 // K5: byte stuffing into the caller's slot
 
+// A thread takes 16 bytes of the chunk; a workgroup scan of the 0xFF counts gives every thread the place
+// of its bytes in the stuffed chunk, which is staged in LDS laid out like the destination (LDS byte i
+// <-> destination byte dalign + i, dalign 16-byte aligned) and copied out with aligned 16-byte stores.
+// Staging is done in ALIGNED DWORDS by the rule of K3: a thread writes every dword whose FIRST byte is
+// one of its own, and completes the last of them with the first bytes of the thread behind it -- which
+// it has loaded itself (a fifth source word), so no two threads ever exchange anything.  94 % of the
+// threads hold no 0xFF byte (1 byte in 256 of an entropy-coded stream): four byte-aligns and two
+// ds_write2_b32 instead of the sixteen byte stores of the general path, which the others keep.
 __global__ __launch_bounds__(kThreads) void stuff_chunks(const StitchArgs a) {
   __shared__ uint32_t scratch[16];
-  // stuffed bytes of one chunk (<= 2 * 4 KiB), placed so that LDS words line up with the
-  // 4-byte words of the destination: the copy-out is aligned dword stores
-  __shared__ __attribute__((aligned(16))) uint8_t stage[2 * kChunkBytes + 16];
+  __shared__ __attribute__((aligned(16))) uint8_t stage[2 * kChunkBytes + 64];
   const int frame = blockIdx.y;
   const unsigned long long T = a.seg_off[static_cast<size_t>(frame) * (a.nseg + 1) + a.nseg];
   const unsigned long long U = (T + 7) >> 3;
@@ -342,10 +432,11 @@ __global__ __launch_bounds__(kThreads) void stuff_chunks(const StitchArgs a) {
   const uint32_t hsize = a.hdr_off ? a.hdr_off[frame + 1] - a.hdr_off[frame] : a.header_size;
   uint8_t* const dst0 = a.out + static_cast<size_t>(frame) * a.out_stride + hsize;
   if (a.sizes[frame] == 0) return;                          // did not fit (see K4)
-  // the 16 bytes of this thread in the NEXT chunk of the workgroup are requested while the current
-  // ones are stuffed
-  auto fetch = [&](uint32_t chunk, uint4* q, int* valid, unsigned long long* off) {
+  // the 16 bytes of this thread in the NEXT chunk of the workgroup (and the word behind them) are
+  // requested while the current ones are stuffed
+  auto fetch = [&](uint32_t chunk, uint4* q, uint32_t* behind, int* valid, unsigned long long* off) {
     *q = make_uint4(0, 0, 0, 0);
+    *behind = 0;
     *valid = 0;
     *off = 0;
     if (chunk >= nchunks) return;
@@ -355,17 +446,20 @@ __global__ __launch_bounds__(kThreads) void stuff_chunks(const StitchArgs a) {
     if (byte0 < U) {
       *q = *reinterpret_cast<const uint4*>(ub + w0);
       *valid = (U - byte0 >= 16) ? 16 : static_cast<int>(U - byte0);
+      if (byte0 + 16 < U) *behind = ub[w0 + 4];              // (inside the stream: the buffer is longer)
     }
   };
   uint4 q_next;
+  uint32_t behind_next;
   int valid_next;
   unsigned long long off_next;
-  fetch(blockIdx.x, &q_next, &valid_next, &off_next);
+  fetch(blockIdx.x, &q_next, &behind_next, &valid_next, &off_next);
   for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
     const uint4 q = q_next;
+    const uint32_t behind = behind_next;
     const int valid = valid_next;
     const unsigned long long chunk_off = off_next;
-    fetch(chunk + gridDim.x, &q_next, &valid_next, &off_next);
+    fetch(chunk + gridDim.x, &q_next, &behind_next, &valid_next, &off_next);
     const uint32_t w[4] = {q.x, q.y, q.z, q.w};
     uint32_t ffs = 0;
     if (valid == 16) {
@@ -378,32 +472,51 @@ __global__ __launch_bounds__(kThreads) void stuff_chunks(const StitchArgs a) {
     uint32_t total_ff;
     const uint32_t ex = wg_exclusive_scan<kThreads>(ffs, scratch, &total_ff);
     uint8_t* const dchunk = dst0 + static_cast<unsigned long long>(chunk) * kChunkBytes + chunk_off;
-    const uint32_t mis = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(dchunk) & 3u);
-    uint8_t* sp = stage + mis + threadIdx.x * 16 + ex;
-    // (4-byte stores at the lanes' odd offsets and a permute-based expansion of the words that
-    // hold 0xFF bytes were tried: bit-exact, but the unaligned LDS stores made the kernel 47 %
-    // slower, 125 against 85 us; a padded buffer without bank conflicts: 102 us; a pre-cleared
-    // buffer with branch-free placement by popcount: 87 us -- neither the conflicts nor the
-    // per-byte control flow is what bounds this kernel)
+    const uint32_t mis = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(dchunk) & 15u);
+    const uint32_t o = mis + threadIdx.x * 16 + ex;          // where this thread's bytes start in `stage`
+    // the first three bytes the thread behind will produce: its first source bytes, stuffed
+    const uint32_t n0 = behind >> 24, n1 = (behind >> 16) & 0xffu, n2 = (behind >> 8) & 0xffu;
+    const bool behind_plain = (ff_bytes(behind) & 0x80808000u) == 0u;
+    if (valid == 16 && ffs == 0u && behind_plain) {
+      // memory-order dwords of the 16 bytes and of the word behind them
+      const uint32_t m[5] = {__builtin_bswap32(w[0]), __builtin_bswap32(w[1]), __builtin_bswap32(w[2]),
+                             __builtin_bswap32(w[3]), __builtin_bswap32(behind)};
+      const uint32_t up = (0u - o) & 3u;                     // bytes in front of the first dword that starts here
+      uint32_t d[4];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      if (j < valid) {
-        const uint8_t b = static_cast<uint8_t>(w[j >> 2] >> (24 - 8 * (j & 3)));
-        *sp++ = b;
-        if (b == 0xff) *sp++ = 0x00;
+      for (int k = 0; k < 4; ++k) d[k] = __builtin_amdgcn_alignbyte(m[k + 1], m[k], up);
+      uint32_t* const sp = reinterpret_cast<uint32_t*>(stage + o + up);
+      sp[0] = d[0]; sp[1] = d[1]; sp[2] = d[2]; sp[3] = d[3];
+      if (threadIdx.x == 0) {                                // nobody in front: the chunk's first bytes one by one
+        for (uint32_t j = 0; j < up; ++j) stage[o + j] = static_cast<uint8_t>(m[0] >> (8 * j));
       }
+    } else {
+      uint8_t* sp = stage + o;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        if (j < valid) {
+          const uint8_t b = static_cast<uint8_t>(w[j >> 2] >> (24 - 8 * (j & 3)));
+          *sp++ = b;
+          if (b == 0xff) *sp++ = 0x00;
+        }
+      }
+      // ... and the head of the thread behind (the dword its first byte shares with this thread's last
+      // bytes is this thread's to complete; what lies behind the stream's end is never copied out)
+      sp[0] = static_cast<uint8_t>(n0);
+      sp[1] = static_cast<uint8_t>(n0 == 0xffu ? 0u : n1);
+      sp[2] = static_cast<uint8_t>(n0 == 0xffu ? n1 : (n1 == 0xffu ? 0u : n2));
     }
     __syncthreads();
     const unsigned long long rest = U - static_cast<unsigned long long>(chunk) * kChunkBytes;
     const uint32_t nbytes = static_cast<uint32_t>(rest < kChunkBytes ? rest : kChunkBytes) + total_ff;
-    // bytes [mis, mis + nbytes) of `stage` go to dchunk - mis + [mis, ...): whole words in
-    // the middle, single bytes at the two ragged ends
+    // bytes [mis, mis + nbytes) of `stage` go to dchunk - mis + [mis, ...): whole 16-byte units in the
+    // middle, single bytes at the two ragged ends
     uint8_t* const dalign = dchunk - mis;
     const uint32_t lo = mis, hi = mis + nbytes;
-    const uint32_t first_full = (lo + 3u) & ~3u, last_full = hi & ~3u;
+    const uint32_t first_full = (lo + 15u) & ~15u, last_full = hi & ~15u;
     if (first_full <= last_full) {
-      for (uint32_t i = first_full / 4 + threadIdx.x; i < last_full / 4; i += kThreads) {
-        reinterpret_cast<uint32_t*>(dalign)[i] = reinterpret_cast<const uint32_t*>(stage)[i];
+      for (uint32_t i = first_full / 16 + threadIdx.x; i < last_full / 16; i += kThreads) {
+        reinterpret_cast<uint4*>(dalign)[i] = reinterpret_cast<const uint4*>(stage)[i];
       }
       if (threadIdx.x < first_full - lo) dalign[lo + threadIdx.x] = stage[lo + threadIdx.x];
       if (threadIdx.x < hi - last_full) dalign[last_full + threadIdx.x] = stage[last_full + threadIdx.x];

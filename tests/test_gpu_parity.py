@@ -1188,18 +1188,18 @@ def _sweep_segment_lengths(engine, oracle, mode, q, words_lo, words_hi, nseg, pe
 
 def test_segments_of_every_length_around_the_slot_size(engine, oracle):
     """Segment lengths from ~100 words below to ~200 above a 1024-word slot.  Slots of 1024 / 1088 / 1152
-    words (chosen through out_stride) put the boundary between 'fits the slot' and 'continues in the
+    words (chosen through out_stride: a slot is three quarters of a segment's share, 1024 words at least) put the boundary between 'fits the slot' and 'continues in the
     pool' at three places of that sweep.  Found at 65535 x 65535 (tools/max_frame_check.py): a segment
     of slot_words - 3 words had its last word placed from the wrong source words."""
-    _sweep_segment_lengths(engine, oracle, 1, 90.0, 940, 1230, 2400, (6000, 8640, 9152, 20000), 2024)
-    _sweep_segment_lengths(engine, oracle, 3, 90.0, 940, 1230, 1600, (6000, 8640, 9152, 20000), 2025)
-    _sweep_segment_lengths(engine, oracle, 4, 85.0, 940, 1230, 1600, (6000, 8640, 9152, 20000), 2026)
+    _sweep_segment_lengths(engine, oracle, 1, 90.0, 940, 1230, 2400, (5000, 5760, 6100, 20000), 2024)
+    _sweep_segment_lengths(engine, oracle, 3, 90.0, 940, 1230, 1600, (5000, 5760, 6100, 20000), 2025)
+    _sweep_segment_lengths(engine, oracle, 4, 85.0, 940, 1230, 1600, (5000, 5760, 6100, 20000), 2026)
 
 
 def test_segments_of_every_length_around_the_stitch_window(engine, oracle):
     """K1 stitches a segment through an 8 KiB window in LDS, in several rounds if it is longer: lengths
     sweeping across one window (q 97: lean and checked parts mixed) and across two (q 100), with slots
     that end before, inside and behind the window boundary."""
-    _sweep_segment_lengths(engine, oracle, 1, 97.0, 1900, 2500, 1500, (12000, 17000, 40000), 7)
-    _sweep_segment_lengths(engine, oracle, 1, 100.0, 3800, 4500, 1500, (24000, 33500, 80000), 8)
-    _sweep_segment_lengths(engine, oracle, 3, 97.0, 1900, 2500, 1000, (12000, 17000, 40000), 9)
+    _sweep_segment_lengths(engine, oracle, 1, 97.0, 1900, 2500, 1500, (9400, 11500, 40000), 7)
+    _sweep_segment_lengths(engine, oracle, 1, 100.0, 3800, 4500, 1500, (17800, 22400, 80000), 8)
+    _sweep_segment_lengths(engine, oracle, 3, 97.0, 1900, 2500, 1000, (9400, 11500, 40000), 9)
