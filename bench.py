@@ -167,6 +167,41 @@ def run_config(sj, torch, eng, frames_np, tile, q, mode, want_md5, reps=10):
             "bit_exact": bool(ok)}
 
 
+def run_batch_config(sj, torch, eng, frames_np, tile, mode, method, want, quality=75.0, quant=None, reps=5):
+    """A configuration that goes through the per-picture analysis of the reference (adaptive quantization,
+    optimised Huffman tables: sjpeg_hip_encode_batch_src, device passes + host analysis in between), or
+    through caller-supplied matrices (C5): `tile` copies resident in HBM, whole call timed, frame 0
+    against the committed digest."""
+    h, w = frames_np[0].shape[:2]
+    F = len(frames_np) * tile
+    frames = torch.empty((F, h, w, 3), dtype=torch.uint8, device="cuda")
+    for k in range(F):
+        frames[k] = torch.from_numpy(frames_np[k % len(frames_np)]).cuda()
+    src, _ = sj.make_source(sj.SRC_RGB, [frames.view(F, h, w * 3)])
+    qm = np.zeros((2, 64), np.uint8)
+    if quant is None:
+        sj.lib().sjpeg_hip_quality_matrices(float(quality), qm.ctypes.data)
+    else:
+        qm[:] = quant
+    stride = ((w * h * 2) // 2 + 4096 + 4095) & ~4095
+    out = torch.empty((F, stride), dtype=torch.uint8, device="cuda")
+    sizes = torch.zeros(F, dtype=torch.int64, device="cuda")
+    step = lambda: eng.encode_batch(src, F, w, h, mode, qm, method, min_quant=quant, out_stride=stride, out=out, sizes=sizes)
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    sz = sizes.cpu().numpy()
+    got = bytes(out[0, :int(sz[0])].cpu().numpy())
+    ok = hashlib.md5(got).hexdigest() == want["md5"] and len(got) == want["size"]
+    return {"frames": F, "width": w, "height": h, "method": method, "mpix_s": round(F * w * h / dt / 1e6, 1),
+            "ms_per_step": round(dt * 1e3, 4), "bytes_per_frame": int(sz[0]), "bit_exact": bool(ok)}
+
+
 def emit(res):
     """The ONE JSON line, last on stdout: RCCL prints a version banner through C stdio, which would
     otherwise be flushed behind it at exit."""
@@ -440,6 +475,15 @@ def main():
                 oc["C2 4K G_struct q75 420 x1 (latency)"] = run_config(
                     sj, torch, eng, [host[0]] if args.input == "struct" else [synth.g_struct(W, H, 7654321)], 1, 75.0,
                     sj.YUV_420, digests["struct4k|420|q75|m0"]["md5"], reps=50)
+                g4k = [host[0]] if args.input == "struct" else [synth.g_struct(W, H, 7654321)]
+                oc["C2 4K G_struct q75 420 default parameters (method 4) x32"] = run_batch_config(
+                    sj, torch, eng, g4k, 32, sj.YUV_420, 4, digests["struct4k|420|q75|m4"])
+                c5q = np.array(digests["recompress|r90|m0"]["source_quant"], np.uint8).reshape(2, 64)
+                c5q = np.clip((c5q.astype(np.float64) * 100.0 / 90.0 + 0.5).astype(np.int64), 1, 255).astype(np.uint8)
+                oc["C5 4K recompress r=90 method 0 x32"] = run_batch_config(
+                    sj, torch, eng, g4k, 32, sj.YUV_420, 0, digests["recompress|r90|m0"], quant=c5q)
+                oc["C5 4K recompress r=90 default parameters x32"] = run_batch_config(
+                    sj, torch, eng, g4k, 32, sj.YUV_420, 4, digests["recompress|r90|default"], quant=c5q)
             except Exception as exc:
                 oc["error"] = repr(exc)
             res["other_configs"] = oc

@@ -6,7 +6,6 @@
 #include <string.h>
 
 #include <algorithm>
-#include <queue>
 #include <vector>
 
 namespace sjpeg_host {
@@ -509,7 +508,7 @@ void AdaptQuantMatrices(const uint32_t hist[2][64][128], int nb_comps, uint8_t q
 // all-ones code, which JPEG forbids for real symbols), the length histogram limited to 16 bits
 // (T.81 K.2), symbols listed by (length, value).  The reference keeps ties out of the merge order with
 // a combined key (weight << 9 | id), a merged node inheriting the id of its heavier child: the same
-// strict order is used here, on an explicit tree with a priority queue.
+// strict order is used here, on an explicit tree with a heap of the open nodes.
 namespace {
 
 struct TreeNode {
@@ -518,12 +517,35 @@ struct TreeNode {
   int parent;                                 // index into the node array, -1 for the root
 };
 
-struct LighterFirst {                         // priority_queue keeps the LARGEST on top: invert
-  const std::vector<TreeNode>* nodes;
-  bool operator()(int a, int b) const {
-    const TreeNode& x = (*nodes)[a];
-    const TreeNode& y = (*nodes)[b];
-    return x.weight != y.weight ? x.weight > y.weight : x.id > y.id;
+// The open nodes as a binary min-heap of node indices on a fixed array (no allocation: a batch codes a
+// table per component and frame between two device passes).  Order: (weight, id), both ascending.
+struct OpenNodes {
+  const TreeNode* nodes;
+  int heap[258];
+  int n = 0;
+  bool Before(int a, int b) const {
+    const TreeNode& x = nodes[a];
+    const TreeNode& y = nodes[b];
+    return x.weight != y.weight ? x.weight < y.weight : x.id < y.id;
+  }
+  void Push(int v) {
+    int i = n++;
+    while (i > 0 && Before(v, heap[(i - 1) >> 1])) { heap[i] = heap[(i - 1) >> 1]; i = (i - 1) >> 1; }
+    heap[i] = v;
+  }
+  int Pop() {                                 // the lightest
+    const int top = heap[0], v = heap[--n];
+    int i = 0;
+    for (;;) {
+      int c = 2 * i + 1;
+      if (c >= n) break;
+      if (c + 1 < n && Before(heap[c + 1], heap[c])) ++c;
+      if (!Before(heap[c], v)) break;
+      heap[i] = heap[c];
+      i = c;
+    }
+    if (n > 0) heap[i] = v;
+    return top;
   }
 };
 
@@ -551,36 +573,38 @@ void BuildOptimalSpec(const uint32_t* freq, int size, HuffSpec* out) {
   constexpr int kLongest = 32, kLimit = 16;
   memset(out->syms, 0, sizeof(out->syms));
   memset(out->bits, 0, sizeof(out->bits));
-  std::vector<TreeNode> nodes;
-  nodes.reserve(2 * (size + 1));
+  TreeNode nodes[2 * 257];
+  int nnodes = 0;
   for (int sym = 0; sym < size; ++sym) {
-    if (freq[sym] > 0) nodes.push_back(TreeNode{freq[sym], sym, -1});
+    if (freq[sym] > 0) nodes[nnodes++] = TreeNode{freq[sym], sym, -1};
   }
-  const int used = static_cast<int>(nodes.size());
+  const int used = nnodes;
   out->nsyms = used;
   if (used == 0) return;
-  nodes.push_back(TreeNode{1, size, -1});     // the reserved leaf
+  nodes[nnodes++] = TreeNode{1, size, -1};    // the reserved leaf
   const int leaves = used + 1;
   {
-    std::priority_queue<int, std::vector<int>, LighterFirst> open(LighterFirst{&nodes});
-    for (int i = 0; i < used; ++i) open.push(i);
+    OpenNodes open;
+    open.nodes = nodes;
+    for (int i = 0; i < used; ++i) open.Push(i);
     // (the reserved leaf is not ranked by its key: it is the lighter half of the FIRST merge whatever
     // the weights, src/entropy.cc:304-305 appends it behind the sorted symbols)
-    for (int light = used; !open.empty(); light = -1) {
+    for (int light = used; open.n > 0; light = -1) {
       if (light < 0) {
-        if (open.size() == 1) break;
-        light = open.top(); open.pop();
+        if (open.n == 1) break;
+        light = open.Pop();
       }
-      const int heavy = open.top(); open.pop();
-      const int parent = static_cast<int>(nodes.size());
-      nodes.push_back(TreeNode{nodes[heavy].weight + nodes[light].weight, nodes[heavy].id, -1});
+      const int heavy = open.Pop();
+      const int parent = nnodes;
+      nodes[nnodes++] = TreeNode{nodes[heavy].weight + nodes[light].weight, nodes[heavy].id, -1};
       nodes[light].parent = nodes[heavy].parent = parent;
-      open.push(parent);
+      open.Push(parent);
     }
   }
   // depth of every node, root first (a parent is always created after its children)
-  std::vector<int> depth(nodes.size(), 0);
-  for (int i = static_cast<int>(nodes.size()) - 2; i >= 0; --i) depth[i] = depth[nodes[i].parent] + 1;
+  int depth[2 * 257];
+  depth[nnodes - 1] = 0;
+  for (int i = nnodes - 2; i >= 0; --i) depth[i] = depth[nodes[i].parent] + 1;
   uint8_t count[kLongest];                    // count[l]: leaves with a code of l + 1 bits
   memset(count, 0, sizeof(count));
   int length_of[257];
@@ -593,11 +617,16 @@ void BuildOptimalSpec(const uint32_t* freq, int size, HuffSpec* out) {
     if (len > longest) longest = len;
   }
   // the symbol list: by code length, then by value -- with the lengths of the unlimited tree
+  // (counting sort: where the symbols of every length start, then one pass over the symbols)
+  int next_of[kLongest + 1];
   int fill = 0;
   for (int len = 1; len <= longest; ++len) {
-    for (int sym = 0; sym < size; ++sym) {
-      if (length_of[sym] == len) out->syms[fill++] = static_cast<uint8_t>(sym);
-    }
+    next_of[len] = fill;
+    fill += count[len - 1];
+  }
+  // (the reserved leaf is not listed: it is the last of the longest length)
+  for (int sym = 0; sym < size; ++sym) {
+    if (length_of[sym] > 0) out->syms[next_of[length_of[sym]]++] = static_cast<uint8_t>(sym);
   }
   LimitCodeLengths(count, longest, kLimit);
   int last = kLimit;                          // the reserved leaf is the last code of the longest length

@@ -102,8 +102,9 @@ constexpr int kOffAcm = kOffAc + 2 * 256 * 4;                   // uint32[2][10]
 constexpr int kOffZrl = kOffAcm + 2 * 160 * 4;                  // uint4[2][4]: ZRL patterns
 constexpr int kOffMisc = kOffZrl + 128;                         // scan scratch
 constexpr int kLdsBytes = kOffMisc + 64;                        // 48592: three workgroups per CU
-constexpr int kOffStats = kLdsBytes;                            // kKindStats only: u32[2][272]
-constexpr int kLdsBytesStats = kOffStats + 2 * 272 * 4;
+constexpr int kOffStats = kLdsBytes;                            // kKindStats only: u32[2 replicas][2][272]
+constexpr int kLdsBytesStats = kOffStats + 2 * 2 * 272 * 4;
+static_assert(3 * kLdsBytesStats <= 160 * 1024, "three workgroups per CU (statistics kind)");
 static_assert(kWinWords * 4 >= 1152 + 512 && kWinWords >= 64 + 512 + 512, "window region too small");
 static_assert(3 * kLdsBytes <= 160 * 1024, "three workgroups per CU");
 

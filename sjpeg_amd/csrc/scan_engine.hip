@@ -123,6 +123,9 @@ struct sjpeg_hip_engine {
   hipStream_t tables_stream = nullptr, header_stream = nullptr;
   DevBuf<uint32_t> seg_words, seg_nbits, pool, pool_ctr, seg_xbase, ubuf, chunk_ff, partial, replay;
   int replay_w = 0, replay_h = 0, replay_mode = 0, replay_nframes = 0;   // what `replay` holds (0 = nothing)
+  // A batch coded in parts (sjpeg_hip_encode_batch_src): the statistics / replay calls of a part address the
+  // kept blocks of frames [replay_first, replay_first + nframes) of a buffer for replay_total frames.
+  int replay_first = 0, replay_total = 0;
   DevBuf<unsigned long long> seg_off, chunk_off, stamps;
   DevBuf<uint32_t> hdr_off;
   bool want_stamps = false;
@@ -596,9 +599,13 @@ static int scan_statistics(sjpeg_hip_engine* e, const sjpeg_hip_source* src, int
   if ((rc = e->partial.ensure(static_cast<size_t>(nframes) * g.nseg * words))) return rc;
   a.partial = e->partial.p;
   if (!histogram && (tables->flags & SJPEG_HIP_QUANT_KEEP)) {
-    if ((rc = e->replay.ensure(static_cast<size_t>(nframes) * g.nseg * kScanThreads * 36))) return rc;
-    a.replay = e->replay.p;
-    e->replay_w = width; e->replay_h = height; e->replay_mode = yuv_mode; e->replay_nframes = nframes;
+    const size_t per_frame = static_cast<size_t>(g.nseg) * kScanThreads * 36;
+    const int total = e->replay_total > 0 ? e->replay_total : nframes;
+    const int first = e->replay_total > 0 ? e->replay_first : 0;
+    if (first < 0 || first + nframes > total) return fail(SJPEG_HIP_EINVAL, "kept-block range outside the batch");
+    if ((rc = e->replay.ensure(static_cast<size_t>(total) * per_frame))) return rc;
+    a.replay = e->replay.p + static_cast<size_t>(first) * per_frame;
+    e->replay_w = width; e->replay_h = height; e->replay_mode = yuv_mode; e->replay_nframes = total;
   }
   if (histogram) rc = launch_scan<kKindHisto>(yuv_mode, cls, dim3(g.nseg, nframes), st, a);
   else if (tables != nullptr && (tables->flags & SJPEG_HIP_QUANT_TRELLIS)) rc = launch_scan<kKindStatsTrellis>(yuv_mode, cls, dim3(g.nseg, nframes), st, a);
@@ -800,12 +807,14 @@ static int encode_scan_impl(sjpeg_hip_engine* e, const sjpeg_hip_source* src, in
 
   if (e->timing) HIP_TRY(hipEventRecord(e->ev[0], st));
   if (tables->flags & SJPEG_HIP_QUANT_REPLAY) {
+    const int first = e->replay_total > 0 ? e->replay_first : 0;
+    const int total = e->replay_total > 0 ? e->replay_total : nframes;
     if (e->replay.p == nullptr || e->replay_w != width || e->replay_h != height || e->replay_mode != yuv_mode ||
-        e->replay_nframes != nframes) {
+        e->replay_nframes != total || first < 0 || first + nframes > total) {
       return fail(SJPEG_HIP_EINVAL, "SJPEG_HIP_QUANT_REPLAY: no kept coefficients of this geometry "
                                     "(run the statistics pass with SJPEG_HIP_QUANT_KEEP first)");
     }
-    a.replay = e->replay.p;
+    a.replay = e->replay.p + static_cast<size_t>(first) * g.nseg * kScanThreads * 36;
     rc = launch_scan<kKindEncodeReplay>(yuv_mode, cls, dim3(g.nseg, nframes), st, a);
   } else if (tables->flags & SJPEG_HIP_QUANT_TRELLIS) {
     rc = launch_scan<kKindEncodeTrellis>(yuv_mode, cls, dim3(g.nseg, nframes), st, a);
@@ -1054,12 +1063,30 @@ struct BatchScratch {                 // per host thread: device scratch of sjpe
   void* d_hist = nullptr; size_t hist_cap = 0;
   void* d_sums = nullptr; size_t sums_cap = 0;
   void* d_freq = nullptr; size_t freq_cap = 0;
+  void* h_pinned = nullptr; size_t pinned_cap = 0;   // where the device's sums / counts land on the host
   int device = -1;
   void Drop() {
     if (d_hist) (void)hipFree(d_hist);
     if (d_sums) (void)hipFree(d_sums);
     if (d_freq) (void)hipFree(d_freq);
-    d_hist = d_sums = d_freq = nullptr; hist_cap = sums_cap = freq_cap = 0;
+    if (h_pinned) (void)hipHostFree(h_pinned);
+    for (auto& e : ev) { if (e) (void)hipEventDestroy(e); e = nullptr; }
+    d_hist = d_sums = d_freq = h_pinned = nullptr; hist_cap = sums_cap = freq_cap = pinned_cap = 0;
+  }
+  hipEvent_t ev[8] = {};                         // behind the read-backs of a part: sums [0..3], counts [4..7]
+  bool EnsureEvents() {
+    for (auto& e : ev) {
+      if (e == nullptr && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { e = nullptr; return false; }
+    }
+    return true;
+  }
+  bool EnsurePinned(size_t need) {
+    if (need <= pinned_cap) return true;
+    if (h_pinned) (void)hipHostFree(h_pinned);
+    h_pinned = nullptr; pinned_cap = 0;
+    if (hipHostMalloc(&h_pinned, need, hipHostMallocDefault) != hipSuccess) return false;
+    pinned_cap = need;
+    return true;
   }
   ~BatchScratch() { if (device >= 0) { (void)hipSetDevice(device); Drop(); } }
   bool Ensure(void** p, size_t* cap, size_t need) {
@@ -1072,6 +1099,7 @@ struct BatchScratch {                 // per host thread: device scratch of sjpe
   }
 };
 thread_local BatchScratch g_batch;
+
 }  // namespace
 
 int sjpeg_hip_encode_batch_src(sjpeg_hip_engine* engine, const sjpeg_hip_source* src,
@@ -1082,8 +1110,13 @@ int sjpeg_hip_encode_batch_src(sjpeg_hip_engine* engine, const sjpeg_hip_source*
   if (engine == nullptr || src == nullptr || quant_in == nullptr || nframes <= 0) {
     return fail(SJPEG_HIP_EINVAL, "null argument or nframes <= 0");
   }
+  if (d_out == nullptr || d_sizes == nullptr) return fail(SJPEG_HIP_EINVAL, "d_out/d_sizes == NULL");
   if (method < 0) method = 0;
   if (method > 6) return fail(SJPEG_HIP_EINVAL, "sjpeg_hip_encode_batch_src: methods 0..6 (trellis goes through the host API)");
+  struct PartsGuard {                              // the engine addresses whole calls again when this returns
+    sjpeg_hip_engine* e;
+    ~PartsGuard() { e->replay_first = 0; e->replay_total = 0; }
+  } parts_guard{engine};
   try {
     const bool adaptive = method >= 3, optimize = (method != 0) && (method != 3);
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -1103,67 +1136,113 @@ int sjpeg_hip_encode_batch_src(sjpeg_hip_engine* engine, const sjpeg_hip_source*
       sjpeg_hip_default_huffman(&t0);
       for (size_t f = 0; f < n; ++f) { tables[f] = t0; memcpy(&quant[f * 128], q0, 128); }
     }
-    if (adaptive) {
-      constexpr size_t kHist = 2 * 64 * 128 * sizeof(uint32_t);
-      constexpr size_t kSums = 2 * 64 * kAdaptDeltas * 2 * sizeof(int64_t), kTot = 2 * 64 * 2 * sizeof(int32_t);
-      if (!sc.Ensure(&sc.d_hist, &sc.hist_cap, n * kHist) || !sc.Ensure(&sc.d_sums, &sc.sums_cap, n * (kSums + kTot))) {
-        return fail(SJPEG_HIP_ENOMEM, "hipMalloc(batch scratch) failed");
+    // The batch is coded in PARTS (two halves from 24 frames on): every device pass of a part is one
+    // launch, and the host analysis a part needs between two passes -- the reference's float regression
+    // per frame (10 us), its Huffman table builder (10 us) -- runs while the device is busy with the
+    // other part's pass instead of leaving it idle (a quarter of the call for 32 4K frames).  Everything
+    // goes to the caller's stream in order; the host waits on events behind the read-backs only.
+    constexpr int kMaxParts = 4;
+    static const int parts_env = getenv("SJPEG_HIP_BATCH_PARTS") ? atoi(getenv("SJPEG_HIP_BATCH_PARTS")) : 0;   // (experiments)
+    // (measured: 32 4K frames 1.84 -> 1.61 ms in two parts, 16 frames 1.13 -> 1.21: parts of fewer than a dozen
+    // frames lose more to their smaller launches than the overlap gives)
+    int nparts = (n >= 24 && (adaptive || optimize)) ? 2 : 1;
+    if (parts_env >= 1 && parts_env <= kMaxParts && (adaptive || optimize) && n >= static_cast<size_t>(parts_env)) nparts = parts_env;
+    size_t part_lo[kMaxParts + 1];
+    for (int p = 0; p <= kMaxParts; ++p) {               // (the larger parts first: the engine scratch is sized once)
+      part_lo[p] = p >= nparts ? n : (n * p + nparts - 1) / nparts;
+    }
+    constexpr size_t kHist = 2 * 64 * 128 * sizeof(uint32_t);
+    constexpr size_t kSums = 2 * 64 * kAdaptDeltas * 2 * sizeof(int64_t), kTot = 2 * 64 * 2 * sizeof(int32_t);
+    constexpr size_t kFreq = 2 * 272 * sizeof(uint32_t);
+    if (adaptive && (!sc.Ensure(&sc.d_hist, &sc.hist_cap, n * kHist) || !sc.Ensure(&sc.d_sums, &sc.sums_cap, n * (kSums + kTot)))) {
+      return fail(SJPEG_HIP_ENOMEM, "hipMalloc(batch scratch) failed");
+    }
+    if (optimize && !sc.Ensure(&sc.d_freq, &sc.freq_cap, n * kFreq)) return fail(SJPEG_HIP_ENOMEM, "hipMalloc(batch scratch) failed");
+    if (!sc.EnsurePinned(n * (kSums + kTot + kFreq)) || !sc.EnsureEvents()) return fail(SJPEG_HIP_ENOMEM, "hipHostMalloc / hipEventCreate(batch scratch) failed");
+    uint8_t* const h_sums = static_cast<uint8_t*>(sc.h_pinned);                  // [n][kSums] then [n][kTot]
+    uint8_t* const h_freq = h_sums + n * (kSums + kTot);                          // [n][kFreq]
+    auto part_source = [&](size_t f0) {
+      sjpeg_hip_source s = *src;
+      for (int i = 0; i < 3; ++i) {
+        if (s.plane[i] != nullptr) s.plane[i] = static_cast<const uint8_t*>(s.plane[i]) + static_cast<int64_t>(f0) * s.frame_stride[i];
       }
+      return s;
+    };
+    if (adaptive) {
       int64_t* const d_sums = static_cast<int64_t*>(sc.d_sums);
       int32_t* const d_tot = reinterpret_cast<int32_t*>(static_cast<uint8_t*>(sc.d_sums) + n * kSums);
-      int rc = sjpeg_hip_scan_histogram_src(engine, src, width, height, yuv_mode, nframes,
-                                            static_cast<uint32_t*>(sc.d_hist), stream);
-      if (rc == 0) {
-        rc = sjpeg_hip_adapt_sums(static_cast<const uint32_t*>(sc.d_hist), nframes,
-                                  reinterpret_cast<const uint8_t(*)[64]>(&quant[0]), min_quant, d_sums, d_tot, stream);
-      }
-      if (rc != 0) return rc;
-      std::vector<uint8_t> host(n * (kSums + kTot));
-      if (hipMemcpyAsync(host.data(), sc.d_sums, host.size(), hipMemcpyDeviceToHost, st) != hipSuccess ||
-          hipStreamSynchronize(st) != hipSuccess) {
-        return fail(SJPEG_HIP_ERUNTIME, "analysis sums read-back failed");
-      }
-      for (size_t f = 0; f < n; ++f) {
-        sjpeg_hip_adapt_quant_sums(reinterpret_cast<const int64_t*>(host.data() + f * kSums),
-                                   reinterpret_cast<const int32_t*>(host.data() + n * kSums + f * kTot), yuv_mode,
-                                   reinterpret_cast<uint8_t(*)[64]>(&quant[f * 128]), min_quant, q_bias,
-                                   qdelta_max_luma, qdelta_max_chroma, &tables[f]);
+      for (int p = 0; p < nparts; ++p) {
+        const size_t f0 = part_lo[p], nf = part_lo[p + 1] - f0;
+        const sjpeg_hip_source ps = part_source(f0);
+        uint32_t* const d_hist = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(sc.d_hist) + f0 * kHist);
+        int rc = sjpeg_hip_scan_histogram_src(engine, &ps, width, height, yuv_mode, static_cast<int>(nf), d_hist, stream);
+        if (rc == 0) {
+          rc = sjpeg_hip_adapt_sums(d_hist, static_cast<int>(nf), reinterpret_cast<const uint8_t(*)[64]>(&quant[0]), min_quant,
+                                    d_sums + f0 * (kSums / sizeof(int64_t)), d_tot + f0 * (kTot / sizeof(int32_t)), stream);
+        }
+        if (rc != 0) return rc;
+        HIP_TRY(hipMemcpyAsync(h_sums + f0 * kSums, d_sums + f0 * (kSums / sizeof(int64_t)), nf * kSums, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(h_sums + n * kSums + f0 * kTot, d_tot + f0 * (kTot / sizeof(int32_t)), nf * kTot, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipEventRecord(sc.ev[p], st));
       }
     }
-    std::vector<sjpeg_hip_huffman_spec> specs;
-    if (optimize) {
-      constexpr size_t kFreq = 2 * 272 * sizeof(uint32_t);
-      if (!sc.Ensure(&sc.d_freq, &sc.freq_cap, n * kFreq)) return fail(SJPEG_HIP_ENOMEM, "hipMalloc(batch scratch) failed");
-      // the statistics pass leaves its quantized blocks behind (144 B each) and the encode pass
-      // replays them: no second colour conversion / DCT / quantization (the reference's stored
-      // run/levels, src/enc.cc:121-129,374-386)
-      // (measured: 3 % of the call for 32 4K frames -- writing and reading the blocks costs nearly what it saves)
-      for (size_t f = 0; f < n; ++f) tables[f].flags |= SJPEG_HIP_QUANT_KEEP;
-      const int rc = sjpeg_hip_scan_symbol_stats_multi(engine, src, width, height, yuv_mode, nframes, tables.data(),
-                                                       static_cast<uint32_t*>(sc.d_freq), stream);
-      if (rc != 0) return rc;
-      std::vector<uint32_t> freq(n * 2 * 272);
-      if (hipMemcpyAsync(freq.data(), sc.d_freq, n * kFreq, hipMemcpyDeviceToHost, st) != hipSuccess ||
-          hipStreamSynchronize(st) != hipSuccess) {
-        return fail(SJPEG_HIP_ERUNTIME, "symbol statistics read-back failed");
+    std::vector<sjpeg_hip_huffman_spec> specs(optimize ? n * 4 : 0);
+    // (part p's regression runs while the device works on the histogram of part p + 1 / the statistics of part p - 1)
+    for (int p = 0; p < nparts; ++p) {
+      const size_t f0 = part_lo[p], nf = part_lo[p + 1] - f0;
+      if (adaptive) {
+        HIP_TRY(hipEventSynchronize(sc.ev[p]));
+        for (size_t f = f0; f < f0 + nf; ++f) {
+          sjpeg_hip_adapt_quant_sums(reinterpret_cast<const int64_t*>(h_sums + f * kSums),
+                                     reinterpret_cast<const int32_t*>(h_sums + n * kSums + f * kTot), yuv_mode,
+                                     reinterpret_cast<uint8_t(*)[64]>(&quant[f * 128]), min_quant, q_bias,
+                                     qdelta_max_luma, qdelta_max_chroma, &tables[f]);
+        }
       }
-      specs.resize(n * 4);
-      for (size_t f = 0; f < n; ++f) tables[f].flags = (tables[f].flags & ~SJPEG_HIP_QUANT_KEEP) | SJPEG_HIP_QUANT_REPLAY;
-      for (size_t f = 0; f < n; ++f) sjpeg_hip_optimize_huffman(&freq[f * 2 * 272], yuv_mode, &specs[f * 4], &tables[f]);
+      if (optimize) {
+        // the statistics pass leaves its quantized blocks behind (144 B each) and the encode pass
+        // replays them: no second colour conversion / DCT / quantization (the reference's stored
+        // run/levels, src/enc.cc:121-129,374-386)
+        for (size_t f = f0; f < f0 + nf; ++f) tables[f].flags |= SJPEG_HIP_QUANT_KEEP;
+        engine->replay_total = nframes; engine->replay_first = static_cast<int>(f0);
+        const sjpeg_hip_source ps = part_source(f0);
+        uint32_t* const d_freq = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(sc.d_freq) + f0 * kFreq);
+        const int rc = sjpeg_hip_scan_symbol_stats_multi(engine, &ps, width, height, yuv_mode, static_cast<int>(nf), &tables[f0], d_freq, stream);
+        if (rc != 0) return rc;
+        HIP_TRY(hipMemcpyAsync(h_freq + f0 * kFreq, d_freq, nf * kFreq, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipEventRecord(sc.ev[kMaxParts + p], st));
+      }
     }
+    // (part p's table builder runs while the device counts the symbols of part p + 1 / codes part p - 1)
     std::vector<uint8_t> headers;
-    std::vector<size_t> offs(n + 1, 0);
-    uint8_t one[2048];
-    for (size_t f = 0; f < n; ++f) {
-      const size_t hs = sjpeg_hip_make_header_ex(width, height, yuv_mode, reinterpret_cast<const uint8_t(*)[64]>(&quant[f * 128]),
-                                                 optimize ? &specs[f * 4] : nullptr, one, sizeof(one));
-      if (hs == 0) return fail(SJPEG_HIP_EINVAL, "header generation failed");
-      headers.insert(headers.end(), one, one + hs);
-      offs[f + 1] = headers.size();
+    std::vector<size_t> offs;
+    for (int p = 0; p < nparts; ++p) {
+      const size_t f0 = part_lo[p], nf = part_lo[p + 1] - f0;
+      if (optimize) {
+        HIP_TRY(hipEventSynchronize(sc.ev[kMaxParts + p]));
+        for (size_t f = f0; f < f0 + nf; ++f) {
+          tables[f].flags = (tables[f].flags & ~SJPEG_HIP_QUANT_KEEP) | SJPEG_HIP_QUANT_REPLAY;
+          sjpeg_hip_optimize_huffman(reinterpret_cast<const uint32_t*>(h_freq + f * kFreq), yuv_mode, &specs[f * 4], &tables[f]);
+        }
+        engine->replay_total = nframes; engine->replay_first = static_cast<int>(f0);
+      }
+      headers.clear();
+      offs.assign(nf + 1, 0);
+      uint8_t one[2048];
+      for (size_t f = f0; f < f0 + nf; ++f) {
+        const size_t hs = sjpeg_hip_make_header_ex(width, height, yuv_mode, reinterpret_cast<const uint8_t(*)[64]>(&quant[f * 128]),
+                                                   optimize ? &specs[f * 4] : nullptr, one, sizeof(one));
+        if (hs == 0) return fail(SJPEG_HIP_EINVAL, "header generation failed");
+        headers.insert(headers.end(), one, one + hs);
+        offs[f - f0 + 1] = headers.size();
+      }
+      const sjpeg_hip_source ps = part_source(f0);
+      const int rc_enc = sjpeg_hip_encode_scan_multi(engine, &ps, width, height, yuv_mode, static_cast<int>(nf), &tables[f0], headers.data(),
+                                                     offs.data(), /*append_eoi=*/1, static_cast<uint8_t*>(d_out) + f0 * out_stride,
+                                                     out_stride, d_sizes + f0, stream);
+      if (rc_enc != 0) return rc_enc;
     }
-    const int rc_enc = sjpeg_hip_encode_scan_multi(engine, src, width, height, yuv_mode, nframes, tables.data(), headers.data(),
-                                       offs.data(), /*append_eoi=*/1, d_out, out_stride, d_sizes, stream);
-    return rc_enc;
+    return 0;
   } catch (...) {
     return fail(SJPEG_HIP_ENOMEM, "out of host memory");
   }

@@ -27,8 +27,12 @@ __device__ __forceinline__ void race_point(int code, int n) {
 #define RACE_POINT(n)
 #endif
 
+// (the histogram kind needs the block slots and nothing else in LDS: four workgroups per CU instead of
+// three, with its registers held to the 128 that leaves room for -- 131 without the bound.  Packed RGB
+// only: ROCm 7.2's clang crashes in its register allocator on the 4-byte-pixel instantiation with the
+// smaller LDS block)
 template <int MODE, int KINDX, int SRC>
-__global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) {
+__global__ __launch_bounds__(kScanThreads, (KINDX == kKindHisto && SRC == kSrcRgb24) ? 4 : 1) void scan_segments(const ScanArgs a) {
   constexpr bool TRELLIS = (KINDX == kKindEncodeTrellis || KINDX == kKindStatsTrellis);
   constexpr bool REPLAY = (KINDX == kKindEncodeReplay);
   constexpr int KIND = (KINDX == kKindEncodeTrellis || KINDX == kKindEncodeReplay) ? kKindEncode : (KINDX == kKindStatsTrellis) ? kKindStats : KINDX;
@@ -37,7 +41,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
   constexpr int PX = G::kMcuPx;
   // static, not `extern __shared__`: the address of a dynamic block is resolved after instruction
   // selection and leaves a `+ 0` in ~65 address computations of this kernel
-  __shared__ __attribute__((aligned(16))) unsigned char smem[(KIND == kKindStats) ? kLdsBytesStats : kLdsBytes];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[(KIND == kKindStats) ? kLdsBytesStats : (KIND == kKindHisto && SRC == kSrcRgb24) ? kSamplesBytes : kLdsBytes];
   uint32_t* const win = reinterpret_cast<uint32_t*>(smem + kOffWin);
   uint4* const lq = reinterpret_cast<uint4*>(smem + kOffQ);
   uint32_t* const lac = reinterpret_cast<uint32_t*>(smem + kOffAc);
@@ -66,6 +70,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
   prio_stress<SJPEG_HIP_PRIO_STRESS>(0);
 #endif
   auto stage_tables = [&]() {
+    if (KIND == kKindHisto) return;                // (no table is read, and there may be no room for one)
     const DevTables* t = a.tables + frame * a.tables_stride;
     // two contiguous groups, 16 bytes per thread: quantizer + DC codes + level bounds into the idle
     // window, AC codes + merged code words + ZRL patterns behind it
@@ -80,7 +85,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
     }
     if (KIND == kKindStats) {                      // the symbol counters (their own LDS behind everything else)
       uint32_t* const lf0 = reinterpret_cast<uint32_t*>(smem + kOffStats);
-      for (int i = tid; i < kStatsWords; i += kScanThreads) lf0[i] = 0;
+      for (int i = tid; i < 2 * kStatsWords; i += kScanThreads) lf0[i] = 0;
     }
   };
 
@@ -401,25 +406,32 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
     __syncthreads();                            // every thread holds its samples: slots are free
     RACE_POINT(15);
     uint32_t* const lh = reinterpret_cast<uint32_t*>(smem);
-    // Bins 0..3 (one word per position) take most of the hits and every lane of a wave hits the
-    // SAME word: an LDS atomic serialises those lanes.  Eight replicas of that word, picked by
-    // lane, cut the conflicts eight-fold; they are folded back before the flush.  (A position
-    // has at most 252 entries per workgroup: the 8-bit fields cannot overflow.)
-    constexpr int kReps = 8;
-    uint32_t* const rep = lh + kHistoWords;       // [2][64][kReps]
-    for (int i = tid; i < kHistoWords + 2 * 64 * kReps; i += kScanThreads) lh[i] = 0;
+    // LDS layout, 40 words per (table, position): eight replicas of the word of bins 0..3, picked by
+    // lane -- those bins take most of the hits of ordinary pictures and every lane of a wave hits the
+    // SAME word, which an LDS atomic serialises; the replicas are folded at the flush --, the words
+    // of bins 4..127, and one word for bin 128 = everything above (the reference's histogram stops at 127;
+    // never flushed).  8-bit counters: a workgroup has at most 252 blocks, a field cannot overflow.
+    constexpr int kPosWords = 40, kReps = 8;
+    for (int i = tid; i < 2 * 64 * kPosWords; i += kScanThreads) lh[i] = 0;
     RACE_POINT(16);
     __syncthreads();
     int acc[8];
+    const uint32_t one = emits ? 1u : 0u;          // (blocks that are not coded add zero)
+    const uint32_t rep_off = static_cast<uint32_t>(tid & (kReps - 1)) * 4u;
     auto bump = [&](int row, const int* ac8) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int c = ac8[i] >> 16;
-        const uint32_t bin = static_cast<uint32_t>(c < 0 ? -c : c) >> 2;
-        if (emits && bin < 128u) {
-          const int pos = tbl * 64 + row * 8 + i;
-          uint32_t* const w = (bin < 4u) ? &rep[pos * kReps + (tid & (kReps - 1))] : &lh[pos * 32 + (bin >> 2)];
-          atomicAdd(w, 1u << (8 * (bin & 3)));
+      for (int k = 0; k < 4; ++k) {
+        // both coefficients of a pair at once: |c| >> 2, clamped to 128 (packed 16-bit operations)
+        const s16x2 c = as_pk(__builtin_amdgcn_perm(static_cast<uint32_t>(ac8[2 * k + 1]), static_cast<uint32_t>(ac8[2 * k]), 0x07060302u));
+        const u16x2 mag = __builtin_bit_cast(u16x2, __builtin_elementwise_max(c, pk_const(0, 0) - c));
+        uint32_t bins;
+        asm("v_pk_min_u16 %0, %1, %2" : "=v"(bins) : "v"(__builtin_bit_cast(uint32_t, mag >> u16x2{2, 2})), "v"(0x00800080u));
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          const uint32_t bin = half ? bins >> 16 : bins & 0xffffu;
+          const uint32_t base = static_cast<uint32_t>((tbl * 64 + row * 8 + 2 * k + half) * kPosWords * 4);
+          const uint32_t at = bin < 4u ? rep_off : (bin & ~3u) + 28u;            // byte offset inside the position
+          atomicAdd(reinterpret_cast<uint32_t*>(smem + base + at), one << ((bin & 3u) * 8u));
         }
       }
     };
@@ -433,16 +445,22 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
     fdct_row8_pk<31521, 29692, 26722, 22725, 17855, 12299, 6270>(p[7], acc); bump(7, acc);
     RACE_POINT(17);
     __syncthreads();
-    if (tid < 128) {                               // fold the replicas into word 0 of their position
-      uint32_t sum = 0;
-#pragma unroll
-      for (int r = 0; r < kReps; ++r) sum += rep[tid * kReps + r];
-      lh[tid * 32] += sum;
-    }
     RACE_POINT(18);
-    __syncthreads();
+    // this workgroup's partial: u8 counters [2][64][128], four to a word
     uint32_t* const dst = a.partial + (static_cast<size_t>(frame) * a.nseg + seg) * kHistoWords;
-    for (int i = tid; i < kHistoWords; i += kScanThreads) dst[i] = lh[i];
+    for (int i = tid; i < kHistoWords; i += kScanThreads) {
+      const int pos = i >> 5, w = i & 31;
+      const uint32_t* const ph = lh + pos * kPosWords;
+      uint32_t v;
+      if (w == 0) {
+        v = 0;
+#pragma unroll
+        for (int r = 0; r < kReps; ++r) v += ph[r];
+      } else {
+        v = ph[kReps - 1 + w];
+      }
+      dst[i] = v;
+    }
     return;
   }
   uint32_t ent[32];                             // natural order, 2 entries per dword
@@ -682,7 +700,10 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
   }
   *reinterpret_cast<uint4*>(tail) = make_uint4(nz_lo, nz_hi, dc_word, part_info);
 
-  uint32_t* const lf = reinterpret_cast<uint32_t*>(smem + kOffStats);   // kKindStats: [2][272], 256 AC then 16 DC
+  // kKindStats: [2][272] counters, 256 AC then 16 DC, in TWO copies picked by lane parity: the lanes of a
+  // wave count the same few symbols most of the time and an LDS atomic serialises the lanes that hit one
+  // word; the copies are added up at the flush
+  uint32_t* const lf = reinterpret_cast<uint32_t*>(smem + kOffStats) + (KIND == kKindStats ? (tid & 1) * kStatsWords : 0);
   if (KIND == kKindStats) {
     // Symbol statistics for optimised Huffman tables (reference AddEntropyStats,
     // src/entropy.cc:208-227): per table, counts of AC symbols (run << 4 | size, ZRL, EOB) and
@@ -772,7 +793,8 @@ __global__ __launch_bounds__(kScanThreads) void scan_segments(const ScanArgs a) 
     RACE_POINT(20);
     __syncthreads();
     uint32_t* const dst = a.partial + (static_cast<size_t>(frame) * a.nseg + seg) * kStatsWords;
-    for (int i = tid; i < kStatsWords; i += kScanThreads) dst[i] = lf[i];
+    const uint32_t* const lf_all = reinterpret_cast<const uint32_t*>(smem + kOffStats);
+    for (int i = tid; i < kStatsWords; i += kScanThreads) dst[i] = lf_all[i] + lf_all[kStatsWords + i];
     return;
   }
 
