@@ -240,11 +240,9 @@ struct DeviceContext {
   bool EnsureRiskTable() {
     std::lock_guard<std::mutex> lock(g_risk_mutex);
     if (!LoadRiskTableFromEnv()) {
-      return Fail("the riskiness score table is not installed: SJPEG_YUV_AUTO / SjpegCompress / "
-                  "SjpegRiskiness need the reference's trained table (sjpeg_hip_set_riskiness_table(), the file "
-                  "named by SJPEG_HIP_RISKINESS_TABLE, or riskiness.bin next to this library: "
-                  "tools/extract_riskiness_table.py writes it from a build of the reference), which this "
-                  "library does not ship");
+      return Fail("the riskiness score table was not found: SJPEG_YUV_AUTO / SjpegCompress / SjpegRiskiness need "
+                  "riskiness.bin (shipped next to libsjpeg_amd.so; a copy of the library installed elsewhere needs it "
+                  "beside it, the file named by SJPEG_HIP_RISKINESS_TABLE, or sjpeg_hip_set_riskiness_table())");
     }
     if (risk_generation == g_risk_generation) return true;
     if (d_risk == nullptr && hipMalloc(&d_risk, SJPEG_HIP_RISKINESS_TABLE_SIZE) != hipSuccess) return Fail("hipMalloc failed");

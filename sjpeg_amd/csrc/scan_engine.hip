@@ -801,7 +801,14 @@ static int encode_scan_impl(sjpeg_hip_engine* e, const sjpeg_hip_source* src, in
   s.append_eoi = append_eoi;
   s.out = static_cast<uint8_t*>(d_out); s.out_stride = out_stride;
   s.sizes = reinterpret_cast<unsigned long long*>(d_sizes);
-  s.seg_nbits64 = nullptr; s.total_bits_out = nullptr; s.subs = 1;
+  s.seg_nbits64 = nullptr; s.total_bits_out = nullptr; s.subs = 1; s.wide_subs = 0;
+  // few segments (one 4K frame: 791, one 8K 4:4:4 frame: 6172): one wave per 768 words of a slot instead of
+  // one per segment -- a 1030-word segment was two dependent round trips of one wave (8K 4:4:4: K3 38 us)
+  if (static_cast<size_t>(nframes) * g.nseg <= 8192 && (plan.slot_words & 3u) == 0u && plan.slot_words >= 776u) {
+    s.subs = (plan.slot_words + kWideSpec * 256u - 1u) / (kWideSpec * 256u);
+    s.wide_subs = s.subs > 1u ? 1u : 0u;
+    if (!s.wide_subs) s.subs = 1;
+  }
   s.hdr_off = multi ? e->hdr_off.p : nullptr;
   s.seg_first = a.seg_first; s.rst_tail = rst_tail;
 
@@ -834,7 +841,7 @@ static int encode_scan_impl(sjpeg_hip_engine* e, const sjpeg_hip_source* src, in
   uint32_t gx = 4096u / static_cast<uint32_t>(nframes);
   if (gx < 64) gx = 64;
   if (gx > max_chunks) gx = max_chunks;
-  hipLaunchKernelGGL(place_segments, dim3((g.nseg + 3) / 4, nframes), dim3(kThreads), 0, hs, s);
+  hipLaunchKernelGGL(place_segments, dim3((g.nseg * s.subs + 3) / 4, nframes), dim3(kThreads), 0, hs, s);
   HIP_TRY(hipGetLastError());
   hipLaunchKernelGGL(scan_chunk_offsets, dim3(nframes), dim3(kThreads), 0, hs, s);
   HIP_TRY(hipGetLastError());

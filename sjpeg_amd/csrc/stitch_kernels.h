@@ -28,7 +28,8 @@ struct StitchArgs {
   unsigned long long* sizes;
   const unsigned long long* seg_nbits64;   // band stitch: lengths as uint64 (else NULL)
   unsigned long long* total_bits_out;      // band encode: where the bit count of the band goes (else NULL)
-  uint32_t subs;                           // K3: waves per segment (1 unless segments are whole bands)
+  uint32_t subs;                           // K3: waves per segment (1 unless segments are whole bands, or wide_subs)
+  uint32_t wide_subs;                      // K3: an ordinary call whose (few) segments are cut into sub-ranges of 768 words
   int seg_first;                           // restart mode, band of a frame: frame-level index of segment 0 ...
   int rst_tail;                            // ... and whether the band's last interval gets its marker too (it is not the frame's last)
 };
@@ -130,7 +131,7 @@ __global__ __launch_bounds__(kThreads) void place_segments(const StitchArgs a) {
   // (subs == 1, the loop below takes the rare longer rest), whole bands are cut into many
   const uint32_t unit = blockIdx.x * (kThreads / kPlaceLanes) + (threadIdx.x >> 6);
   const int sc0 = static_cast<int>(unit / a.subs);
-  const uint32_t ibase = (unit % a.subs) * (kSpec * kPlaceLanes);
+  const uint32_t ibase = (unit % a.subs) * (a.wide_subs ? kWideSpec * 256u : kSpec * kPlaceLanes);
   if (sc0 >= a.nseg) return;
   const unsigned long long* off = a.seg_off + static_cast<size_t>(frame) * (a.nseg + 1);
   const uint32_t* segw = a.seg_words + static_cast<size_t>(frame) * a.nseg * a.slot_words;
@@ -140,16 +141,19 @@ __global__ __launch_bounds__(kThreads) void place_segments(const StitchArgs a) {
   // store instructions instead of 24 and 11: with one dword per lane the kernel was bound by the
   // number of memory instructions, not by bytes.  NARROW (bands cut into sub-ranges, slots that are
   // not a multiple of 16 bytes): one word per lane.
-  const bool wide = a.subs == 1u && (a.slot_words & 3u) == 0u && a.slot_words >= 776u;      // uniform
+  // (wide_subs: an ordinary call with few segments cuts them into sub-ranges of kWideSpec * 256 words too,
+  // one wave each, so that a long segment is not one wave's chain of round trips)
+  const bool wide = (a.subs == 1u || a.wide_subs) && (a.slot_words & 3u) == 0u && a.slot_words >= 776u;      // uniform
   uint32_t spec[kSpec][2];
   uint4 wq[kWideSpec];
   uint32_t wx[kWideSpec];
   if (wide) {
 #pragma unroll
     for (int k = 0; k < kWideSpec; ++k) {                    // words 0 .. 771: inside the slot whatever the length
-      const uint32_t i = 256u * k + 4u * (threadIdx.x & 63);
+      // (a last sub-range may reach behind the slot: clamped like the batches of the loop below)
+      const uint32_t i = min(ibase + 256u * k + 4u * (threadIdx.x & 63), a.slot_words - 4u);
       wq[k] = *reinterpret_cast<const uint4*>(src + i);
-      wx[k] = src[i + 4];
+      wx[k] = src[min(i + 4u, a.slot_words - 1u)];
     }
   } else {
 #pragma unroll
@@ -306,8 +310,9 @@ __global__ __launch_bounds__(kThreads) void place_segments(const StitchArgs a) {
     };
 #pragma unroll
     for (int k = 0; k < kWideSpec; ++k) {
-      if (256u * k < nwords) batch(256u * k, wq[k], wx[k]);
+      if (ibase + 256u * k < nwords) batch(ibase + 256u * k, wq[k], wx[k]);
     }
+    if (a.wide_subs) { if (ff_chunk != 0xffffffffu) ff_flush(); return; }   // (the other sub-ranges have their own waves)
     // longer segments: the words of batch k + 1 are requested before batch k is worked on
     // A lane whose four words start inside the slot must get exactly those (a segment that is not
     // `long_seg` has up to slot_words - 2 of them); only the fifth word of the slot's last lane,
@@ -339,7 +344,9 @@ __global__ __launch_bounds__(kThreads) void place_segments(const StitchArgs a) {
       }
     }
   } else {
-    const uint32_t iend = a.subs == 1u ? nwords : min(nwords, ibase + kSpec * kPlaceLanes);
+    // (a long segment of a call with wide sub-ranges: the last of them takes what lies behind the slot)
+    const bool takes_rest = a.subs == 1u || (a.wide_subs && (unit % a.subs) == a.subs - 1u);
+    const uint32_t iend = takes_rest ? nwords : min(nwords, ibase + kSpec * kPlaceLanes);
     for (uint32_t i0 = ibase; i0 < iend; i0 += kPlaceLanes) {
       const uint32_t i = i0 + lane;
       one(i, seg_word(sc0, i), seg_word(sc0, i + 1));

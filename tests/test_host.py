@@ -206,6 +206,19 @@ def test_optimal_huffman_ties_and_long_codes_match_oracle(oracle):
                 assert list(sp.syms[:n]) == [int(x) for x in syms][:n]
 
 
+def test_shipped_riskiness_table_is_the_reference_table():
+    """sjpeg_amd/csrc/riskiness.bin (reference DATA, shipped with attribution: riskiness.NOTICE) is the table
+    of the reference build, where there is one; its digest is pinned either way."""
+    import hashlib
+    data = open(os.path.join(sj.CSRC, "riskiness.bin"), "rb").read()
+    assert len(data) == 117649 and hashlib.md5(data).hexdigest() == "56618d0235dbfddab20358969d2dd241"
+    from oracle import refso
+    if refso.available():
+        import ctypes
+        ref = bytes((ctypes.c_uint8 * 117649).in_dll(ctypes.CDLL(refso.REF_SO), "_ZN5sjpeg15kSharpnessScoreE"))
+        assert ref == data
+
+
 def test_header_with_custom_tables_matches_golden(golden_small, oracle, img128):
     # method-1 golden stream: its header must be reproduced from oracle statistics
     want = golden_small["test128|128x128|420|q75|m1"]
