@@ -31,7 +31,8 @@ Rank 0 prints ONE JSON line.
   tests/golden/digests.json.  Rank 0 at N = 1 only.
 * N > 1: a second timed region with the exchange step INSIDE it (`with_gather`): the streams of
   every step are packed on the device (sjpeg_hip_compact_streams) and gathered to rank 0 over
-  RCCL under the next step's kernels (sjpeg_amd.dist.exchange_loop).
+  RCCL by the library's own communicator (sjpeg_hip_gather_rows / _bytes, exact lengths) under the next
+  step's kernels (sjpeg_amd.dist.exchange_loop).
 * `cpu_baseline` times the real reference (oracle/_ref, SSE2 path, "reference") or, if that .so
   cannot load, the plain-C oracle ("port") on this host's cores on a bounded sample.
 """
@@ -447,9 +448,10 @@ def main():
                 ok = all(fr[k] == coded[k // world] for k in ids) and all(f is not None and f[:2] == b"\xff\xd8" for f in fr)
             with_gather = {"value": round(W * H * F * world * args.steps / gdt / 1e6, 1), "unit": "Mpixels/s",
                            "ms_per_step": round(gdt / args.steps * 1e3, 4), "verified": bool(ok),
-                           "what": "encode + device-side packing (sjpeg_hip_compact_streams) + all_gather of sizes + "
-                                   "RCCL gather of the packed streams into rank 0's HBM, the exchange of step s "
-                                   "under the kernels of step s + 1; host copy / concatenation not included"}
+                           "what": "encode + device-side packing (sjpeg_hip_compact_streams) + the C-ABI exchange "
+                                   "(sjpeg_hip_gather_rows: RCCL all-gather of one row of sizes per rank, one small host "
+                                   "read; sjpeg_hip_gather_bytes: exact-length ncclSend / ncclRecv into rank 0's HBM), the "
+                                   "exchange of step s under the kernels of step s + 1; host copy / concatenation not included"}
         except Exception as exc:                 # the exchange is outside the headline metric: report, do not lose the line
             with_gather = {"error": repr(exc)}
         dog.cancel()

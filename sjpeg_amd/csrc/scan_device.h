@@ -37,10 +37,11 @@ struct alignas(16) DevTables {
   uint32_t pad_a[6];
   // group B (3456 B)
   uint32_t ac[2][256];
-  // Lean entropy walk: row = clz(level) - 22 (level 1..1023 <=> clz 31..22), column = run & 15:
+  // Lean entropy walk, indexed [run & 15][clz(level) - 22] (level 1..1023 <=> clz 31..22):
   // (code << n) | (code length + n) << 27, i.e. everything of a run/size symbol but the n suffix
-  // bits, in one word.
-  uint32_t acm[2][10][16];
+  // bits, in one word.  Run-major: the symbols a picture is made of (runs 0..3, 1..7 level bits) are
+  // 28 words in a row, one LDS bank each -- size-major (rows of 16 runs) they shared eight banks.
+  uint32_t acm[2][16][10];
   // 1, 2 or 3 ZRL codes as a left-aligned 64-bit pattern {high word, low word, bits, 0} (index 0 unused):
   // what the stitch puts in front of a part whose first run is 16 or longer
   uint4 zrlpat[2][4];

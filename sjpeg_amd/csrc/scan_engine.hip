@@ -195,7 +195,7 @@ void digest_tables(const sjpeg_hip_scan_tables* t, DevTables* d) {
       for (int run = 0; run < 16; ++run) {
         const uint32_t cw = t->ac_codes[c][(run << 4) | n];
         const uint32_t len = cw & 0xffu, code = cw >> 16;
-        d->acm[c][10 - n][run] = len == 0u ? 0u : ((code << n) | ((len + n) << 27));
+        d->acm[c][run][10 - n] = len == 0u ? 0u : ((code << n) | ((len + n) << 27));
       }
     }
   }

@@ -891,7 +891,7 @@ __global__ __launch_bounds__(kScanThreads, (KINDX == kKindHisto && SRC == kSrcRg
   // stored (the quarter has room for exactly 8); the last, partial word stays in a register.
   // Code words come from the merged table (code << n | total length << 27), indexed by clz(level)
   // and run, so a symbol costs two LDS reads and about thirty simple instructions.
-  const uint32_t acm_base = static_cast<uint32_t>(kOffAcm) - 22u * 64u;   // row = clz - 22, 64 bytes per row
+  const uint32_t acm_base = static_cast<uint32_t>(kOffAcm) - 22u * 4u;    // word [run][clz - 22]: 40 bytes per run
   typedef uint16_t __attribute__((may_alias)) u16_alias2;
   auto walk_lean = [&](uint32_t unit, uint4 bt, uint32_t& rec_out, uint32_t& tail_out) {
     const uint32_t blk = unit & 255u, q = unit >> 8;
@@ -947,7 +947,7 @@ __global__ __launch_bounds__(kScanThreads, (KINDX == kKindHisto && SRC == kSrcRg
       uint32_t sgn;                                // bit 15 over the whole word (asm: the builtin is turned into compare + select)
       asm("v_bfe_i32 %0, %1, 15, 1" : "=v"(sgn) : "v"(e));
       lv = mag ^ (ones & sgn);
-      cw_at = (tb + nl * 64u) + run * 4u;
+      cw_at = (tb + nl * 4u) + run * 40u;
     };
     if (m) {
       int i = __builtin_ctz(m);
