@@ -259,7 +259,11 @@ __global__ __launch_bounds__(kThreads) void place_segments(const StitchArgs a) {
     // segments of tiny pictures, empty bands -- which takes the general path of one().
     const uint32_t edge_bits = len > lead ? (len - lead) & 31u : 0u;      // bits of the edge word that are this segment's
     const bool edge_easy = !has_next || (b2 - b1) >= 32u - edge_bits;
-    const uint32_t last_valid = (sc0 == a.nseg - 1) ? static_cast<uint32_t>(U - (wend - 1) * 4) : 4u;   // bytes of the frame's last word
+    // bytes of the edge word that belong to the stream: four, unless the frame ends inside it -- which
+    // is the LAST segment's edge word, or an earlier segment's when everything behind it is so short
+    // that it starts no word of its own (flat pictures with one-bit codes: found by the soak)
+    const unsigned long long edge_byte0 = (wbeg + n_int) * 4;
+    const uint32_t edge_valid = edge_byte0 >= U ? 0u : (U - edge_byte0 >= 4 ? 4u : static_cast<uint32_t>(U - edge_byte0));
     auto batch = [&](uint32_t i0, uint4 q, uint32_t x) {     // destination words i0 .. i0 + 255, four per lane
       const uint32_t i = i0 + 4u * lane;
       const uint32_t v[5] = {q.x, q.y, q.z, q.w, x};
@@ -285,8 +289,7 @@ __global__ __launch_bounds__(kThreads) void place_segments(const StitchArgs a) {
           const uint32_t idx = i + u;
           if (edge_here && idx == n_int) {
             o.w[u] = edge_easy ? ((o.w[u] & hi_mask) | tail) : gathered;
-            f[u] = (sc0 == a.nseg - 1) ? count_ff(o.w[u], static_cast<int>(last_valid))
-                                      : static_cast<uint32_t>(__popc(ff_bytes(o.w[u])));
+            f[u] = edge_valid == 4u ? static_cast<uint32_t>(__popc(ff_bytes(o.w[u]))) : count_ff(o.w[u], static_cast<int>(edge_valid));
           }
           if (idx < nwords) dst[idx] = o.w[u]; else f[u] = 0;
         }

@@ -396,6 +396,24 @@ def test_c5_end_to_end_4k(engine, digests):
         assert len(got) == digests[key]["size"] and hashlib.md5(got).hexdigest() == digests[key]["md5"], key
 
 
+def test_flat_pictures_with_one_bit_codes(oracle):
+    """Flat pictures coded with optimised tables are streams of one-bit codes: segments of a few dozen
+    bits, a last segment that may start no 32-bit word of its own -- then the frame ends inside an
+    EARLIER segment's last word, whose padding bytes must not be counted as 0xFF data (found by the
+    soak: sizes 1-3 bytes too long, zeros in front of the EOI)."""
+    for (w, h, q, method, mode) in ((123, 251, 75.0, 2, 4), (203, 158, 75.0, 6, 4), (193, 296, 0.0, 4, 1),
+                                    (219, 1356, 100.0, 2, 1), (131, 34, 100.0, 7, 3), (2027, 7, 3.0, 2, 3),
+                                    (2044, 30, 97.0, 2, 4), (1161, 2095, 90.0, 3, 4), (60, 250, 0.0, 3, 4),
+                                    (16, 16, 75.0, 1, 1), (8, 8, 50.0, 4, 4), (4000, 24, 75.0, 1, 1)):
+        for v in (0, 3, 77, 128, 200, 255):
+            img = np.full((h, w, 3), v, np.uint8)
+            got = sj.SjpegEncode(img, q, method, mode)
+            assert got == oracle.encode_method(img, q, mode, method), (w, h, q, method, mode, v)
+            if method <= 6:
+                got = sj.encode_device_method(dev(img), q, mode, method)[0]
+                assert got == oracle.encode_method(img, q, mode, method), ("batch", w, h, q, method, mode, v)
+
+
 # ---- other input layouts: BGRA / RGBA / gray / planar YUV / NV12 / NV21 -------------------------
 
 def _random_planes(rng, fmt, w, h):

@@ -15,7 +15,7 @@ if command -v hipcc >/dev/null 2>&1 || [ -x /opt/rocm/bin/hipcc ]; then
     make -s -C sjpeg_amd/csrc STRESS=$s || exit 1
     echo "== stress build $s"
     N=2 run python -m pytest tests -m gpu -x -q
-    N=1 run python tools/race_sweep.py
+    N=2 run python tools/race_sweep.py
     N=1 run python tools/gpu_soak.py $((40 + s)) 60
   done
   make -s -C sjpeg_amd/csrc || exit 1
