@@ -98,8 +98,8 @@ __global__ __launch_bounds__(kThreads) void scan_seg_offsets(const StitchArgs a)
 
 // 0x80 in every byte of w that equals 0xFF (exact, no carries between bytes)
 __device__ __forceinline__ uint32_t ff_bytes(uint32_t w) {
-  const uint32_t z = ~w;                                     // 0x00 where w has 0xFF
-  return ~(((z & 0x7f7f7f7fu) + 0x7f7f7f7fu) | z | 0x7f7f7f7fu);
+  // low seven bits all set <=> + 1 carries into bit 7 (never out of the byte), and bit 7 itself set
+  return ((w & 0x7f7f7f7fu) + 0x01010101u) & w & 0x80808080u;
 }
 __device__ __forceinline__ uint32_t count_ff(uint32_t w, int nbytes /*valid leading bytes, MSB first*/) {
   uint32_t n = 0;
