@@ -611,12 +611,17 @@ static int scan_statistics(sjpeg_hip_engine* e, const sjpeg_hip_source* src, int
   else if (tables != nullptr && (tables->flags & SJPEG_HIP_QUANT_TRELLIS)) rc = launch_scan<kKindStatsTrellis>(yuv_mode, cls, dim3(g.nseg, nframes), st, a);
   else rc = launch_scan<kKindStats>(yuv_mode, cls, dim3(g.nseg, nframes), st, a);
   if (rc) return rc;
-  // slices of the segments meet in the output with atomics: as many as it takes to fill the device
-  // (a single frame needs 32 of them, a batch brings its own parallelism and pays for every atomic:
-  // 32 4K histograms 0.65 ms with 32 slices, 0.58 ms with 8)
+  // Slices of the segments meet in the output with device-scope atomics, and those are what the summing
+  // kernel waits for: as FEW slices as still fill the device.  The histogram (4096 words x 4 counters per
+  // frame) wants about a thousand workgroups -- 16 frames: 63 us with 16 slices, 40 with 4, 38 with 2; a
+  // single frame needs its 32 --, the symbol counts (544 words) are small enough for the atomics not to
+  // matter and take the slices they can get (16 frames: 7 us with 32, 25 with 2).
   const int xblocks = (words + kThreads - 1) / kThreads;
-  int slices = 4096 / (xblocks * nframes);
+  int slices = (histogram ? 1024 : 4096) / (xblocks * nframes);
   if (slices > 32) slices = 32;
+  if (histogram && slices < 2) slices = 2;
+  static const int slices_env = getenv("SJPEG_HIP_REDUCE_SLICES") ? atoi(getenv("SJPEG_HIP_REDUCE_SLICES")) : 0;   // (experiments)
+  if (slices_env > 0) slices = slices_env;
   if (slices < 1 || g.nseg < 64) slices = 1;
   const dim3 grid(xblocks, nframes, slices);
   HIP_TRY(hipMemsetAsync(d_out, 0, static_cast<size_t>(nframes) * words * (histogram ? 4 : 1) * sizeof(uint32_t), st));
