@@ -1059,7 +1059,7 @@ int sjpeg_hip_adapt_sums(const uint32_t* d_hist, int nframes, const uint8_t quan
   a.totlast = d_totlast;
   memcpy(a.quant, quant, sizeof(a.quant));
   if (min_quant != nullptr) memcpy(a.min_quant, min_quant, sizeof(a.min_quant)); else memset(a.min_quant, 1, sizeof(a.min_quant));
-  hipLaunchKernelGGL(adapt_sums_kernel, dim3(64, 2, nframes), dim3(32), 0, static_cast<hipStream_t>(stream), a);
+  hipLaunchKernelGGL(adapt_sums_kernel, dim3(64, 2, nframes), dim3(64), 0, static_cast<hipStream_t>(stream), a);
   HIP_TRY(hipGetLastError());
   return 0;
 }

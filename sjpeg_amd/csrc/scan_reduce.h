@@ -60,15 +60,22 @@ struct AdaptArgs {
   int* totlast;                     // [nframes][2][64][2]: population, highest occupied bin + 1
   uint8_t quant[2][64], min_quant[2][64];
 };
-__global__ __launch_bounds__(32) void adapt_sums_kernel(const AdaptArgs a) {
+__global__ __launch_bounds__(64) void adapt_sums_kernel(const AdaptArgs a) {
+  // one wave per (frame, table, position): the 128 bins go to LDS once (two per lane; population and
+  // highest occupied bin by a wave reduction), then lane d < 25 walks them for its candidate step
+  __shared__ uint32_t bins[128];
   const int pos = blockIdx.x, idx = blockIdx.y, frame = blockIdx.z, delta = threadIdx.x;
   const uint32_t* const h = a.hist + ((static_cast<size_t>(frame) * 2 + idx) * 64 + pos) * 128;
-  int total = 0, last = 0;
-  for (int i = 0; i < 128; ++i) {
-    const uint32_t hi = h[i];
-    total += static_cast<int>(hi);
-    if (hi) last = i + 1;
+  const uint2 mine = reinterpret_cast<const uint2*>(h)[delta];          // bins 2 * lane, 2 * lane + 1
+  bins[2 * delta] = mine.x;
+  bins[2 * delta + 1] = mine.y;
+  int total = static_cast<int>(mine.x + mine.y);
+  int last = mine.y ? 2 * delta + 2 : (mine.x ? 2 * delta + 1 : 0);
+  for (int d = 32; d > 0; d >>= 1) {
+    total += __shfl_xor(total, d, 64);
+    last = max(last, __shfl_xor(last, d, 64));
   }
+  __syncthreads();
   const size_t cell = (static_cast<size_t>(frame) * 2 + idx) * 64 + pos;
   if (delta == 0) { a.totlast[cell * 2] = total; a.totlast[cell * 2 + 1] = last; }
   if (delta >= 25) return;
@@ -79,7 +86,7 @@ __global__ __launch_bounds__(32) void adapt_sums_kernel(const AdaptArgs a) {
   } else {
     const uint32_t idq = static_cast<uint32_t>(((1 << 16) + dq - 1) / dq);
     for (int i = 0; i < last; ++i) {
-      const uint32_t hi = h[i];
+      const uint32_t hi = bins[i];
       const uint32_t v = (static_cast<uint32_t>(i) << 2) + 2;
       const uint32_t qv = (v * idq + (1u << 16 >> 1)) >> 16;
       const uint32_t bits = 32u - __clz(qv);                        // 0 for qv == 0
@@ -91,4 +98,3 @@ __global__ __launch_bounds__(32) void adapt_sums_kernel(const AdaptArgs a) {
   a.sums[(cell * 25 + delta) * 2] = bsum;
   a.sums[(cell * 25 + delta) * 2 + 1] = dsum;
 }
-
