@@ -508,8 +508,8 @@ float sjpeg_hip_engine_last_total_ms(sjpeg_hip_engine* engine);
  * the worst case of the geometry -- not the worst case itself. */
 size_t sjpeg_hip_engine_scratch_bytes(sjpeg_hip_engine* engine);
 
-/* Gives the engine's scratch back to the device (waits for the device's work first; the tables and the
- * header buffer stay).  The next call allocates what it needs again -- for a service that has just coded
+/* Gives the engine's scratch back to the device (waits for the device's work first; tables and header
+ * buffer included).  The next call allocates what it needs again -- for a service that has just coded
  * an unusually large frame or batch and does not want to keep its high-water mark. */
 int sjpeg_hip_engine_trim(sjpeg_hip_engine* engine);
 

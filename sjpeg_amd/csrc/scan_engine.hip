@@ -126,6 +126,11 @@ struct sjpeg_hip_engine {
   // A batch coded in parts (sjpeg_hip_encode_batch_src): the statistics / replay calls of a part address the
   // kept blocks of frames [replay_first, replay_first + nframes) of a buffer for replay_total frames.
   int replay_first = 0, replay_total = 0;
+  // ... and their per-workgroup partial statistics likewise live in a buffer for replay_total frames, summed on
+  // `reduce_stream` (behind an event) instead of the call's stream: the sums of one part run under the device
+  // pass of the next
+  hipStream_t reduce_stream = nullptr;
+  hipEvent_t reduce_ev = nullptr;
   DevBuf<unsigned long long> seg_off, chunk_off, stamps;
   DevBuf<uint32_t> hdr_off;
   bool want_stamps = false;
@@ -465,6 +470,8 @@ int sjpeg_hip_engine_trim(sjpeg_hip_engine* e) {
   e->seg_words2.release(); e->seg_nbits2.release(); e->pool2.release(); e->pool_ctr2.release(); e->seg_xbase2.release();
   e->ubuf.release(); e->chunk_ff.release(); e->partial.release(); e->replay.release();
   e->seg_off.release(); e->chunk_off.release(); e->hdr_off.release(); e->stamps.release();
+  e->tables.release(); e->header.release();        // (per-frame tables of a large batch are scratch like the rest)
+  e->tables_held_at = nullptr; e->header_held_at = nullptr;
   e->replay_w = e->replay_h = e->replay_mode = e->replay_nframes = 0;
   e->stamps_n = 0;
   e->last_nseg = e->last_nframes = 0;
@@ -596,8 +603,12 @@ static int scan_statistics(sjpeg_hip_engine* e, const sjpeg_hip_source* src, int
   int rc = prepare_scan(e, src, width, height, yuv_mode, nframes, tables, st, &g, &a, &cls, per_frame_tables);
   if (rc) return rc;
   const int words = histogram ? kHistoWords : kStatsWords;
-  if ((rc = e->partial.ensure(static_cast<size_t>(nframes) * g.nseg * words))) return rc;
-  a.partial = e->partial.p;
+  const int part_total = e->replay_total > 0 ? e->replay_total : nframes;
+  const int part_first = e->replay_total > 0 ? e->replay_first : 0;
+  if (part_first < 0 || part_first + nframes > part_total) return fail(SJPEG_HIP_EINVAL, "part outside the batch");
+  if ((rc = e->partial.ensure(static_cast<size_t>(part_total) * g.nseg * words))) return rc;
+  uint32_t* const partial = e->partial.p + static_cast<size_t>(part_first) * g.nseg * words;
+  a.partial = partial;
   if (!histogram && (tables->flags & SJPEG_HIP_QUANT_KEEP)) {
     const size_t per_frame = static_cast<size_t>(g.nseg) * kScanThreads * 36;
     const int total = e->replay_total > 0 ? e->replay_total : nframes;
@@ -624,11 +635,17 @@ static int scan_statistics(sjpeg_hip_engine* e, const sjpeg_hip_source* src, int
   if (slices_env > 0) slices = slices_env;
   if (slices < 1 || g.nseg < 64) slices = 1;
   const dim3 grid(xblocks, nframes, slices);
-  HIP_TRY(hipMemsetAsync(d_out, 0, static_cast<size_t>(nframes) * words * (histogram ? 4 : 1) * sizeof(uint32_t), st));
+  hipStream_t rs = st;
+  if (e->reduce_stream != nullptr && e->reduce_ev != nullptr) {   // (a batch coded in parts: see sjpeg_hip_encode_batch_src)
+    rs = e->reduce_stream;
+    HIP_TRY(hipEventRecord(e->reduce_ev, st));
+    HIP_TRY(hipStreamWaitEvent(rs, e->reduce_ev, 0));
+  }
+  HIP_TRY(hipMemsetAsync(d_out, 0, static_cast<size_t>(nframes) * words * (histogram ? 4 : 1) * sizeof(uint32_t), rs));
   if (histogram) {
-    hipLaunchKernelGGL(reduce_partials<true>, grid, dim3(kThreads), 0, st, e->partial.p, g.nseg, words, d_out);
+    hipLaunchKernelGGL(reduce_partials<true>, grid, dim3(kThreads), 0, rs, partial, g.nseg, words, d_out);
   } else {
-    hipLaunchKernelGGL(reduce_partials<false>, grid, dim3(kThreads), 0, st, e->partial.p, g.nseg, words, d_out);
+    hipLaunchKernelGGL(reduce_partials<false>, grid, dim3(kThreads), 0, rs, partial, g.nseg, words, d_out);
   }
   HIP_TRY(hipGetLastError());
   return 0;
@@ -1083,13 +1100,20 @@ struct BatchScratch {                 // per host thread: device scratch of sjpe
     if (d_freq) (void)hipFree(d_freq);
     if (h_pinned) (void)hipHostFree(h_pinned);
     for (auto& e : ev) { if (e) (void)hipEventDestroy(e); e = nullptr; }
+    if (pass_done) (void)hipEventDestroy(pass_done);
+    if (side) { (void)hipStreamSynchronize(side); (void)hipStreamDestroy(side); }
+    pass_done = nullptr; side = nullptr;
     d_hist = d_sums = d_freq = h_pinned = nullptr; hist_cap = sums_cap = freq_cap = pinned_cap = 0;
   }
   hipEvent_t ev[8] = {};                         // behind the read-backs of a part: sums [0..3], counts [4..7]
+  hipStream_t side = nullptr;                    // the sums of a part (and their read-back) under the next part's pass
+  hipEvent_t pass_done = nullptr;
   bool EnsureEvents() {
     for (auto& e : ev) {
       if (e == nullptr && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { e = nullptr; return false; }
     }
+    if (pass_done == nullptr && hipEventCreateWithFlags(&pass_done, hipEventDisableTiming) != hipSuccess) { pass_done = nullptr; return false; }
+    if (side == nullptr && hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess) { side = nullptr; return false; }
     return true;
   }
   bool EnsurePinned(size_t need) {
@@ -1127,7 +1151,7 @@ int sjpeg_hip_encode_batch_src(sjpeg_hip_engine* engine, const sjpeg_hip_source*
   if (method > 6) return fail(SJPEG_HIP_EINVAL, "sjpeg_hip_encode_batch_src: methods 0..6 (trellis goes through the host API)");
   struct PartsGuard {                              // the engine addresses whole calls again when this returns
     sjpeg_hip_engine* e;
-    ~PartsGuard() { e->replay_first = 0; e->replay_total = 0; }
+    ~PartsGuard() { e->replay_first = 0; e->replay_total = 0; e->reduce_stream = nullptr; e->reduce_ev = nullptr; }
   } parts_guard{engine};
   try {
     const bool adaptive = method >= 3, optimize = (method != 0) && (method != 3);
@@ -1180,6 +1204,14 @@ int sjpeg_hip_encode_batch_src(sjpeg_hip_engine* engine, const sjpeg_hip_source*
       }
       return s;
     };
+    // (in parts: the sums of a part and their read-back go to the side stream, behind the pass that made
+    // the partials, so that the next part's pass starts right behind this one's)
+    hipStream_t rs = st;
+    if (nparts > 1) {
+      engine->reduce_stream = sc.side; engine->reduce_ev = sc.pass_done;
+      engine->replay_total = nframes;
+      rs = sc.side;
+    }
     if (adaptive) {
       int64_t* const d_sums = static_cast<int64_t*>(sc.d_sums);
       int32_t* const d_tot = reinterpret_cast<int32_t*>(static_cast<uint8_t*>(sc.d_sums) + n * kSums);
@@ -1187,15 +1219,16 @@ int sjpeg_hip_encode_batch_src(sjpeg_hip_engine* engine, const sjpeg_hip_source*
         const size_t f0 = part_lo[p], nf = part_lo[p + 1] - f0;
         const sjpeg_hip_source ps = part_source(f0);
         uint32_t* const d_hist = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(sc.d_hist) + f0 * kHist);
+        engine->replay_first = static_cast<int>(f0);
         int rc = sjpeg_hip_scan_histogram_src(engine, &ps, width, height, yuv_mode, static_cast<int>(nf), d_hist, stream);
         if (rc == 0) {
           rc = sjpeg_hip_adapt_sums(d_hist, static_cast<int>(nf), reinterpret_cast<const uint8_t(*)[64]>(&quant[0]), min_quant,
-                                    d_sums + f0 * (kSums / sizeof(int64_t)), d_tot + f0 * (kTot / sizeof(int32_t)), stream);
+                                    d_sums + f0 * (kSums / sizeof(int64_t)), d_tot + f0 * (kTot / sizeof(int32_t)), rs);
         }
         if (rc != 0) return rc;
-        HIP_TRY(hipMemcpyAsync(h_sums + f0 * kSums, d_sums + f0 * (kSums / sizeof(int64_t)), nf * kSums, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipMemcpyAsync(h_sums + n * kSums + f0 * kTot, d_tot + f0 * (kTot / sizeof(int32_t)), nf * kTot, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipEventRecord(sc.ev[p], st));
+        HIP_TRY(hipMemcpyAsync(h_sums + f0 * kSums, d_sums + f0 * (kSums / sizeof(int64_t)), nf * kSums, hipMemcpyDeviceToHost, rs));
+        HIP_TRY(hipMemcpyAsync(h_sums + n * kSums + f0 * kTot, d_tot + f0 * (kTot / sizeof(int32_t)), nf * kTot, hipMemcpyDeviceToHost, rs));
+        HIP_TRY(hipEventRecord(sc.ev[p], rs));
       }
     }
     std::vector<sjpeg_hip_huffman_spec> specs(optimize ? n * 4 : 0);
@@ -1221,8 +1254,8 @@ int sjpeg_hip_encode_batch_src(sjpeg_hip_engine* engine, const sjpeg_hip_source*
         uint32_t* const d_freq = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(sc.d_freq) + f0 * kFreq);
         const int rc = sjpeg_hip_scan_symbol_stats_multi(engine, &ps, width, height, yuv_mode, static_cast<int>(nf), &tables[f0], d_freq, stream);
         if (rc != 0) return rc;
-        HIP_TRY(hipMemcpyAsync(h_freq + f0 * kFreq, d_freq, nf * kFreq, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipEventRecord(sc.ev[kMaxParts + p], st));
+        HIP_TRY(hipMemcpyAsync(h_freq + f0 * kFreq, d_freq, nf * kFreq, hipMemcpyDeviceToHost, rs));
+        HIP_TRY(hipEventRecord(sc.ev[kMaxParts + p], rs));
       }
     }
     // (part p's table builder runs while the device counts the symbols of part p + 1 / codes part p - 1)

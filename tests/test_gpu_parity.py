@@ -396,6 +396,24 @@ def test_c5_end_to_end_4k(engine, digests):
         assert len(got) == digests[key]["size"] and hashlib.md5(got).hexdigest() == digests[key]["md5"], key
 
 
+def test_batch_in_parts_equals_per_picture_encodes(engine, oracle):
+    """sjpeg_hip_encode_batch_src codes a batch of 24 frames or more in two parts (host analysis of one under
+    the device pass of the other, partial sums on a side stream, kept blocks addressed by part): every
+    frame must still be the reference's single-picture encode -- odd frame counts, every analysis method."""
+    rng = np.random.RandomState(77)
+    for (w, h, f) in ((160, 96, 27), (97, 61, 24), (320, 200, 33)):
+        imgs = [synth.g_struct(w, h, 3000 + k) if k % 3 else rng.randint(0, 256, (h, w, 3)).astype(np.uint8) for k in range(f)]
+        frames = torch.from_numpy(np.stack(imgs)).cuda()
+        for mode, q, method in ((1, 75.0, 4), (3, 90.0, 1), (4, 50.0, 3), (1, 30.0, 6)):
+            got = sj.encode_device_method(frames, q, mode, method, engine=engine)
+            for k in range(f):
+                assert got[k] == oracle.encode_method(imgs[k], q, mode, method), (w, h, f, k, mode, method)
+    # twice in a row on one engine, then a smaller (single-part) batch: the part state does not leak
+    got = sj.encode_device_method(frames[:5], 75.0, 1, 4, engine=engine)
+    for k in range(5):
+        assert got[k] == oracle.encode_method(imgs[k], 75.0, 1, 4), k
+
+
 def test_flat_pictures_with_one_bit_codes(oracle):
     """Flat pictures coded with optimised tables are streams of one-bit codes: segments of a few dozen
     bits, a last segment that may start no 32-bit word of its own -- then the frame ends inside an
