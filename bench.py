@@ -27,7 +27,9 @@ Rank 0 prints ONE JSON line.
   `source`) x the cycles a wave64 instruction occupies a SIMD, measured live by a
   microbenchmark of the two issue classes (tools/valu_rate.hip has the full table).
 * `other_configs`: the other BASELINE.json configurations on this device (C2 with noise, C3 8K
-  4:4:4 q90, C4 64 x 1080p, one resident 4K frame), each parity-checked against
+  4:4:4 q90, C4 64 x 1080p, one resident 4K frame; 32 4K frames with the reference's default
+  parameters = method 4, and C5's recompress matrices with method 0 and with the default
+  parameters, through sjpeg_hip_encode_batch_src), each parity-checked against
   tests/golden/digests.json.  Rank 0 at N = 1 only.
 * N > 1: a second timed region with the exchange step INSIDE it (`with_gather`): the streams of
   every step are packed on the device (sjpeg_hip_compact_streams) and gathered to rank 0 over
