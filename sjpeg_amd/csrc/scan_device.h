@@ -204,7 +204,8 @@ __device__ __forceinline__ s16x2 pk_const(int lo, int hi) {
 }
 
 // Column transform of TWO adjacent columns at once; operation order of src/fdct.cc:67-144.
-// All intermediates stay inside int16 (|value| <= 8216).
+// All intermediates stay inside int16 (samples -128 .. +128 -- pure blue / red chroma is +128 --: sums of
+// eight <= 1024, << 3 = 8192; differences <= 256 before their shifts).
 __device__ __forceinline__ void fdct_col8_pk(uint32_t& r0, uint32_t& r1, uint32_t& r2, uint32_t& r3,
                                              uint32_t& r4, uint32_t& r5, uint32_t& r6, uint32_t& r7) {
   const s16x2 x0 = as_pk(r0), x1 = as_pk(r1), x2 = as_pk(r2), x3 = as_pk(r3);
@@ -260,10 +261,14 @@ __device__ __forceinline__ void fdct_row8_pk(const uint32_t* row, int* acc) {
   const s16x2 p0 = as_pk(row[0]), q1 = as_pk(row[1]), q2 = as_pk(row[2]), q3 = as_pk(row[3]);
   const s16x2 A01 = p0 + q3, B01 = p0 - q3;       // (a0,a1), (b0,b1)
   const s16x2 A32 = q1 + q2, B32 = q1 - q2;       // (a3,a2), (b3,b2)
-  // even part: (c0, c2) = (a0 + a3, a1 + a2), (c1, c3) = (a0 - a3, a1 - a2); one product pair per output
-  const s16x2 C02 = A01 + A32, C13 = A01 - A32;
-  acc[0] = dot2z(C02, C4, C4);
-  acc[4] = dot2z(C02, C4, -C4);
+  // even part: (c1, c3) = (a0 - a3, a1 - a2), one product pair per output.  The sums c0 = a0 + a3 and
+  // c2 = a1 + a2 are NOT formed in 16 bits: a chroma sample can be +128 (pure blue: Cb = (32768 * 255 +
+  // 32768) >> 16; pure red: Cr), four all-128 columns make the column pass' DC terms 8192 each and their
+  // sum 32768 -- one past int16 (solid red / blue pictures came out wrong up to round 3: found by the fuzz).
+  // Their two outputs are accumulated from (a0, a1) and (a3, a2) in 32 bits instead: one dot product more.
+  const s16x2 C13 = A01 - A32;
+  acc[0] = dot2(A32, C4, C4, dot2z(A01, C4, C4));
+  acc[4] = dot2(A32, C4, -C4, dot2z(A01, C4, -C4));
   acc[2] = dot2z(C13, C2, C6);
   acc[6] = dot2z(C13, C6, -C2);
   acc[1] = dot2(B32, C7, C5, dot2z(B01, C1, C3));

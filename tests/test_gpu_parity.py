@@ -414,6 +414,34 @@ def test_batch_in_parts_equals_per_picture_encodes(engine, oracle):
         assert got[k] == oracle.encode_method(imgs[k], 75.0, 1, 4), k
 
 
+def test_saturated_primaries_chroma_plus_128(engine, oracle):
+    """Pure blue makes Cb = +128 and pure red Cr = +128 (one past the int8 range the other samples stay in):
+    four such columns in a block put the row pass' even sum at 32768, one past int16 -- solid red and blue
+    pictures were wrong in 4:2:0 and 4:4:4 until this was accumulated in 32 bits (found by the fuzz, round 3)."""
+    rng = np.random.RandomState(12)
+    prim = np.array([(0, 0, 255), (255, 0, 0), (255, 0, 255), (0, 255, 0), (255, 255, 255), (0, 0, 0), (0, 255, 255), (255, 255, 0)], np.uint8)
+    pics = []
+    for px in prim[:3]:
+        for (w, h) in ((8, 8), (16, 16), (64, 8), (100, 37)):
+            img = np.zeros((h, w, 3), np.uint8)
+            img[:] = px
+            pics.append(img)
+    for (w, h, cell) in ((257, 1, 1), (640, 1, 1), (96, 64, 8), (160, 120, 16), (333, 77, 4)):   # primaries in cells / columns
+        idx = rng.randint(0, 8, ((h + cell - 1) // cell, (w + cell - 1) // cell))
+        pics.append(np.repeat(np.repeat(prim[idx], cell, 0), cell, 1)[:h, :w].copy())
+    for img in pics:
+        h, w = img.shape[:2]
+        for mode in (1, 3, 4):
+            for q, method in ((75.0, 0), (99.0, 0), (90.0, 4), (100.0, 1), (50.0, 3), (99.0, 7)):
+                assert sj.SjpegEncode(img, q, method, mode) == oracle.encode_method(img, q, mode, method), (w, h, mode, q, method)
+        for fmt in (1, 2):                                   # BGRA / RGBA through the 4-byte P1
+            x = np.zeros((h, w, 4), np.uint8)
+            x[..., :3] = img[..., ::-1] if fmt == 1 else img
+            planes = [x.reshape(h, 4 * w)]
+            got = sj.encode_source_method(fmt, [torch.from_numpy(p).cuda().unsqueeze(0) for p in planes], w, h, 99.0, 3, 4, engine=engine)
+            assert got == oracle.encode_src(fmt, planes, w, h, oracle.quality_matrices(99.0), yuv_mode=3, method=4), (fmt, w, h)
+
+
 def test_flat_pictures_with_one_bit_codes(oracle):
     """Flat pictures coded with optimised tables are streams of one-bit codes: segments of a few dozen
     bits, a last segment that may start no 32-bit word of its own -- then the frame ends inside an

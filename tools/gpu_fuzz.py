@@ -14,8 +14,12 @@ for it in range(N):
     k = rng.rand()
     if k < 0.45:
         img = rng.randint(0, 256, (h, w, 3)).astype(np.uint8)
-    elif k < 0.6:
+    elif k < 0.55:
         img = (rng.randint(0, 2, (h, w, 3)) * 255).astype(np.uint8)
+    elif k < 0.6:                                  # saturated primaries in cells (pure red / blue: chroma +128)
+        cell = int(rng.choice([1, 4, 8, 16]))
+        idx = rng.randint(0, 2, ((h + cell - 1) // cell, (w + cell - 1) // cell, 3))
+        img = (np.repeat(np.repeat(idx, cell, 0), cell, 1)[:h, :w] * 255).astype(np.uint8)
     elif k < 0.8:
         img = synth.g_struct(w, h, int(rng.randint(1 << 30)))
     else:

@@ -32,7 +32,11 @@ def picture(w, h):
         img[(np.arange(h)[:, None] // 3 + np.arange(w)[None, :] // 5) % 2 == 0] = (255, 0, 40)
         img[(np.arange(h)[:, None] // 7 + np.arange(w)[None, :] // 2) % 3 == 0] = (0, 250, 255)
         return img
-    return np.full((h, w, 3), int(rng.randint(256)), np.uint8)
+    if k < 0.93:
+        return np.full((h, w, 3), int(rng.randint(256)), np.uint8)
+    cell = int(rng.choice([1, 8, 16, 64]))           # saturated primaries in cells (pure red / blue: chroma +128)
+    idx = rng.randint(0, 2, ((h + cell - 1) // cell, (w + cell - 1) // cell, 3))
+    return (np.repeat(np.repeat(idx, cell, 0), cell, 1)[:h, :w] * 255).astype(np.uint8)
 
 
 while time.time() < t_end:
