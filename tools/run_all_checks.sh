@@ -7,6 +7,7 @@ run() { echo "== $*"; timeout "${T:-600}" "$@" 2>&1 | grep -v amdgpu.ids | tail 
 N=2 run python -m pytest tests -m gpu -x -q
 N=1 run python tools/gpu_fuzz.py 1 240
 N=3 run python tools/low_entropy_fuzz.py 1 "${LOWENT:-120}"
+N=3 run python tools/extremes_fuzz.py 1 "${LOWENT:-120}"
 N=1 run python tools/gpu_soak.py 1 "${SOAK:-120}"
 N=1 run python tools/thread_soak.py 16 100
 N=2 run python tools/engine_churn.py 100
