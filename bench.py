@@ -12,8 +12,15 @@ finished when the closing fence returns); `ms_per_step_ordered` is the same step
 ordered kernels, and `roofline.kernel_ms` the dominant kernel alone.
 
   python bench.py --gpus 1 --steps 20 --warmup 3
+  python bench.py --gpus N ...          (no WORLD_SIZE in the environment: bench.py starts the N ranks
+                                         itself -- it re-executes under torch.distributed.run on 127.0.0.1)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
+
+Methodology: after W warm-up steps, `--regions` R (default 11) timed regions of
+EXACTLY K steps each, every one bracketed by barrier + device synchronise, the maximum over ranks taken
+per region; `ms_per_step` / `value` are the MEDIAN region, `ms_per_step_min` / `_max` the spread, and
+`clocks` the device's sclk / mclk before the first and after the last region (boxes differ by a few per cent).
 
 Rank 0 prints ONE JSON line.
 * `roofline` prices the dominant kernel (scan_segments) against the HBM read roofline with
@@ -31,10 +38,13 @@ Rank 0 prints ONE JSON line.
   parameters = method 4, and C5's recompress matrices with method 0 and with the default
   parameters, through sjpeg_hip_encode_batch_src), each parity-checked against
   tests/golden/digests.json.  Rank 0 at N = 1 only.
-* N > 1: a second timed region with the exchange step INSIDE it (`with_gather`): the streams of
+* N > 1 (or `--exchange` at N = 1): `value` stays the device-resident figure, gather EXCLUDED.  Beside it
+  `with_gather`: the same steps with the exchange step INSIDE the timed region -- the streams of
   every step are packed on the device (sjpeg_hip_compact_streams) and gathered to rank 0 over
   RCCL by the library's own communicator (sjpeg_hip_gather_rows / _bytes, exact lengths) under the next
-  step's kernels (sjpeg_amd.dist.exchange_loop).
+  step's kernels (sjpeg_amd.dist.exchange_loop) --, and `c4_sharded_gathered`: BASELINE.json config #4 as
+  written (64 x 1080p, frame k on rank k % N, gathered to rank 0, concatenation checked against the MD5 of
+  SURVEY.md section 8c), with its own gather-excluded and gather-included figures.
 * `cpu_baseline` times the real reference (oracle/_ref, SSE2 path, "reference") or, if that .so
   cannot load, the plain-C oracle ("port") on this host's cores on a bounded sample.
 """
@@ -201,10 +211,148 @@ def run_batch_config(sj, torch, eng, frames_np, tile, mode, method, want, qualit
         per_call.append(time.perf_counter() - t0)
     dt = float(np.median(per_call))
     sz = sizes.cpu().numpy()
-    got = bytes(out[0, :int(sz[0])].cpu().numpy())
-    ok = hashlib.md5(got).hexdigest() == want["md5"] and len(got) == want["size"]
+    # every frame (all are copies of one picture; a batch of 24 frames or more is coded in two parts: both are checked)
+    ok = len(frames_np) == 1 and all(int(n) == want["size"] for n in sz)
+    for k in range(F):
+        ok = ok and hashlib.md5(bytes(out[k, :int(sz[k])].cpu().numpy())).hexdigest() == want["md5"]
     return {"frames": F, "width": w, "height": h, "method": method, "mpix_s": round(F * w * h / dt / 1e6, 1),
             "ms_per_step": round(dt * 1e3, 4), "bytes_per_frame": int(sz[0]), "bit_exact": bool(ok)}
+
+
+def device_clocks(index=0):
+    """Current shader / memory clock of device `index` in MHz: the starred line of the amdgpu sysfs
+    tables (pp_dpm_sclk / pp_dpm_mclk), else rocm-smi; None where neither can be read."""
+    import glob
+    out = {}
+    cards = []
+    for d in sorted(glob.glob("/sys/class/drm/card[0-9]*/device")):
+        try:
+            if open(os.path.join(d, "vendor")).read().strip() == "0x1002" and os.path.exists(os.path.join(d, "pp_dpm_sclk")):
+                cards.append(d)
+        except OSError:
+            pass
+    if index < len(cards):
+        for key, name in (("sclk_mhz", "pp_dpm_sclk"), ("mclk_mhz", "pp_dpm_mclk")):
+            try:
+                for line in open(os.path.join(cards[index], name)):
+                    if "*" in line:
+                        out[key] = int(re.search(r"(\d+)\s*[Mm][Hh]z", line).group(1))
+            except (OSError, AttributeError):
+                pass
+    if not out:
+        try:
+            import subprocess
+            txt = subprocess.run(["rocm-smi", "-d", str(index), "--showclocks", "--json"], capture_output=True,
+                                 text=True, timeout=20).stdout
+            card = next(iter(json.loads(txt).values()))
+            for key, pat in (("sclk_mhz", "sclk"), ("mclk_mhz", "mclk")):
+                for k, v in card.items():
+                    if pat in k.lower() and "level" in k.lower():
+                        m = re.search(r"(\d+)\s*[Mm][Hh]z", str(v))
+                        if m:
+                            out[key] = int(m.group(1))
+        except Exception:
+            pass
+    return out or None
+
+
+def launch_ranks(args):
+    """`--gpus N` with N > 1 and no torch.distributed environment: this process becomes the launcher --
+    one rank per GPU under torch.distributed.run on 127.0.0.1 with the same arguments; rank 0 of the
+    started world prints the line.  Refuses more ranks than devices."""
+    import socket
+    if not args.launch_check:
+        import torch
+        have = torch.cuda.device_count()
+        if args.gpus > have:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but this node shows {have} device(s)")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    os.execv(sys.executable, cmd)
+
+
+def launch_check(world, rank):
+    """What the CPU-side test of the launcher runs (tests/test_dist_cpu.py): the started world meets on gloo,
+    no device is touched; rank 0 prints who came."""
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    seen = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(seen, torch.tensor([rank], dtype=torch.int64))
+    dist.barrier()
+    if rank == 0:
+        emit({"launch_check": True, "n_gpus": world, "ranks": [int(t.item()) for t in seen],
+              "local_ranks_env": os.environ.get("LOCAL_RANK")})
+    dist.destroy_process_group()
+
+
+def c4_region(sj, torch, eng, rank, world, steps, regions, digests, fence, max_over_ranks):
+    """BASELINE.json config #4 as it is written: 64 frames G_struct(1920, 1080, 7654321 + k), q75 4:2:0 method 0,
+    frame k coded by rank k % world (64 / world resident frames per rank, one encode call per step), the coded
+    streams gathered to rank 0 (device-side packing + the C-ABI exchange, under the next step's kernels).
+    Two figures, both medians over `regions` regions of `steps` steps: `encode_only` = device-resident, gather
+    EXCLUDED; `with_gather` = the gather inside the timed region.  Rank 0 brings the last step's gathered
+    streams to the host, concatenates them in frame order and compares the MD5 with SURVEY.md section 8c."""
+    from oracle import synth
+    from sjpeg_amd.dist import exchange_loop, shard_frames
+    w, h, total = 1920, 1080, 64
+    ids = shard_frames(total, rank, world)
+    n = len(ids)
+    frames = torch.empty((max(n, 1), h, w, 3), dtype=torch.uint8, device="cuda")
+    for i, k in enumerate(ids):
+        frames[i] = torch.from_numpy(synth.g_struct(w, h, 7654321 + k)).cuda()
+    tables, quant = sj.make_tables(quality=75.0)
+    header = sj.make_header(w, h, sj.YUV_420, quant)
+    stride = ((w * h * 3) // 2 + len(header) + 4095) & ~4095
+    outs = [torch.empty((max(n, 1), stride), dtype=torch.uint8, device="cuda") for _ in range(2)]
+    sizes = [torch.zeros(max(n, 1), dtype=torch.int64, device="cuda") for _ in range(2)]
+
+    def encode(b=0):
+        if n > 0:
+            eng.encode_frames(frames[:n], tables, header, sj.YUV_420, out=outs[b], sizes=sizes[b], out_stride=stride)
+
+    def timed(fn):
+        dts = []
+        for _ in range(regions):
+            fence()
+            t0 = time.perf_counter()
+            fn()
+            fence()
+            dts.append(max_over_ranks(time.perf_counter() - t0))
+        return float(np.median(dts)), dts
+
+    for _ in range(3):
+        encode()
+    enc_dt, _ = timed(lambda: [encode(s & 1) for s in range(steps)])
+    exchange_loop(2, encode, outs, sizes, ids, total, use_streams=True, keep="last")
+    got = []
+    gat_dt, gat_all = timed(lambda: got.append(exchange_loop(steps, encode, outs, sizes, ids, total, use_streams=True, keep="last")))
+    ok, nbytes = None, None
+    if rank == 0:
+        fr = got[-1][-1].frames()
+        cat = hashlib.md5()
+        for f in fr:
+            cat.update(f)
+        want = digests["struct1080p_k0..63_concat|420|q75|m0"]
+        nbytes = sum(len(f) for f in fr)
+        ok = cat.hexdigest() == want["md5"] and nbytes == want["size"]
+    px = w * h * total * steps
+    return {"frames": total, "frames_per_rank": n, "width": w, "height": h,
+            "encode_only": {"mpix_s": round(px / enc_dt / 1e6, 1), "ms_per_step": round(enc_dt / steps * 1e3, 4),
+                            "what": "every rank codes its 64 / N resident frames, nothing leaves the device: gather EXCLUDED"},
+            "with_gather": {"mpix_s": round(px / gat_dt / 1e6, 1), "ms_per_step": round(gat_dt / steps * 1e3, 4),
+                            "ms_per_step_min": round(min(gat_all) / steps * 1e3, 4),
+                            "ms_per_step_max": round(max(gat_all) / steps * 1e3, 4),
+                            "what": "the same steps with packing + the gather of all 64 streams into rank 0's HBM INSIDE the "
+                                    "timed region (the exchange of step s under the kernels of step s + 1)"},
+            "gathered_bytes_per_step": nbytes, "bit_exact": ok,
+            "check": "rank 0: streams of the last step, host-side concatenation in frame order, MD5 db599667..."}
 
 
 def emit(res):
@@ -229,19 +377,38 @@ def main():
     ap.add_argument("--no-other-configs", action="store_true")
     ap.add_argument("--exchange", action="store_true",
                     help="N = 1 only: run the `with_gather` region too (RCCL with a single rank: packing + self-gather)")
+    ap.add_argument("--regions", type=int, default=11,
+                    help="timed regions of --steps steps each; the line carries the median region and the spread")
+    ap.add_argument("--timed-only", action="store_true",
+                    help="stop after the timed regions and the parity check: no per-kernel timing calls, no ordered "
+                         "steps, no other configurations -- the run tools/profile_gpu.sh traces to compare the "
+                         "rocprof mean of the dominant kernel with ms_per_step")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="start the world exactly as a run would, meet on gloo, print who came, touch no device")
     ap.add_argument("--pipelined", type=int, default=1,
                     help="1 (default): the timed steps run in the engine's pipelined mode (the stitch kernels of "
                          "step i on the engine's own stream, under K1 of step i + 1); 0: ordered calls")
     args = ap.parse_args()
+    if args.gpus < 1 or args.steps < 1 or args.regions < 1:
+        raise SystemExit("bench.py: --gpus, --steps and --regions must be positive")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args)                        # does not return
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and rank == 0:
+        print(f"bench.py: started with WORLD_SIZE={world}, --gpus {args.gpus}: the line reports n_gpus = {world}",
+              file=sys.stderr)
+    if args.launch_check:
+        return launch_check(world, rank)
 
     import torch
     import torch.distributed as dist
     import sjpeg_amd as sj                       # raises if the HIP library is not built
     from oracle import synth
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > torch.cuda.device_count():
+        raise SystemExit(f"bench.py: {world} ranks but {torch.cuda.device_count()} device(s): one rank per GPU")
     if rank != 0:
         # only rank 0's stdout carries the JSON line: whatever the other ranks (or the libraries
         # they load: RCCL prints a banner through C stdio at exit) write goes to stderr
@@ -296,43 +463,50 @@ def main():
     for _ in range(args.warmup):
         encode()
     fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        encode()
-    fence()
-    dt = max_over_ranks(time.perf_counter() - t0)
+    clocks = {"start": device_clocks(local)} if rank == 0 else None
+    region_s = []
+    for _ in range(args.regions):                 # every region: EXACTLY --steps steps between two fences
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            encode()
+        fence()
+        region_s.append(max_over_ranks(time.perf_counter() - t0))
+    if rank == 0:
+        clocks["end"] = device_clocks(local)
+    dt = float(np.median(region_s))
     # what the timed steps left behind is what gets checked (fence() waited for the engine's stream too)
     sz = sizes.cpu().numpy()
     coded = [bytes(out[k, :int(sz[k])].cpu().numpy()) for k in range(F)]
 
     scratch_piped = eng.scratch_bytes()
-    if args.pipelined:                            # back to ordered calls for the per-kernel figures
-        eng.set_pipelined(False)
-    # ---- dominant-kernel duration, HIP events on the launch stream -------------------------
-    eng.set_timing(True)
-    scan_ms, total_ms = [], []
-    for _ in range(max(5, min(args.steps, 20))):
-        encode()
-        scan_ms.append(eng.last_scan_ms())
-        total_ms.append(eng.last_total_ms())
-    eng.set_timing(False)
-    fence()
-    t1 = time.perf_counter()
-    for _ in range(5):
-        encode()
-    fence()
-    ordered_ms = (time.perf_counter() - t1) / 5 * 1e3
-    scan_avg = float(np.mean(scan_ms)) * 1e-3
     algo_bytes = 3.0 * W * H * F
-    achieved = algo_bytes / scan_avg
-    traffic, valu_per_wave, waves = pmc_figures()
-    default_workload = (F == 64 and args.input == "struct")
-    if not default_workload:
-        traffic = valu_per_wave = waves = None     # the PMC pass is of the default command
+    scan_ms, total_ms, ordered_ms = [], [], None
+    traffic = valu_per_wave = waves = None
+    stream_gbps, rates = None, None
+    if not args.timed_only:
+        if args.pipelined:                        # back to ordered calls for the per-kernel figures
+            eng.set_pipelined(False)
+        # ---- dominant-kernel duration, HIP events on the launch stream -------------------------
+        eng.set_timing(True)
+        for _ in range(max(5, min(args.steps, 20))):
+            encode()
+            scan_ms.append(eng.last_scan_ms())
+            total_ms.append(eng.last_total_ms())
+        eng.set_timing(False)
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(5):
+            encode()
+        fence()
+        ordered_ms = (time.perf_counter() - t1) / 5 * 1e3
+        if F == 64 and args.input == "struct":    # the PMC pass is of the default command
+            traffic, valu_per_wave, waves = pmc_figures()
+    scan_avg = float(np.mean(scan_ms)) * 1e-3 if scan_ms else None
+    achieved = algo_bytes / scan_avg if scan_avg else None
 
     # ---- what a read-only stream kernel reaches on this device (context for `peak`) ----------
-    stream_gbps, rates = None, None
-    if rank == 0:
+    if rank == 0 and not args.timed_only:
         try:
             import ctypes as C
             L = sj.lib()
@@ -372,17 +546,19 @@ def main():
     res = {}
     if rank == 0:
         mpix = W * H * F * world * args.steps / dt / 1e6
-        roof = {"bound": "hbm", "achieved": round(achieved / 1e9, 1), "peak": HBM_PEAK / 1e9,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK, 4), "traffic": traffic,
-                "traffic_source": PMC_SUMMARY if traffic is not None else None,
-                # the same algorithmic bytes over the whole timed step (K1 with the stitch kernels of the
+        per_step = sorted(r / args.steps * 1e3 for r in region_s)
+        roof = {"bound": "hbm", "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                # the algorithmic bytes over the whole timed step (K1 with the stitch kernels of the
                 # previous step beside it): what the headline `value` corresponds to
                 "frac_in_region": round(algo_bytes / (dt / args.steps) / HBM_PEAK, 4),
-                "kernel": "scan_segments<420>", "kernel_ms": round(scan_avg * 1e3, 4),
-                "all_kernels_ms": round(float(np.mean(total_ms)), 4),
-                "algorithmic_bytes_per_launch": int(algo_bytes),
-                "stream_read_GBps": None if stream_gbps is None else round(stream_gbps, 1),
-                "frac_of_stream_read": None if not stream_gbps else round(achieved / 1e9 / stream_gbps, 4)}
+                "kernel": "scan_segments<420>", "algorithmic_bytes_per_launch": int(algo_bytes)}
+        if scan_avg:
+            roof.update({"achieved": round(achieved / 1e9, 1), "frac": round(achieved / HBM_PEAK, 4), "traffic": traffic,
+                         "traffic_source": PMC_SUMMARY if traffic is not None else None,
+                         "kernel_ms": round(scan_avg * 1e3, 4), "kernel_ms_min": round(float(np.min(scan_ms)), 4),
+                         "all_kernels_ms": round(float(np.mean(total_ms)), 4),
+                         "stream_read_GBps": None if stream_gbps is None else round(stream_gbps, 1),
+                         "frac_of_stream_read": None if not stream_gbps else round(achieved / 1e9 / stream_gbps, 4)})
         if rates is not None:
             valu = {"cycles_per_instr": {"packed_vop3_mul_perm": round(rates[0], 2), "simple_int_f32": round(rates[1], 2)},
                     "cycles_source": "measured in this run (sjpeg_hip_debug_valu_rate, 8 waves per SIMD, nominal 2.4 GHz)"}
@@ -405,14 +581,19 @@ def main():
                                    "q=75 YUV420 method 0 (standard Huffman), one complete JPEG per frame",
                        "frames_per_gpu": F, "width": W, "height": H, "quality": QUALITY,
                        "yuv_mode": "420", "parallelism": f"frame-sharded x{world}, no data-path collective"},
+            # value / ms_per_step = the median of `regions` timed regions of `steps` steps each (max over ranks per region)
+            "regions": args.regions, "ms_per_step_min": round(per_step[0], 4), "ms_per_step_max": round(per_step[-1], 4),
+            "ms_per_step_regions": [round(r / args.steps * 1e3, 4) for r in region_s],
+            "clocks": clocks,
             "bit_exact": bool(parity),
             "bytes_per_frame": int(sz[0]),
             "engine_scratch_bytes": scratch_piped,
             "roofline": roof,
         }
         res["config"]["pipelined"] = bool(args.pipelined)
-        res["ms_per_step_ordered"] = round(ordered_ms, 4)
-        if args.pipelined:                        # what the strictly ordered mode holds (one set of segment buffers)
+        if ordered_ms is not None:
+            res["ms_per_step_ordered"] = round(ordered_ms, 4)
+        if args.pipelined and not args.timed_only:   # what the strictly ordered mode holds (one set of segment buffers)
             e2 = sj.Engine(local)
             e2.encode_frames(frames, tables, header, sj.YUV_420, out=outs[0], sizes=sizes_b[0], out_stride=out_stride)
             torch.cuda.synchronize()
@@ -424,13 +605,14 @@ def main():
     # ---- N > 1: the same steps with the exchange step of config #4 inside a second timed region ----
     # The headline line is complete at this point.  A watchdog prints it anyway if the exchange (RCCL
     # on a node this code has not met before) does not come back: the metric must not be lost with it.
-    if exchange:
+    if exchange and not args.timed_only:
         import threading
         from sjpeg_amd.dist import exchange_loop
 
         def give_up():
             if rank == 0:
-                res["with_gather"] = {"error": "the exchange region did not finish within 240 s"}
+                res.setdefault("with_gather", {"error": "the exchange region did not finish within 240 s"})
+                res.setdefault("c4_sharded_gathered", {"error": "the exchange region did not finish within 240 s"})
                 emit(res)
             os._exit(0)
 
@@ -458,11 +640,19 @@ def main():
                                    "exchange of step s under the kernels of step s + 1; host copy / concatenation not included"}
         except Exception as exc:                 # the exchange is outside the headline metric: report, do not lose the line
             with_gather = {"error": repr(exc)}
-        dog.cancel()
         if rank == 0:
             res["with_gather"] = with_gather
+        try:                                      # config #4 as written: 64 x 1080p, 64 / N per rank, gathered to rank 0
+            c4 = c4_region(sj, torch, eng, rank, world, args.steps, min(args.regions, 5), digests, fence, max_over_ranks)
+        except Exception as exc:
+            c4 = {"error": repr(exc)}
+        dog.cancel()
+        if rank == 0:
+            res["c4_sharded_gathered"] = c4
+            if isinstance(c4, dict) and c4.get("bit_exact") is False:
+                parity = False
     if rank == 0:
-        if world == 1 and not args.no_other_configs:
+        if world == 1 and not args.no_other_configs and not args.timed_only:
             del frames
             torch.cuda.empty_cache()
             oc = {}
@@ -495,7 +685,7 @@ def main():
             res["other_configs"] = oc
             if any(isinstance(v, dict) and v.get("bit_exact") is False for v in oc.values()):
                 parity = False
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and not args.timed_only:
             res["cpu_baseline"] = cpu_baseline(host)
         if not parity:
             res["value"] = 0.0

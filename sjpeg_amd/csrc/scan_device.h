@@ -204,8 +204,17 @@ __device__ __forceinline__ s16x2 pk_const(int lo, int hi) {
 }
 
 // Column transform of TWO adjacent columns at once; operation order of src/fdct.cc:67-144.
-// All intermediates stay inside int16 (samples -128 .. +128 -- pure blue / red chroma is +128 --: sums of
-// eight <= 1024, << 3 = 8192; differences <= 256 before their shifts).
+// RANGES: proven, not argued -- tools/int16_ranges.py writes every statement of this function, of fdct_row8_pk and
+// of row_quant as an affine form of the block's 64 samples and bounds it at the corners of the sample box, for
+// samples -128 .. 127 (luma, planar sources) and -127 .. 128 (chroma from RGB: pure blue / red are +128) -- NOT for
+// their union, which does not fit.  Tightest values (profiles/r04/int16_ranges.txt, tests/test_packed_ranges.py; the
+// GPU tests paint these corners: test_extremal_patterns_of_the_packed_fdct):
+//   int16 lanes   column pass: outputs |r0|, |r4| <= 8192, all others <= 6290; every multiplier operand <= 4926,
+//                 every 24-bit product < 2^28 (u3 / t4: 4926 * 43790 = 2.16e8)
+//                 row pass: a_i, b_i of rows 0 / 4 <= 16384; c1 = a0 - a3, c3 = a1 - a2 of rows 0 / 4 <= 32 640
+//                 (127 below the lane's limit: eight rows x 16 samples x 255); |coefficient| <= 16 385
+//   32-bit sums   dot-product chains <= 2^30 (row 0, acc0)
+//   quantizer     |c| * iquant + bias * iquant <= 1.08e9 for any table the host can make; level <= 1025
 __device__ __forceinline__ void fdct_col8_pk(uint32_t& r0, uint32_t& r1, uint32_t& r2, uint32_t& r3,
                                              uint32_t& r4, uint32_t& r5, uint32_t& r6, uint32_t& r7) {
   const s16x2 x0 = as_pk(r0), x1 = as_pk(r1), x2 = as_pk(r2), x3 = as_pk(r3);
@@ -223,12 +232,12 @@ __device__ __forceinline__ void fdct_col8_pk(uint32_t& r0, uint32_t& r1, uint32_
   r2 = as_u32(pk_mulhi(fd, 27146) + ed);
   r6 = as_u32(pk_mulhi(ed, 27146) - fd);
   // ((x << 4) * 23170) >> 16 == (x * (23170 << 4)) >> 16: the shift rides in the 24-bit multiplier
-  // (|d16 -+ d25| <= 510, the product stays below 2^28)
+  // (|d16 -+ d25| <= 510, the product stays below 2^28: range table above)
   const s16x2 od = pk_mulhi(d16 - d25, 23170 << 4);
   const s16x2 os = pk_mulhi(d16 + d25, 23170 << 4);
   const s16x2 p3 = d34 - od, p1 = d34 + od;
   const s16x2 p0 = d07 - os, p2 = d07 + os;
-  // ((p * K) >> 16) + p == (p * (K + 65536)) >> 16 exactly (|p| < 2^13: the product stays below 2^29)
+  // ((p * K) >> 16) + p == (p * (K + 65536)) >> 16 exactly (|p| <= 4926: the product stays below 2^28; range table above)
   const s16x2 u3 = pk_mulhi(p3, 65536 - 21746);              // t3 - 1
   const s16x2 t4 = pk_mulhi(p0, 65536 - 21746);
   const s16x2 t5 = pk_mulhi(p2, 13036);
@@ -266,6 +275,7 @@ __device__ __forceinline__ void fdct_row8_pk(const uint32_t* row, int* acc) {
   // 32768) >> 16; pure red: Cr), four all-128 columns make the column pass' DC terms 8192 each and their
   // sum 32768 -- one past int16 (solid red / blue pictures came out wrong up to round 3: found by the fuzz).
   // Their two outputs are accumulated from (a0, a1) and (a3, a2) in 32 bits instead: one dot product more.
+  // The DIFFERENCES do fit: |a0 - a3| <= 8 * 16 * 255 = 32 640 for either sample range (tools/int16_ranges.py).
   const s16x2 C13 = A01 - A32;
   acc[0] = dot2(A32, C4, C4, dot2z(A01, C4, C4));
   acc[4] = dot2(A32, C4, -C4, dot2z(A01, C4, -C4));

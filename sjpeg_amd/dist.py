@@ -87,7 +87,7 @@ def _capacity_error(msg):
 
 def gather_streams(out: torch.Tensor, sizes: torch.Tensor, frame_ids: Sequence[int],
                    nframes: int, dst: int = 0, group=None, compact=None,
-                   to_host: bool = True, buffers: Optional[dict] = None):
+                   to_host: bool = True, buffers: Optional[dict] = None, reuse_gathered: bool = True):
     """Gathers variable-length coded frames to `dst`: the exchange step of the batch path.
 
     out [F_local, stride] uint8 and sizes [F_local] int64 as an encode call left them, frame_ids the
@@ -99,7 +99,9 @@ def gather_streams(out: torch.Tensor, sizes: torch.Tensor, frame_ids: Sequence[i
     C-ABI (the library's own RCCL communicator, rccl_comm()); CPU tensors (the gloo tests) through the
     same steps written with torch.distributed, `compact(out, sizes, n, capacity)` -> (packed, offsets)
     standing in for the kernel.  A frame of size 0 raises on every rank before anything is sent; the root
-    sizes its buffer from the actual total.  `buffers`: a dict the call keeps its device buffers in (reuse across steps).
+    sizes its buffer from the actual total.  `buffers`: a dict the call keeps its device buffers in (reuse across
+    steps); with to_host=False the RESULT lives in the "gathered" buffer, so a caller that keeps the results of
+    several calls passes reuse_gathered=False (a fresh buffer per call; only the scratch is reused).
     Returns on `dst` the nframes byte strings in global order (to_host=True) or a GatheredStreams holding
     the device-resident buffer (to_host=False); None elsewhere."""
     world = dist.get_world_size(group)
@@ -131,7 +133,9 @@ def gather_streams(out: torch.Tensor, sizes: torch.Tensor, frame_ids: Sequence[i
         # the root sizes its buffer from the actual total (kept between steps, grown by halves)
         total = int(offs[world])
         gathered = None
-        if rank == dst:
+        if rank == dst and not reuse_gathered:
+            gathered = torch.empty(max(total, 16), dtype=torch.uint8, device=dev)
+        elif rank == dst:
             have = buffers.get("gathered")
             gathered = buf("gathered", max(total, 16) if have is not None and have.numel() >= total else total + total // 2 + 16,
                            torch.uint8)
@@ -158,7 +162,8 @@ def gather_streams(out: torch.Tensor, sizes: torch.Tensor, frame_ids: Sequence[i
         if my_bytes > 0:
             dist.send(packed[:my_bytes].contiguous(), dst=dst, group=group)
         return None
-    gathered = buf("gathered", max(offs[world], 16), torch.uint8)
+    gathered = (buf("gathered", max(offs[world], 16), torch.uint8) if reuse_gathered
+                else torch.empty(max(offs[world], 16), dtype=torch.uint8, device=dev))
     reqs = []
     for r in range(world):
         n = int(rows[r][0])
@@ -226,12 +231,15 @@ def exchange_loop(nsteps: int, encode, outs, sizes, frame_ids: Sequence[int], nf
     """bench.py's timed multi-rank region, as a function so that the CPU/gloo test runs exactly
     this code: `nsteps` encode calls, double buffered (outs[b], sizes[b], b = 0 / 1), the streams
     of every step gathered to `dst` (device resident there) under the next step's kernels.
-    Returns the GatheredStreams of every step on `dst`, a list of None elsewhere."""
+    Returns the GatheredStreams of every step on `dst` (keep="last": of the last step only), a list of None
+    elsewhere.  The exchange's scratch (packed block, offsets, rows) is held per output set and reused; the
+    buffer a result lives in is reused only with keep="last" -- with keep="all" every step gets its own, or the
+    streams of step s would be overwritten by step s + 2."""
     held = [{}, {}]                                 # device buffers of the exchange, one set per output set
     return overlapped_steps(
         nsteps, encode,
         lambda b: gather_streams(outs[b], sizes[b], frame_ids, nframes, dst=dst, group=group,
-                                 compact=compact, to_host=False, buffers=held[b]),
+                                 compact=compact, to_host=False, buffers=held[b], reuse_gathered=(keep == "last")),
         use_streams, keep)
 
 

@@ -115,7 +115,7 @@ def test_gather_ragged_and_empty_rank():
     _run(1)
 
 
-def _loop_worker(rank, world, port, nframes, nsteps, q):
+def _loop_worker(rank, world, port, nframes, nsteps, q, shrink=False):
     """bench.py's multi-rank region (sjpeg_amd.dist.exchange_loop) with a stand-in encoder: step s
     leaves the oracle-coded frames of picture set s in buffer set s & 1."""
     sys.path.insert(0, ROOT)
@@ -128,7 +128,10 @@ def _loop_worker(rank, world, port, nframes, nsteps, q):
     ids = shard_frames(nframes, rank, world)
 
     def coded(step, k):
-        return o.encode(synth.g_struct(40 + 8 * (k % 3), 24, 1000 * step + k), 75.0, 1)
+        # (shrink: every step's streams are shorter than the step before -- a result that shared its buffer with
+        # step s + 2 would read that step's bytes)
+        wide = (40 + 8 * (k % 3)) if not shrink else (88 - 16 * step + 8 * (k % 3))
+        return o.encode(synth.g_struct(wide, 24, 1000 * step + k), 75.0, 1)
 
     stride = 4096
     outs = [torch.zeros((max(len(ids), 1), stride), dtype=torch.uint8) for _ in range(2)]
@@ -169,6 +172,42 @@ def test_bench_exchange_loop_two_ranks():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert ok
+
+
+def test_exchange_loop_keeps_every_step_when_later_steps_are_smaller():
+    """keep="all": the result of step s must survive step s + 2, which reuses the same output set and scratch
+    and gathers FEWER bytes (the gathered buffer was shared)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 35500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_loop_worker, args=(r, 2, port, 5, 4, q, True)) for r in range(2)]
+    for p in procs:
+        p.start()
+    ok = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert ok
+
+
+def test_bench_launcher_starts_the_world_it_was_asked_for():
+    """`python bench.py --gpus 2` without a torch.distributed environment must start two ranks by itself
+    (the flag was parsed and ignored).  --launch-check takes the launcher's exact path -- re-exec
+    under torch.distributed.run on 127.0.0.1 -- and meets on gloo instead of touching a device."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout                                   # ONE line, from rank 0
+    got = json.loads(lines[0])
+    assert got["n_gpus"] == 2 and got["ranks"] == [0, 1]
+    # one rank: no launcher, same line shape
+    r1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--launch-check"],
+                        capture_output=True, text=True, timeout=300, env=env)
+    assert r1.returncode == 0 and json.loads([ln for ln in r1.stdout.splitlines() if ln.startswith("{")][0])["n_gpus"] == 1
 
 
 # ---- one frame over several ranks: exchange of band bit strings (SURVEY.md section 8e) -------------

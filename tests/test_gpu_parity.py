@@ -1267,3 +1267,92 @@ def test_segments_of_every_length_around_the_stitch_window(engine, oracle):
     _sweep_segment_lengths(engine, oracle, 1, 97.0, 1900, 2500, 1500, (9400, 11500, 40000), 7)
     _sweep_segment_lengths(engine, oracle, 1, 100.0, 3800, 4500, 1500, (17800, 22400, 80000), 8)
     _sweep_segment_lengths(engine, oracle, 3, 97.0, 1900, 2500, 1000, (9400, 11500, 40000), 9)
+
+
+# ---- the lanes of the packed fDCT at their proven extremes (tools/int16_ranges.py) --------------
+
+_PAIRS = {"blue|yellow (Cb +128 / -127)": ((0, 0, 255), (255, 255, 0)),
+          "red|cyan (Cr +128 / -127)": ((255, 0, 0), (0, 255, 255)),
+          "white|black (Y +127 / -128)": ((255, 255, 255), (0, 0, 0))}
+
+
+def _extremal_masks():
+    import json
+    pats = json.load(open(os.path.join(ROOT, "tests", "golden", "extremal_patterns.json")))["patterns"]
+    masks = sorted({int(p[k], 16) for p in pats for k in ("max", "min")})
+    assert len(masks) >= 40
+    return masks
+
+
+def _paint(masks, scale, hi, lo, per_row=12):
+    """One tile of 8 x 8 cells (`scale` pixels a side) per mask: cell i = `hi` where bit i is set, else `lo`."""
+    side = 8 * scale
+    rows = (len(masks) + per_row - 1) // per_row
+    img = np.zeros((rows * side, per_row * side, 3), np.uint8)
+    img[:] = np.array(lo, np.uint8)
+    for t, m in enumerate(masks):
+        bits = np.array([(m >> i) & 1 for i in range(64)], bool).reshape(8, 8)
+        cell = np.where(bits[..., None], np.array(hi, np.uint8), np.array(lo, np.uint8)).astype(np.uint8)
+        y0, x0 = (t // per_row) * side, (t % per_row) * side
+        img[y0:y0 + side, x0:x0 + side] = cell.repeat(scale, 0).repeat(scale, 1)
+    return img
+
+
+def _tap_and_bytes(engine, oracle, img, mode, q, what):
+    t, quant = sj.make_tables(quality=q)
+    zz = engine.scan_coeffs(dev(img), t, mode)
+    torch.cuda.synchronize()
+    want = oracle.scan_coeffs(img, quant, 0x78, mode)
+    assert (zz[0].cpu().numpy() == want).all(), ("tap", what, mode, q)
+    got = sj.encode_device(dev(img), q, mode, engine=engine)[0]
+    assert got == oracle.encode(img, q, mode), ("bytes", what, mode, q)
+
+
+def test_extremal_patterns_of_the_packed_fdct(engine, oracle):
+    """The corner patterns at which the int16 lanes / 32-bit accumulators of fdct_col8_pk, fdct_row8_pk and row_quant
+    come closest to their type (c1 = a0 - a3 reaches 32 640 of 32 767), painted with the colour pairs that put Cb, Cr
+    and Y at the ends of their ranges: coefficients (tap) and bytes against the oracle.  4:4:4 and 4:0:0 see the
+    pattern per pixel; 4:2:0 sees it per pixel in luma and -- at two pixels per cell -- exactly in chroma."""
+    masks = _extremal_masks()
+    for name, (hi, lo) in _PAIRS.items():
+        for scale in (1, 2):
+            img = _paint(masks, scale, hi, lo)
+            for mode in (3, 1, 4):
+                for q in (100.0, 75.0):
+                    _tap_and_bytes(engine, oracle, img, mode, q, (name, scale))
+            # the same corners with the two colours exchanged (the minimum of every form)
+            _tap_and_bytes(engine, oracle, _paint(masks, scale, lo, hi), 3, 100.0, (name, scale, "exchanged"))
+            _tap_and_bytes(engine, oracle, _paint(masks, scale, lo, hi), 1, 100.0, (name, scale, "exchanged"))
+
+
+def test_extreme_stripes_through_tap_and_bytes(engine, oracle):
+    """Column and row stripes of period 1 / 2 / 4 / 8 (and 16 for the 4:2:0 chroma blocks) between the colours
+    that put a component at both ends of its range, every phase against the block grid."""
+    for name, (hi, lo) in _PAIRS.items():
+        for period in (1, 2, 4, 8, 16):
+            for phase in range(0, min(period, 8), max(1, period // 4)):
+                x = np.arange(160)
+                on = (((x + phase) // period) & 1).astype(bool)
+                col = np.where(on[None, :, None], np.array(hi, np.uint8), np.array(lo, np.uint8)).astype(np.uint8)
+                for img in (np.broadcast_to(col, (96, 160, 3)).copy(),
+                            np.broadcast_to(col.transpose(1, 0, 2), (160, 96, 3)).copy()):
+                    for mode in (3, 1, 4):
+                        _tap_and_bytes(engine, oracle, img, mode, 100.0 if period < 4 else 90.0, (name, period, phase))
+
+
+def test_tap_on_lattices_of_constant_columns_and_rows(engine, oracle):
+    """Blocks whose columns (rows) are constant, drawn from the corners of the RGB cube: the column pass feeds the
+    row pass one non-zero row (column) of the largest magnitudes -- what g_struct / g_noise never do."""
+    rng = np.random.RandomState(404)
+    corners = np.array([[r, g, b] for r in (0, 255) for g in (0, 255) for b in (0, 255)], np.uint8)
+    for trial in range(6):
+        for cell in (1, 2):
+            w, h = 192, 128
+            cx = corners[rng.randint(0, 8, w // cell)].repeat(cell, 0)[:w]          # one colour per column
+            cy = corners[rng.randint(0, 8, h // cell)].repeat(cell, 0)[:h]          # one colour per row
+            imgs = [np.broadcast_to(cx[None], (h, w, 3)).copy(), np.broadcast_to(cy[:, None], (h, w, 3)).copy()]
+            mix = np.where((rng.randint(0, 2, (h // 8, w // 8)).repeat(8, 0).repeat(8, 1))[..., None] == 1, imgs[0], imgs[1])
+            imgs.append(mix.astype(np.uint8))                                       # column blocks beside row blocks
+            for img in imgs:
+                for mode in (3, 1, 4):
+                    _tap_and_bytes(engine, oracle, img, mode, (100.0, 95.0, 60.0)[trial % 3], (trial, cell))
