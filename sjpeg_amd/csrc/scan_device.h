@@ -9,7 +9,6 @@
 constexpr int kThreads = 256;        // stitch kernels (K2..K5): 4 waves
 constexpr int kScanThreads = 256;    // K1: 4 waves = 41 coded MCUs + 1 halo MCU in 4:2:0
 constexpr int kSlotBytes = 144;      // 64 int16 + 16 B pad: conflict-free ds_read_b128 per lane
-constexpr int kWinWords = 2048;       // LDS bit window, 32-bit MSB-first words (8 KiB)
 constexpr int kMaxBlockBits = 1728;  // 22 (DC) + 63*27 (AC) rounded up; reference bound enc.cc:206-209
 constexpr int kChunkWords = 1024;    // K3/K5 chunk: 4 KiB of un-stuffed stream
 constexpr int kChunkBytes = kChunkWords * 4;
@@ -34,7 +33,9 @@ struct alignas(16) DevTables {
   // bits a block's AC entries (sign-magnitude pairs) must NOT have for the lean walk to be provably
   // in place: levels of n <= n_safe bits, n_safe = largest n with len(0, n') + n' <= 16 for all n' <= n
   uint32_t safe_mask[2];
-  uint32_t pad_a[6];
+  // the AC code words the lean walk needs beside the merged ones: {EOB, ZRL} per table ((code << 16) | length)
+  uint32_t eob_zrl[2][2];
+  uint32_t pad_a[2];
   // group B (3456 B)
   uint32_t ac[2][256];
   // Lean entropy walk, indexed [run & 15][clz(level) - 22] (level 1..1023 <=> clz 31..22):
@@ -79,35 +80,66 @@ struct ScanArgs {
   int ablate;              // profiling knob (env SJPEG_HIP_ABLATE): stop after phase 1/2/3; 0 = full
 };
 
-// LDS carve (bytes), all offsets multiples of 16
-constexpr int kSamplesBytes = kScanThreads * kSlotBytes;        // 36864
-constexpr int kOffWin = kSamplesBytes;
-// The quantizer table (1 KiB) and the DC codes are only read before the bit window is first
-// touched (P2 / DC coding), so they live INSIDE the window region.
-constexpr int kOffQ = kOffWin;                                  // uint4[64]
-constexpr int kOffDc = kOffWin + 1024;                          // uint32[24] + safe masks [2]
-constexpr int kOffTlen = kOffWin + 1152;                        // uint8[2][256], trellis kinds only
-// Entropy-phase bookkeeping inside the (still idle) bit window, as window WORD offsets.  All of it
-// lies behind the tables staged at the front of the window (quantizer 0..1023, DC codes ..1151,
-// trellis lengths ..1663 bytes): the DC codes are still being read by slow waves when fast ones
-// already write the part list -- there is no barrier between the two any more.
-constexpr int kPartLens = 576;                                  // u16 [256][4]: bits per part (bytes 2304..4351)
-constexpr int kSortHist = 1100;                                 // u32 [32]: the sort's bins (bytes 4400..4527)
-constexpr int kPartList = 1168;                                 // u16 [1024]: block | quarter << 8 (bytes 4672..6719)
-constexpr int kDcVals = 1680;                                   // i32 [256]: quantized DC values, for the prediction (bytes 6720..7743)
-static_assert(kPartLens * 4 >= 1664 && kSortHist >= kPartLens + 512 && kPartList >= kSortHist + 32 &&
-              kDcVals >= kPartList + 512 && kDcVals + kScanThreads <= kWinWords,
-              "bookkeeping behind the tables, inside the window");
-constexpr int kOffAc = kOffWin + kWinWords * 4 + 16;            // +1 spare word (16 B keeps alignment)
-constexpr int kOffAcm = kOffAc + 2 * 256 * 4;                   // uint32[2][10][16]: merged code words of the lean walk
-constexpr int kOffZrl = kOffAcm + 2 * 160 * 4;                  // uint4[2][4]: ZRL patterns
-constexpr int kOffMisc = kOffZrl + 128;                         // scan scratch
-constexpr int kLdsBytes = kOffMisc + 64;                        // 48592: three workgroups per CU
-constexpr int kOffStats = kLdsBytes;                            // kKindStats only: u32[2 replicas][2][272]
+// LDS carve of K1 (bytes, all offsets multiples of 16): the block slots, then the region R behind them.
+// Two layouts.  ROOMY (every kind, every mode): 256 slots, an 8 KiB bit window that also takes the tables of
+// P1 / P2 and the bookkeeping of the entropy phase while it is idle, the raw AC table, 48.6 KB: three workgroups
+// per CU.  COMPACT (the plain encode kind of 4:2:0 from packed RGB -- the headline path): 252 slots (42 MCUs of
+// six blocks: the four spare threads have none), R = 4 656 B, 40 944 B in all: FOUR workgroups per CU and, for the
+// compiler, 128 registers.  What makes R that small: the raw AC table stays in global memory (the lean walk needs
+// its EOB / ZRL words only, which ride in the padding of the DC codes; the checked walk -- q >= 97 noise -- reads
+// the rest from global memory), the part lengths go back into the tail word the part was described by, the DC
+// predictors are read from the neighbour's slot, the part list lies over the dead quantizer table, and the bit
+// window (4 448 B: the ordinary segment of 2.7 KB still fits one round) lies over everything the stitch no
+// longer needs.
+template <bool COMPACT> struct Lds;
+template <> struct Lds<false> {
+  static constexpr int kSlots = kScanThreads;
+  static constexpr int kSamplesBytes = kSlots * kSlotBytes;      // 36864
+  static constexpr int kWinWords = 2048;                         // LDS bit window, 32-bit MSB-first words (8 KiB)
+  static constexpr int kOffWin = kSamplesBytes;
+  // The quantizer table (1 KiB) and the DC codes are only read before the bit window is first
+  // touched (P2 / DC coding), so they live INSIDE the window region.
+  static constexpr int kOffQ = kOffWin;                          // uint4[64]
+  static constexpr int kOffDc = kOffWin + 1024;                  // uint32[24] + safe masks [2] + EOB / ZRL words [4]
+  static constexpr int kOffTlen = kOffWin + 1152;                // uint8[2][256], trellis kinds only
+  // Entropy-phase bookkeeping inside the (still idle) bit window.  All of it lies behind the tables staged at
+  // the front of the window (quantizer 0..1023, DC codes ..1151, trellis lengths ..1663 bytes): the DC codes are
+  // still being read by slow waves when fast ones already write the part list -- no barrier between the two.
+  static constexpr int kOffHist = kOffWin + 4400;                // u32 [32]: the sort's bins
+  static constexpr int kOffList = kOffWin + 4672;                // u16 [1024]: block | quarter << 8
+  static constexpr int kOffDcw = kOffWin + 6720;                 // u32 [256]: DC code words (length << 24 | bits)
+  static constexpr int kOffAc = kOffWin + kWinWords * 4 + 16;    // +1 spare word (16 B keeps alignment)
+  static constexpr int kOffAcm = kOffAc + 2 * 256 * 4;           // uint32[2][16][10]: merged code words of the lean walk
+  static constexpr int kOffZrl = kOffAcm + 2 * 160 * 4;          // uint4[2][4]: ZRL patterns
+  static constexpr int kOffMisc = kOffZrl + 128;                 // scan scratch
+  static constexpr int kLdsBytes = kOffMisc + 64;                // 48592: three workgroups per CU
+  static_assert(kOffHist >= kOffTlen + 512 && kOffList >= kOffHist + 128 && kOffDcw >= kOffList + 2048 &&
+                kOffDcw + 4 * kScanThreads <= kOffWin + kWinWords * 4, "bookkeeping behind the tables, inside the window");
+};
+template <> struct Lds<true> {
+  static constexpr int kSlots = 252;
+  static constexpr int kSamplesBytes = kSlots * kSlotBytes;      // 36288
+  static constexpr int kWinWords = 1112;
+  static constexpr int kOffWin = kSamplesBytes;
+  static constexpr int kOffQ = kOffWin;                          // uint4[64] (P1 / P2) ...
+  static constexpr int kOffList = kOffWin;                       // ... u16[984] (written behind the DC barrier: P2 is over)
+  static constexpr int kOffHist = kOffWin + 1968;                // u32 [20]
+  static constexpr int kOffDc = kOffWin + 2048;                  // uint32[24] + safe masks [2] + EOB / ZRL words [4]
+  static constexpr int kOffTlen = -1, kOffAc = -1;               // (no trellis kind, no raw AC table in this layout)
+  static constexpr int kOffAcm = kOffWin + 2176;
+  static constexpr int kOffDcw = kOffWin + 3456;                 // u32 [252]
+  static constexpr int kOffZrl = kOffWin + 4464;                 // (read by the stitch: behind the window, like misc)
+  static constexpr int kOffMisc = kOffZrl + 128;
+  static constexpr int kLdsBytes = kOffMisc + 64;                // 40944
+  static_assert(kOffHist >= kOffList + 2 * 4 * (kSlots - 6) && kOffDc >= kOffHist + 80 && kOffDcw >= kOffAcm + 1280 &&
+                kOffZrl >= kOffDcw + 4 * kSlots && (kWinWords + 1) * 4 <= kOffZrl - kOffWin, "compact carve");
+  static_assert(4 * kLdsBytes <= 160 * 1024, "four workgroups per CU");
+};
+constexpr int kOffStats = Lds<false>::kLdsBytes;                 // kKindStats only: u32[2 replicas][2][272]
 constexpr int kLdsBytesStats = kOffStats + 2 * 2 * 272 * 4;
+constexpr int kSamplesBytes = Lds<false>::kSamplesBytes;
 static_assert(3 * kLdsBytesStats <= 160 * 1024, "three workgroups per CU (statistics kind)");
-static_assert(kWinWords * 4 >= 1152 + 512 && kWinWords >= 64 + 512 + 512, "window region too small");
-static_assert(3 * kLdsBytes <= 160 * 1024, "three workgroups per CU");
+static_assert(3 * Lds<false>::kLdsBytes <= 160 * 1024, "three workgroups per CU");
 
 // ------------------------------------------------------------------------------------
 // small device helpers

@@ -171,6 +171,7 @@ void digest_tables(const sjpeg_hip_scan_tables* t, DevTables* d) {
       if ((j & 1) == 0) { e.x = iq; e.y = biq; e.w = qv; } else { e.x |= iq << 16; e.z = biq; e.w |= qv << 16; }
     }
   }
+  memset(d->pad_a, 0, sizeof(d->pad_a));
   memcpy(d->dc, t->dc_codes, sizeof(d->dc));
   memcpy(d->ac, t->ac_codes, sizeof(d->ac));
   memcpy(d->tlen, t->trellis_len, sizeof(d->tlen));
@@ -196,6 +197,8 @@ void digest_tables(const sjpeg_hip_scan_tables* t, DevTables* d) {
     }
     const uint32_t bad = ~((1u << n_safe) - 1u) & 0x7fffu;
     d->safe_mask[c] = bad | (bad << 16);
+    d->eob_zrl[c][0] = t->ac_codes[c][0x00];
+    d->eob_zrl[c][1] = t->ac_codes[c][0xf0];
     for (int n = 1; n <= 10; ++n) {
       for (int run = 0; run < 16; ++run) {
         const uint32_t cw = t->ac_codes[c][(run << 4) | n];

@@ -31,22 +31,33 @@ __device__ __forceinline__ void race_point(int code, int n) {
 // three, with its registers held to the 128 that leaves room for -- 131 without the bound.  Packed RGB
 // only: ROCm 7.2's clang crashes in its register allocator on the 4-byte-pixel instantiation with the
 // smaller LDS block)
+// the compact LDS layout (scan_device.h): four workgroups per CU
 template <int MODE, int KINDX, int SRC>
-__global__ __launch_bounds__(kScanThreads, (KINDX == kKindHisto && SRC == kSrcRgb24) ? 4 : 1) void scan_segments(const ScanArgs a) {
+constexpr bool kCompactLds = (MODE == SJPEG_HIP_YUV420 && KINDX == kKindEncode && SRC == kSrcRgb24);
+
+template <int MODE, int KINDX, int SRC>
+__global__ __launch_bounds__(kScanThreads, ((KINDX == kKindHisto && SRC == kSrcRgb24) || kCompactLds<MODE, KINDX, SRC>) ? 4 : 1) void scan_segments(const ScanArgs a) {
   constexpr bool TRELLIS = (KINDX == kKindEncodeTrellis || KINDX == kKindStatsTrellis);
   constexpr bool REPLAY = (KINDX == kKindEncodeReplay);
   constexpr int KIND = (KINDX == kKindEncodeTrellis || KINDX == kKindEncodeReplay) ? kKindEncode : (KINDX == kKindStatsTrellis) ? kKindStats : KINDX;
+  constexpr bool COMPACT = kCompactLds<MODE, KINDX, SRC>;
+  using L = Lds<COMPACT>;
+  constexpr int kWinWords = L::kWinWords;
   using G = Geo<MODE>;
   constexpr int BPM = G::kBpm;
   constexpr int PX = G::kMcuPx;
+  static_assert(!COMPACT || (G::kSegMcus + 1) * BPM <= L::kSlots, "a slot for every block of the segment and its halo MCU");
   // static, not `extern __shared__`: the address of a dynamic block is resolved after instruction
   // selection and leaves a `+ 0` in ~65 address computations of this kernel
-  __shared__ __attribute__((aligned(16))) unsigned char smem[(KIND == kKindStats) ? kLdsBytesStats : (KIND == kKindHisto && SRC == kSrcRgb24) ? kSamplesBytes : kLdsBytes];
-  uint32_t* const win = reinterpret_cast<uint32_t*>(smem + kOffWin);
-  uint4* const lq = reinterpret_cast<uint4*>(smem + kOffQ);
-  uint32_t* const lac = reinterpret_cast<uint32_t*>(smem + kOffAc);
-  uint32_t* const ldc = reinterpret_cast<uint32_t*>(smem + kOffDc);
-  uint32_t* const misc = reinterpret_cast<uint32_t*>(smem + kOffMisc);
+  __shared__ __attribute__((aligned(16))) unsigned char smem[(KIND == kKindStats) ? kLdsBytesStats : (KIND == kKindHisto && SRC == kSrcRgb24) ? kSamplesBytes : L::kLdsBytes];
+  uint32_t* const win = reinterpret_cast<uint32_t*>(smem + L::kOffWin);
+  uint4* const lq = reinterpret_cast<uint4*>(smem + L::kOffQ);
+  uint32_t* const ldc = reinterpret_cast<uint32_t*>(smem + L::kOffDc);
+  uint32_t* const misc = reinterpret_cast<uint32_t*>(smem + L::kOffMisc);
+  uint32_t* const dcw = reinterpret_cast<uint32_t*>(smem + L::kOffDcw);      // DC code words, by block
+  // (the four spare threads of the compact layout have no slot: theirs would be the tables)
+  const bool has_slot = !COMPACT || threadIdx.x < L::kSlots;
+  typedef uint16_t __attribute__((may_alias)) u16_may_alias;
 
   const int tid = threadIdx.x;
   const int seg = blockIdx.x, frame = blockIdx.y;
@@ -75,12 +86,22 @@ __global__ __launch_bounds__(kScanThreads, (KINDX == kKindHisto && SRC == kSrcRg
     // two contiguous groups, 16 bytes per thread: quantizer + DC codes + level bounds into the idle
     // window, AC codes + merged code words + ZRL patterns behind it
     const uint4* const t16 = reinterpret_cast<const uint4*>(t);
-    if (tid < kTablesB16) reinterpret_cast<uint4*>(smem + kOffAc)[tid] = t16[kTablesA16 + tid];
-    if (tid < kTablesA16) reinterpret_cast<uint4*>(smem + kOffQ)[tid] = t16[tid];
-    if (TRELLIS && tid < 128) reinterpret_cast<uint32_t*>(smem + kOffTlen)[tid] = reinterpret_cast<const uint32_t*>(&t->tlen[0][0])[tid];
+    if (COMPACT) {
+      // quantizer | DC codes, level bounds, EOB / ZRL words | merged code words | ZRL patterns: four places,
+      // still one 16-byte load per thread and group; the raw AC table is not staged at all
+      constexpr int kAcm16 = kTablesA16 + 128;       // group B: 128 uint4 of raw AC codes in front of the merged ones
+      if (tid < 64) reinterpret_cast<uint4*>(smem + L::kOffQ)[tid] = t16[tid];
+      else if (tid < kTablesA16) reinterpret_cast<uint4*>(smem + L::kOffDc)[tid - 64] = t16[tid];
+      if (tid >= 128 && tid < 128 + 80) reinterpret_cast<uint4*>(smem + L::kOffAcm)[tid - 128] = t16[kAcm16 + tid - 128];
+      else if (tid >= 128 + 80 && tid < 128 + 88) reinterpret_cast<uint4*>(smem + L::kOffZrl)[tid - 208] = t16[kAcm16 + tid - 128];
+    } else {
+      if (tid < kTablesB16) reinterpret_cast<uint4*>(smem + L::kOffAc)[tid] = t16[kTablesA16 + tid];
+      if (tid < kTablesA16) reinterpret_cast<uint4*>(smem + L::kOffQ)[tid] = t16[tid];
+      if (TRELLIS && tid < 128) reinterpret_cast<uint32_t*>(smem + L::kOffTlen)[tid] = reinterpret_cast<const uint32_t*>(&t->tlen[0][0])[tid];
+    }
     // bookkeeping of the entropy phase that nothing touches until then: the sort's bins, the group queue
     if (KIND == kKindEncode || KIND == kKindStats) {
-      if (tid < 32) win[kSortHist + tid] = 0;
+      if (tid < 20) reinterpret_cast<uint32_t*>(smem + L::kOffHist)[tid] = 0;
       if (tid == 32) misc[10] = 0;
     }
     if (KIND == kKindStats) {                      // the symbol counters (their own LDS behind everything else)
@@ -324,7 +345,7 @@ __global__ __launch_bounds__(kScanThreads, (KINDX == kKindHisto && SRC == kSrcRg
 #pragma unroll
       for (int c = 0; c < 4; ++c) sum = dot2(as_pk(p[r][c]), 1, 1, sum);
     }
-    reinterpret_cast<int*>(slot + 128)[3] = sum;
+    if (has_slot) reinterpret_cast<int*>(slot + 128)[3] = sum;
     __syncthreads();
     RACE_POINT(12);
     if (has_block && k >= 1 && k <= 3) {
@@ -488,13 +509,15 @@ __global__ __launch_bounds__(kScanThreads, (KINDX == kKindHisto && SRC == kSrcRg
     }
   }
   // zig-zag reorder with byte permutes, 4 entries per ds_write_b64
+  if (has_slot) {
 #pragma unroll
-  for (int i = 0; i < 64; i += 4) {
-    const uint32_t w0 = __builtin_amdgcn_perm(ent[kZig(i + 1) >> 1], ent[kZig(i) >> 1],
-                                              kPairSel(kZig(i), kZig(i + 1)));
-    const uint32_t w1 = __builtin_amdgcn_perm(ent[kZig(i + 3) >> 1], ent[kZig(i + 2) >> 1],
-                                              kPairSel(kZig(i + 2), kZig(i + 3)));
-    *reinterpret_cast<uint2*>(slot + 2 * i) = make_uint2(w0, w1);
+    for (int i = 0; i < 64; i += 4) {
+      const uint32_t w0 = __builtin_amdgcn_perm(ent[kZig(i + 1) >> 1], ent[kZig(i) >> 1],
+                                                kPairSel(kZig(i), kZig(i + 1)));
+      const uint32_t w1 = __builtin_amdgcn_perm(ent[kZig(i + 3) >> 1], ent[kZig(i + 2) >> 1],
+                                                kPairSel(kZig(i + 2), kZig(i + 3)));
+      *reinterpret_cast<uint2*>(slot + 2 * i) = make_uint2(w0, w1);
+    }
   }
   if (!TRELLIS) {
     const int dc_mag = static_cast<int>(ent[0] & 0x7fffu);
@@ -514,7 +537,7 @@ __global__ __launch_bounds__(kScanThreads, (KINDX == kKindHisto && SRC == kSrcRg
     typedef uint16_t __attribute__((may_alias)) u16_alias2;
     const i16_alias* const raw = reinterpret_cast<const i16_alias*>(slot);
     const uint4* const qt = lq + tbl * 32;
-    const uint8_t* const tl = smem + kOffTlen + tbl * 256;
+    const uint8_t* const tl = smem + L::kOffTlen + tbl * 256;
     {
       const int d = raw[0];
       const uint4 t0 = qt[0];
@@ -601,6 +624,10 @@ __global__ __launch_bounds__(kScanThreads, (KINDX == kKindHisto && SRC == kSrcRg
 #pragma unroll
       for (int r = 0; r < 8; ++r) *reinterpret_cast<uint4*>(slot + 16 * r) = make_uint4(0, 0, 0, 0);
     }
+    {   // position 0 = the quantized DC, sign-magnitude like every entry: the next block's predictor is read from here
+      const int dm = dc_val < 0 ? -dc_val : dc_val;
+      *reinterpret_cast<u16_alias2*>(slot) = static_cast<uint16_t>(static_cast<uint32_t>(dm) | (dc_val < 0 ? 0x8000u : 0u));
+    }
     nzq[0] = static_cast<uint32_t>(nzm) & 0xffffu; nzq[1] = static_cast<uint32_t>(nzm >> 16) & 0xffffu;
     nzq[2] = static_cast<uint32_t>(nzm >> 32) & 0xffffu; nzq[3] = static_cast<uint32_t>(nzm >> 48);
   }
@@ -637,21 +664,17 @@ __global__ __launch_bounds__(kScanThreads, (KINDX == kKindHisto && SRC == kSrcRg
   // bytes of each slot (its tail) take what the block's parts need to know: masks, DC word, and what
   // the masks say about every quarter (below).
   uint32_t* const tail = reinterpret_cast<uint32_t*>(slot + 128);
-  uint32_t* const dcv = win + kDcVals;
-  dcv[tid] = static_cast<uint32_t>(dc_val);
-  // (sort bookkeeping that aliases nothing still in use is cleared under the same barrier)
+  // (a block that is not coded -- the halo MCU, a thread without a block -- makes no part and no length)
+  if (!emits) { nzq[0] = 0; nzq[1] = 0; nzq[2] = 0; nzq[3] = 0; }
   RACE_POINT(2);
   // The counting sort of the parts (below) starts here: the bins were cleared when the tables were
   // staged, and the atomics that rank this block's parts are in flight across the DC barrier.
   uint32_t pc[4] = {0, 0, 0, 0}, rank[4] = {0, 0, 0, 0};
   if (KIND == kKindEncode || KIND == kKindStats) {
-    if (KIND == kKindEncode) {
-      *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(win + kPartLens) + 4 * tid) = make_uint2(0u, 0u);
-    }
 #pragma unroll
     for (int q = 0; q < 4; ++q) pc[q] = static_cast<uint32_t>(__popc(nzq[q]));
     if (emits) {
-      uint32_t* const hist0 = win + kSortHist;
+      uint32_t* const hist0 = reinterpret_cast<uint32_t*>(smem + L::kOffHist);
       rank[0] = atomicAdd(&hist0[pc[0]], 1u);      // quarter 0 always makes a part (DC, EOB)
 #pragma unroll
       for (int q = 1; q < 4; ++q) if (pc[q] != 0u) rank[q] = atomicAdd(&hist0[pc[q]], 1u);
@@ -666,7 +689,10 @@ __global__ __launch_bounds__(kScanThreads, (KINDX == kKindHisto && SRC == kSrcRg
     else prev = tid - BPM;
     const bool prev_in_halo = prev < BPM;
     if (emits && !(prev_in_halo && !halo)) {
-      pred = static_cast<int>(dcv[prev]);
+      // the previous block's quantized DC: entry 0 of its slot (sign-magnitude), untouched until the walks
+      const uint32_t e = *reinterpret_cast<const u16_may_alias*>(smem + prev * kSlotBytes);
+      const int mag = static_cast<int>(e & 0x7fffu);
+      pred = (e & 0x8000u) ? -mag : mag;
     }
   }
   uint32_t dc_word = 0;                            // dc_len << 24 | dc_bits (<= 22); 0 = emits nothing
@@ -678,14 +704,16 @@ __global__ __launch_bounds__(kScanThreads, (KINDX == kKindHisto && SRC == kSrcRg
     const uint32_t code = ldc[tbl * 12 + n];
     dc_word = (((code & 0xffu) + n) << 24) | ((code >> 16) << n) | suffix;
   }
-  // bit 29: the block takes the checked walk; bit 30: chroma tables (read by whoever codes a part of it)
+  // the block takes the checked walk (some AC level has more bits than the lean walk is proven for)
   unsafe = (any_ac & ldc[24 + tbl]) != 0u ? 1u : 0u;
-  dc_word |= (unsafe << 29) | (static_cast<uint32_t>(tbl) << 30);
-  // What a part's walk would otherwise work out of the two masks with its quarter as a run-time
-  // value (a dozen selects): per quarter q one byte = the run in front of its first symbol, ZRLs
-  // included (6 bits; the walk splits it into ZRL count and run), and bit 6 = "this part carries the
-  // EOB" (nothing non-zero above the quarter, and position 63 is zero).  Here q is a constant.
-  uint32_t part_info = 0;
+  // What a part's walk needs to know of its block, one word per quarter q in the slot's tail: the quarter's
+  // non-zero mask (bits 0..15), the run in front of its first symbol, ZRLs included (bits 16..21; the walk splits
+  // it into ZRL count and run), bit 22 = "this part carries the EOB" (nothing non-zero above the quarter, and
+  // position 63 is zero), bit 24 = checked walk, bit 25 = chroma tables.  Here q is a constant; a part's walk
+  // would work the same out of the two 32-bit masks with a dozen selects.  The word is read by the ONE thread
+  // that walks the part, which then stores the part's bit length over it: the lengths need no array of their
+  // own, and a quarter without a part keeps its mask -- zero -- as its length.  The DC code word
+  // (length << 24 | bits) goes to an array by block.
   if (KIND == kKindEncode) {
     const uint32_t p1 = 32u - static_cast<uint32_t>(__clz(nzq[0] | 1u));            // position after the last non-zero below quarter 1 (1 = none)
     const uint32_t p2 = 32u - static_cast<uint32_t>(__clz(nz_lo | 1u));
@@ -696,9 +724,16 @@ __global__ __launch_bounds__(kScanThreads, (KINDX == kKindHisto && SRC == kSrcRg
     const uint32_t r3 = 48u + static_cast<uint32_t>(__builtin_ctz(nzq[3] | 0x10000u)) - p3;
     const uint32_t e0 = ((nz_lo >> 16) | nz_hi) == 0u ? 0x40u : 0u, e1 = nz_hi == 0u ? 0x40u : 0u;
     const uint32_t e2 = nzq[3] == 0u ? 0x40u : 0u, e3 = (nzq[3] >> 15) == 0u ? 0x40u : 0u;
-    part_info = ((r0 & 63u) | e0) | (((r1 & 63u) | e1) << 8) | (((r2 & 63u) | e2) << 16) | (((r3 & 63u) | e3) << 24);
+    const uint32_t fl = (unsafe << 24) | (static_cast<uint32_t>(tbl) << 25);
+    if (has_slot) {
+      *reinterpret_cast<uint4*>(tail) = make_uint4(nzq[0] | (((r0 & 63u) | e0) << 16) | fl, nzq[1] | (((r1 & 63u) | e1) << 16) | fl,
+                                                   nzq[2] | (((r2 & 63u) | e2) << 16) | fl, nzq[3] | (((r3 & 63u) | e3) << 16) | fl);
+      dcw[tid] = dc_word;
+    }
+  } else {
+    // (the statistics kind counts a part's symbols out of the two whole masks)
+    *reinterpret_cast<uint4*>(tail) = make_uint4(nz_lo, nz_hi, dc_word | (static_cast<uint32_t>(tbl) << 30), 0u);
   }
-  *reinterpret_cast<uint4*>(tail) = make_uint4(nz_lo, nz_hi, dc_word, part_info);
 
   // kKindStats: [2][272] counters, 256 AC then 16 DC, in TWO copies picked by lane parity: the lanes of a
   // wave count the same few symbols most of the time and an LDS atomic serialises the lanes that hit one
@@ -728,9 +763,8 @@ __global__ __launch_bounds__(kScanThreads, (KINDX == kKindHisto && SRC == kSrcRg
   // descending) in groups of 64 the waves draw from a queue: walks of at most 16 symbols with
   // similar trip counts per wave.
   // The unit list and the part lengths live in the bit window, idle until the stitch.
-  uint32_t* const hist = win + kSortHist;          // [32], bins 0..16 (cleared with the tables, filled before the DC barrier)
-  uint16_t* const ulist = reinterpret_cast<uint16_t*>(win + kPartList);   // [1024] block | quarter << 8
-  uint16_t* const ulen = reinterpret_cast<uint16_t*>(win + kPartLens);    // [256][4] bits per part
+  uint32_t* const hist = reinterpret_cast<uint32_t*>(smem + L::kOffHist);   // bins 0..16 (cleared with the tables, filled before the DC barrier)
+  uint16_t* const ulist = reinterpret_cast<uint16_t*>(smem + L::kOffList);  // block | quarter << 8
   uint32_t n_units;
   {
     RACE_POINT(4);
@@ -817,21 +851,19 @@ __global__ __launch_bounds__(kScanThreads, (KINDX == kKindHisto && SRC == kSrcRg
   // 8 .. 15 when it gets that far (a part is shorter than 496 bits).  A row is only taken by a part
   // that has already produced 32 bytes, so the rows of a frame never add up to more than its
   // output.  Plain and slow: picks an entry out of the registers by a chain of selects.
-  auto walk_checked = [&](uint32_t unit, uint4 bt, uint32_t& rec_out, uint32_t& row_out) {
+  auto walk_checked = [&](uint32_t unit, uint32_t pw, uint32_t dcword, uint32_t& rec_out, uint32_t& row_out) {
     const uint32_t blk = unit & 255u, q = unit >> 8;
-    const uint32_t b_tbl = (bt.z >> 30) & 1u;
-    const uint32_t* const ac = lac + b_tbl * 256;
+    const uint32_t b_tbl = (pw >> 25) & 1u;
+    // (the compact layout keeps the raw AC table in global memory: this walk is the q >= 97 noise path)
+    const uint32_t* const ac = COMPACT ? &(a.tables + frame * a.tables_stride)->ac[b_tbl][0]
+                                       : reinterpret_cast<const uint32_t*>(smem + (COMPACT ? 0 : L::kOffAc)) + b_tbl * 256;
     const uint32_t wp0 = blk * kSlotBytes + 32u * q;
     const uint4 e0 = *reinterpret_cast<const uint4*>(smem + wp0), e1 = *reinterpret_cast<const uint4*>(smem + wp0 + 16);
     const uint32_t ent[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
-    const uint32_t lo = bt.x, hi = bt.y;
-    const uint32_t mw = (q & 2u) ? hi : lo;
-    uint32_t m = (q & 1u) ? (mw >> 16) : (mw & 0xffffu);
-    const uint32_t below_lo = q >= 2u ? lo : (q == 1u ? (lo & 0xffffu) : 0u);
-    const uint32_t below_hi = q == 3u ? (hi & 0xffffu) : 0u;
-    const uint32_t prev0 = below_hi ? 64u - __clz(below_hi) : 32u - __clz(below_lo | 1u);
-    const uint32_t above = q == 0u ? ((lo >> 16) | hi) : (q == 1u ? hi : (q == 2u ? (hi >> 16) : 0u));
-    int prevl = static_cast<int>(prev0) - static_cast<int>(16u * q);
+    uint32_t m = pw & 0xffffu;                     // the part's own 16 positions
+    // local position after the previous non-zero, from the run in front of the first symbol (ZRLs included:
+    // this walk codes them itself); the EOB flag says whether anything follows the part
+    int prevl = __builtin_ctz(m | 0x10000u) - static_cast<int>((pw >> 16) & 63u);
     uint32_t acc = 0, fill = 0, wr = 0, row = kNoRow;
     bool lost = false;                             // the pool is full: the frame reports size 0 anyway
     auto put_word = [&](uint32_t word) {
@@ -850,7 +882,7 @@ __global__ __launch_bounds__(kScanThreads, (KINDX == kKindHisto && SRC == kSrcRg
       if (t >= 32u) { put_word(acc | (bits >> s5)); acc = P; } else { acc |= P; }
       fill = s5;
     };
-    if (q == 0u) append(bt.z & 0xffffffu, (bt.z >> 24) & 31u);
+    if (q == 0u) append(dcword & 0xffffffu, (dcword >> 24) & 31u);
     const uint32_t zrl = ac[0xf0];
     while (m) {
       const int i = __builtin_ctz(m);
@@ -868,10 +900,10 @@ __global__ __launch_bounds__(kScanThreads, (KINDX == kKindHisto && SRC == kSrcRg
       const uint32_t cw = ac[(static_cast<uint32_t>(run) << 4) | n];
       append(((cw >> 16) << n) | suffix, (cw & 0xffu) + n);
     }
-    if (above == 0u && prevl + static_cast<int>(16u * q) <= 63) { const uint32_t eob = ac[0x00]; append(eob >> 16, eob & 0xffu); }
+    if ((pw >> 22) & 1u) { const uint32_t eob = ac[0x00]; append(eob >> 16, eob & 0xffu); }
     const uint32_t len = 32u * wr + fill;
     if (fill != 0u) put_word(acc);                 // the last word, left-aligned, goes where the others are
-    ulen[4 * blk + q] = static_cast<uint16_t>(len);
+    *reinterpret_cast<u32_alias*>(smem + blk * kSlotBytes + 128u + 4u * q) = len;   // the part's length, over its description
     // (spill field: 8 = words 8.. are in the pool row, 31 = all in place)
     rec_out = unit | ((wr > 8u ? 8u : 31u) << 10) | (len << 17) | (b_tbl << 28);
     row_out = row;
@@ -891,31 +923,30 @@ __global__ __launch_bounds__(kScanThreads, (KINDX == kKindHisto && SRC == kSrcRg
   // stored (the quarter has room for exactly 8); the last, partial word stays in a register.
   // Code words come from the merged table (code << n | total length << 27), indexed by clz(level)
   // and run, so a symbol costs two LDS reads and about thirty simple instructions.
-  const uint32_t acm_base = static_cast<uint32_t>(kOffAcm) - 22u * 4u;    // word [run][clz - 22]: 40 bytes per run
+  const uint32_t acm_base = static_cast<uint32_t>(L::kOffAcm) - 22u * 4u;    // word [run][clz - 22]: 40 bytes per run
   typedef uint16_t __attribute__((may_alias)) u16_alias2;
-  auto walk_lean = [&](uint32_t unit, uint4 bt, uint32_t& rec_out, uint32_t& tail_out) {
+  auto walk_lean = [&](uint32_t unit, uint32_t pw, uint32_t dcword, uint32_t& rec_out, uint32_t& tail_out) {
     const uint32_t blk = unit & 255u, q = unit >> 8;
     const uint32_t slot_off = blk * kSlotBytes;
-    const uint32_t b_tbl = (bt.z >> 30) & 1u;
-    const uint32_t* const ac = lac + b_tbl * 256;
+    const uint32_t b_tbl = (pw >> 25) & 1u;
     const uint32_t tb = acm_base + b_tbl * 640u;
-    const uint32_t mw = (q & 2u) ? bt.y : bt.x;
-    uint32_t m = (q & 1u) ? (mw >> 16) : (mw & 0xffffu);           // the part's own 16 positions
-    // the block's thread has read the masks for this quarter already (part_info, P3 start)
-    const uint32_t inf = (bt.w >> (8u * q)) & 0x7fu;
+    uint32_t m = pw & 0xffffu;                     // the part's own 16 positions
+    // the block's thread has read the masks for this quarter already (P3 start)
+    const uint32_t inf = (pw >> 16) & 0x7fu;
     uint32_t acc = 0, fill = 0;                    // bits of the word in the making, left-aligned; their number
     const uint32_t wp0 = slot_off + 32u * q;       // the quarter: 16 entries, then up to 8 words
     uint32_t wp = wp0;                             // byte offset of the next word
     if (q == 0u) {
-      fill = (bt.z >> 24) & 31u;
-      acc = __builtin_amdgcn_alignbit(bt.z & 0xffffffu, 0u, fill);   // DC bits << (32 - fill)
+      fill = (dcword >> 24) & 31u;
+      acc = __builtin_amdgcn_alignbit(dcword & 0xffffffu, 0u, fill);   // DC bits << (32 - fill)
     }
     // positions are local to the quarter from here on; the ZRLs of the first run are taken out of it
     // (only the first symbol of a part can have a run of 16 or more, and never in quarter 0)
     const uint32_t nzrl = (inf >> 4) & 3u;
     int prevl = __builtin_ctz(m | 0x10000u) - static_cast<int>(inf & 15u);   // local position after the previous non-zero; may be negative
     // (the two code words the end of the part may need: fetched here, under the symbols' round trips)
-    const uint32_t eob = ac[0x00], zrl = ac[0xf0];
+    const uint2 ez = *reinterpret_cast<const uint2*>(ldc + 26 + 2 * b_tbl);
+    const uint32_t eob = ez.x, zrl = ez.y;
     auto append = [&](uint32_t bits, uint32_t nb) {                  // 1 <= nb <= 27
       const uint32_t t = fill + nb;
       const uint32_t s5 = t & 31u;
@@ -974,7 +1005,7 @@ __global__ __launch_bounds__(kScanThreads, (KINDX == kKindHisto && SRC == kSrcRg
     if (inf & 0x40u) append(eob >> 16, eob & 0xffu);
     const uint32_t len = ((wp - wp0) << 3) + fill;
     const uint32_t zl = zrl & 0xffu;
-    ulen[4 * blk + q] = static_cast<uint16_t>(len + nzrl * zl);
+    *reinterpret_cast<u32_alias*>(smem + slot_off + 128u + 4u * q) = len + nzrl * zl;   // the part's length, over its description
     rec_out = unit | (31u << 10) | (nzrl << 15) | (len << 17) | (1u << 27) | (b_tbl << 28);
     tail_out = acc;
   };
@@ -991,7 +1022,7 @@ __global__ __launch_bounds__(kScanThreads, (KINDX == kKindHisto && SRC == kSrcRg
   // the waves in boustrophedon order instead (0 1 2 3 / 7 6 5 4 / ...), which is static: a thread
   // knows its (up to) four parts at once and fetches their list entries and block tails together,
   // instead of one dependent chain of LDS round trips in front of every walk.
-  uint32_t un[4]; uint4 bts[4];
+  uint32_t un[4], pws[4], dws[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const uint32_t grp = static_cast<uint32_t>(4 * r) + ((r & 1) ? 3u - (tid >> 6) : (tid >> 6));
@@ -1000,17 +1031,20 @@ __global__ __launch_bounds__(kScanThreads, (KINDX == kKindHisto && SRC == kSrcRg
   }
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    bts[r] = *reinterpret_cast<const uint4*>(smem + (un[r] & 255u) * kSlotBytes + 128);
+    // (no part: some word inside the kernel's LDS is read and not used)
+    const uint32_t blk = un[r] & 255u, q = (un[r] >> 8) & 3u;
+    pws[r] = *reinterpret_cast<const u32_alias*>(smem + blk * kSlotBytes + 128u + 4u * q);
+    dws[r] = dcw[blk];
   }
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     RACE_POINT(6);
     if (un[r] != 0xffffffffu) {
       uint32_t rec, tw = 0;
-      if ((bts[r].z >> 29) & 1u) {
-        walk_checked(un[r], bts[r], rec, tw);      // (tw: the part's pool row)
+      if ((pws[r] >> 24) & 1u) {
+        walk_checked(un[r], pws[r], dws[r], rec, tw);      // (tw: the part's pool row)
       } else {
-        walk_lean(un[r], bts[r], rec, tw);
+        walk_lean(un[r], pws[r], dws[r], rec, tw);
       }
       if (r == 0) { ur0 = rec; tw0 = tw; } else if (r == 1) { ur1 = rec; tw1 = tw; }
       else if (r == 2) { ur2 = rec; tw2 = tw; } else { ur3 = rec; tw3 = tw; }
@@ -1023,11 +1057,13 @@ __global__ __launch_bounds__(kScanThreads, (KINDX == kKindHisto && SRC == kSrcRg
   // (masks and DC word: consumed) becomes the bit offsets of its four parts
   uint32_t total;
   {
-    const uint2 L = *reinterpret_cast<const uint2*>(ulen + 4 * tid);
-    const uint32_t l0 = L.x & 0xffffu, l1 = L.x >> 16, l2 = L.y & 0xffffu, l3 = L.y >> 16;
+    // the lengths the walks left in the tail (a quarter without a part still holds its mask: zero)
+    uint4 Lw = make_uint4(0, 0, 0, 0);
+    if (has_slot) Lw = *reinterpret_cast<const uint4*>(tail);
+    const uint32_t l0 = Lw.x & 0xffffu, l1 = Lw.y & 0xffffu, l2 = Lw.z & 0xffffu, l3 = Lw.w & 0xffffu;
     // (the scratch words are not used again: the barrier after the window is cleared, below, closes the scan)
     const uint32_t s0 = wg_exclusive_scan<kScanThreads, false>(l0 + l1 + l2 + l3, misc, &total);
-    *reinterpret_cast<uint4*>(tail) = make_uint4(s0, s0 + l0, s0 + l0 + l1, s0 + l0 + l1 + l2);
+    if (has_slot) *reinterpret_cast<uint4*>(tail) = make_uint4(s0, s0 + l0, s0 + l0 + l1, s0 + l0 + l1 + l2);
   }
   // Restart mode (optional, never the reference's bytes): the interval ends on a byte boundary,
   // padded with 1-bits, and 16 zero bits hold the place of its RSTn marker -- zero bytes pass the
@@ -1075,7 +1111,7 @@ __global__ __launch_bounds__(kScanThreads, (KINDX == kKindHisto && SRC == kSrcRg
     const uint32_t nzrl = (rec >> 15) & 3u;
     if (nzrl) {
       // the ZRL codes in front of the part's first symbol (lean walk): up to 3 x 16 bits
-      const uint4 zp = reinterpret_cast<const uint4*>(smem + kOffZrl)[((rec >> 28) & 1u) * 4u + nzrl];
+      const uint4 zp = reinterpret_cast<const uint4*>(smem + L::kOffZrl)[((rec >> 28) & 1u) * 4u + nzrl];
       const uint32_t o = pos & 31u;
       uint32_t* const dst = win + (pos >> 5);
       atomicOr(dst, zp.x >> o);
@@ -1088,7 +1124,7 @@ __global__ __launch_bounds__(kScanThreads, (KINDX == kKindHisto && SRC == kSrcRg
       // lean walk: len >> 5 full words in the part's quarter, the rest (left-aligned) in tailw
       uint32_t src = blk * kSlotBytes + 32u * q;
       const uint32_t src_end = src + ((len >> 5) << 2);
-      uint32_t dst = static_cast<uint32_t>(kOffWin) + ((pos >> 5) << 2);
+      uint32_t dst = static_cast<uint32_t>(L::kOffWin) + ((pos >> 5) << 2);
       uint32_t before = 0;                         // source word j - 1
       while (src != src_end) {
         const uint32_t v = *reinterpret_cast<const u32_alias*>(smem + src);
