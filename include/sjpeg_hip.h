@@ -409,7 +409,7 @@ size_t sjpeg_hip_make_header_meta(int width, int height, int yuv_mode, const uin
                                   const sjpeg_hip_huffman_spec* specs,
                                   const sjpeg_hip_metadata* meta, uint8_t* buf, size_t cap);
 
-/* Restart mode (SJPEG_HIP_RESTART_MARKERS): MCUs per restart interval for a colour mode (41 / 84 / 255),
+/* Restart mode (SJPEG_HIP_RESTART_MARKERS): MCUs per restart interval for a colour mode (41 / 82 / 246),
  * and the DRI segment (FF DD 00 04 Ri) inserted in front of the SOS segment of a header made by any of
  * the builders above (in place; returns the new size, 0 if cap < size + 6 or no SOS is found). */
 int sjpeg_hip_restart_interval(int yuv_mode);

@@ -263,7 +263,7 @@ EXPORTED_C_SYMBOLS = [
 
 
 def restart_interval(yuv_mode: int) -> int:
-    """MCUs per restart interval of the optional restart mode (41 / 84 / 255)."""
+    """MCUs per restart interval of the optional restart mode = per K1 segment (41 / 82 / 246)."""
     return int(lib().sjpeg_hip_restart_interval(int(yuv_mode)))
 
 

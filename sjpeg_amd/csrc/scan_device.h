@@ -7,7 +7,7 @@
 // geometry
 
 constexpr int kThreads = 256;        // stitch kernels (K2..K5): 4 waves
-constexpr int kScanThreads = 256;    // K1: 4 waves = 41 coded MCUs + 1 halo MCU in 4:2:0
+constexpr int kScanThreads = 256;    // K1: 4 waves; 252 of them own a block (41 coded MCUs + 1 halo MCU in 4:2:0)
 constexpr int kSlotBytes = 144;      // 64 int16 + 16 B pad: conflict-free ds_read_b128 per lane
 constexpr int kMaxBlockBits = 1728;  // 22 (DC) + 63*27 (AC) rounded up; reference bound enc.cc:206-209
 constexpr int kChunkWords = 1024;    // K3/K5 chunk: 4 KiB of un-stuffed stream
@@ -18,10 +18,10 @@ template <> struct Geo<SJPEG_HIP_YUV420> {
   static constexpr int kBpm = 6, kMcuPx = 16, kSegMcus = 41;    // (41 + 1 halo) * 6 = 252 threads
 };
 template <> struct Geo<SJPEG_HIP_YUV444> {
-  static constexpr int kBpm = 3, kMcuPx = 8, kSegMcus = 84;     // 85 * 3 = 255
+  static constexpr int kBpm = 3, kMcuPx = 8, kSegMcus = 82;     // 83 * 3 = 249; 246 coded blocks like 4:2:0 (the part list's size)
 };
 template <> struct Geo<SJPEG_HIP_YUV400> {
-  static constexpr int kBpm = 1, kMcuPx = 8, kSegMcus = 255;    // 256
+  static constexpr int kBpm = 1, kMcuPx = 8, kSegMcus = 246;    // 247; 246 coded blocks
 };
 
 // device copy of sjpeg_hip_scan_tables, pre-digested
@@ -107,6 +107,7 @@ template <> struct Lds<false> {
   // still being read by slow waves when fast ones already write the part list -- no barrier between the two.
   static constexpr int kOffHist = kOffWin + 4400;                // u32 [32]: the sort's bins
   static constexpr int kOffList = kOffWin + 4672;                // u16 [1024]: block | quarter << 8
+  static constexpr int kListBytes = 2048;
   static constexpr int kOffDcw = kOffWin + 6720;                 // u32 [256]: DC code words (length << 24 | bits)
   static constexpr int kOffAc = kOffWin + kWinWords * 4 + 16;    // +1 spare word (16 B keeps alignment)
   static constexpr int kOffAcm = kOffAc + 2 * 256 * 4;           // uint32[2][16][10]: merged code words of the lean walk
@@ -123,6 +124,7 @@ template <> struct Lds<true> {
   static constexpr int kOffWin = kSamplesBytes;
   static constexpr int kOffQ = kOffWin;                          // uint4[64] (P1 / P2) ...
   static constexpr int kOffList = kOffWin;                       // ... u16[984] (written behind the DC barrier: P2 is over)
+  static constexpr int kListBytes = 1968;
   static constexpr int kOffHist = kOffWin + 1968;                // u32 [20]
   static constexpr int kOffDc = kOffWin + 2048;                  // uint32[24] + safe masks [2] + EOB / ZRL words [4]
   static constexpr int kOffTlen = -1, kOffAc = -1;               // (no trellis kind, no raw AC table in this layout)
@@ -131,7 +133,7 @@ template <> struct Lds<true> {
   static constexpr int kOffZrl = kOffWin + 4464;                 // (read by the stitch: behind the window, like misc)
   static constexpr int kOffMisc = kOffZrl + 128;
   static constexpr int kLdsBytes = kOffMisc + 64;                // 40944
-  static_assert(kOffHist >= kOffList + 2 * 4 * (kSlots - 6) && kOffDc >= kOffHist + 80 && kOffDcw >= kOffAcm + 1280 &&
+  static_assert(kOffHist >= kOffList + kListBytes && kOffDc >= kOffHist + 80 && kOffDcw >= kOffAcm + 1280 &&
                 kOffZrl >= kOffDcw + 4 * kSlots && (kWinWords + 1) * 4 <= kOffZrl - kOffWin, "compact carve");
   static_assert(4 * kLdsBytes <= 160 * 1024, "four workgroups per CU");
 };

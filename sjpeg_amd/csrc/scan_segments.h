@@ -33,7 +33,7 @@ __device__ __forceinline__ void race_point(int code, int n) {
 // smaller LDS block)
 // the compact LDS layout (scan_device.h): four workgroups per CU
 template <int MODE, int KINDX, int SRC>
-constexpr bool kCompactLds = (MODE == SJPEG_HIP_YUV420 && KINDX == kKindEncode && SRC == kSrcRgb24);
+constexpr bool kCompactLds = (KINDX == kKindEncode || KINDX == kKindEncodeReplay);
 
 template <int MODE, int KINDX, int SRC>
 __global__ __launch_bounds__(kScanThreads, ((KINDX == kKindHisto && SRC == kSrcRgb24) || kCompactLds<MODE, KINDX, SRC>) ? 4 : 1) void scan_segments(const ScanArgs a) {
@@ -47,6 +47,8 @@ __global__ __launch_bounds__(kScanThreads, ((KINDX == kKindHisto && SRC == kSrcR
   constexpr int BPM = G::kBpm;
   constexpr int PX = G::kMcuPx;
   static_assert(!COMPACT || (G::kSegMcus + 1) * BPM <= L::kSlots, "a slot for every block of the segment and its halo MCU");
+  // (round 4: 83 MCUs of 4:4:4 made 996 parts at q 92 and the list ran into the sort's bins)
+  static_assert(2 * 4 * G::kSegMcus * BPM <= L::kListBytes, "the part list holds four parts of every coded block");
   // static, not `extern __shared__`: the address of a dynamic block is resolved after instruction
   // selection and leaves a `+ 0` in ~65 address computations of this kernel
   __shared__ __attribute__((aligned(16))) unsigned char smem[(KIND == kKindStats) ? kLdsBytesStats : (KIND == kKindHisto && SRC == kSrcRgb24) ? kSamplesBytes : L::kLdsBytes];
@@ -319,8 +321,10 @@ __global__ __launch_bounds__(kScanThreads, ((KINDX == kKindHisto && SRC == kSrcR
   uint4* const keep = (a.replay == nullptr) ? nullptr
       : reinterpret_cast<uint4*>(a.replay) + ((static_cast<size_t>(frame) * a.nseg + seg) * kScanThreads + tid) * 9;
   if (REPLAY) {
+    if (has_slot) {
 #pragma unroll
-    for (int r = 0; r < 8; ++r) *reinterpret_cast<uint4*>(slot + 16 * r) = keep[r];
+      for (int r = 0; r < 8; ++r) *reinterpret_cast<uint4*>(slot + 16 * r) = keep[r];
+    }
     const uint4 t = keep[8];
     nzq[0] = t.x & 0xffffu; nzq[1] = t.x >> 16; nzq[2] = t.y & 0xffffu; nzq[3] = t.y >> 16;
     dc_val = static_cast<int>(t.z);

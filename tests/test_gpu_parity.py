@@ -1191,11 +1191,14 @@ def test_trim_gives_scratch_back_and_the_next_call_allocates_again(engine, oracl
     assert sj.SjpegEncode(img, 80.0, 0, 1) == want
 
 
-_SEG_ROW = {1: (656, 16), 3: (672, 8), 4: (2040, 8)}      # one K1 segment (41 / 84 / 255 MCUs) per MCU row
+def _seg_row(mode):
+    """(width, MCU height) of a picture whose MCU rows are exactly one K1 segment each (41 / 82 / 246 MCUs)"""
+    px = 16 if mode == 1 else 8
+    return sj.restart_interval(mode) * px, px
 
 
 def _noise_rows(mode, amps, seed):
-    w, mh = _SEG_ROW[mode]
+    w, mh = _seg_row(mode)
     rng = np.random.RandomState(seed)
     amp = np.asarray(amps, np.float64).repeat(mh)[:, None, None]
     return np.clip(128 + rng.randint(-128, 128, (mh * len(amps), w, 3)) * amp / 128.0, 0, 255).astype(np.uint8)
@@ -1356,3 +1359,18 @@ def test_tap_on_lattices_of_constant_columns_and_rows(engine, oracle):
             for img in imgs:
                 for mode in (3, 1, 4):
                     _tap_and_bytes(engine, oracle, img, mode, (100.0, 95.0, 60.0)[trial % 3], (trial, cell))
+
+
+def test_every_block_makes_four_parts(engine, oracle):
+    """Noise at high quality: every quarter of every block holds a non-zero level, so a segment makes the largest
+    number of parts K1's sorted part list can be asked to hold (4 x 246 coded blocks, every mode).  Round 4: with
+    83 MCUs per 4:4:4 segment the list ran 24 bytes into the bins of the counting sort while other waves were still
+    reading them -- wrong in 1 run of 2 at 1080p, never in the small pictures."""
+    rng = np.random.RandomState(77)
+    img = rng.randint(0, 256, (1080, 1920, 3)).astype(np.uint8)
+    for mode in (3, 4, 1):
+        want = oracle.encode(img, 92.0, mode)
+        d = dev(img)
+        for rep in range(8):
+            got = sj.encode_device(d, 92.0, mode, engine=engine)[0]
+            assert got == want, (mode, rep)
