@@ -982,7 +982,9 @@ __global__ __launch_bounds__(kScanThreads, ((KINDX == kKindHisto && SRC == kSrcR
       uint32_t sgn;                                // bit 15 over the whole word (asm: the builtin is turned into compare + select)
       asm("v_bfe_i32 %0, %1, 15, 1" : "=v"(sgn) : "v"(e));
       lv = mag ^ (ones & sgn);
-      cw_at = (tb + nl * 4u) + run * 40u;
+      uint32_t row;                                // tb + 40 run in one operation (the compiler makes it mul + shift + add3)
+      asm("v_mad_u32_u24 %0, %1, 40, %2" : "=v"(row) : "v"(run), "v"(tb));
+      cw_at = row + nl * 4u;
     };
     if (m) {
       int i = __builtin_ctz(m);

@@ -3,7 +3,7 @@
 # Builds nothing itself except the stress configuration, and ALWAYS leaves the plain (shipped) build behind.
 set -u
 cd "$(dirname "$0")/.."
-run() { echo "== $*"; timeout "${T:-600}" "$@" 2>&1 | grep -v amdgpu.ids | tail -${N:-3}; }
+run() { echo "== $*"; timeout "${T:-600}" "$@" 2>&1 | grep -v "amdgpu.ids\|^RCCL version\|^HIP version\|^ROCm version\|^Hostname\|^Librccl path" | tail -${N:-3}; }
 N=2 run python -m pytest tests -m gpu -x -q
 N=1 run python tools/gpu_fuzz.py 1 240
 N=3 run python tools/low_entropy_fuzz.py 1 "${LOWENT:-120}"
