@@ -1084,7 +1084,7 @@ __global__ __launch_bounds__(kScanThreads, ((KINDX == kKindHisto && SRC == kSrcR
   // for the stitch under the same barrier that publishes the offsets
   if (a.ablate != 3) {
     for (int i = tid; i < kWinWords / 4; i += kScanThreads) reinterpret_cast<uint4*>(win)[i] = make_uint4(0, 0, 0, 0);
-    if (tid == 0) { win[kWinWords] = 0; misc[8] = total; }
+    if (tid == 0) win[kWinWords] = 0;              // (the spare word behind the window: a part's last store may land there)
   }
   if (a.ablate == 3) { if (tid == 0) a.seg_nbits[static_cast<size_t>(frame) * a.nseg + seg] = total; return; }
   __syncthreads();
@@ -1110,23 +1110,28 @@ __global__ __launch_bounds__(kScanThreads, ((KINDX == kKindHisto && SRC == kSrcR
       a.seg_xbase[static_cast<size_t>(frame) * a.nseg + seg] = xb;
     }
   }
-  uint32_t base = 0;                               // bit position of window word 0, multiple of 32
-  uint32_t carry = 0;
-  auto place = [&](uint32_t rec, uint32_t pos, uint32_t tailw) {   // pos: bit position in the window
+  // `pos`: the part's bit position in the segment; `base_w`: the segment word the window starts at.  CLIP (a
+  // segment longer than the window, coded window by window): only the words that fall inside the window are
+  // placed -- a part that straddles a window's end is placed twice, each time with the words of that window.
+  auto place = [&](auto clip_tag, uint32_t rec, uint32_t pos, uint32_t tailw, uint32_t base_w) {
+    constexpr bool CLIP = decltype(clip_tag)::value;
     const uint32_t blk = rec & 255u, q = (rec >> 8) & 3u, len = (rec >> 17) & 1023u;
     const uint32_t nzrl = (rec >> 15) & 3u;
+    // window word d (may be "negative" = huge when the word lies in front of the window)
+    auto put = [&](uint32_t d, uint32_t v) {
+      if (!CLIP || d < static_cast<uint32_t>(kWinWords)) atomicOr(win + d, v);
+    };
     if (nzrl) {
       // the ZRL codes in front of the part's first symbol (lean walk): up to 3 x 16 bits
       const uint4 zp = reinterpret_cast<const uint4*>(smem + L::kOffZrl)[((rec >> 28) & 1u) * 4u + nzrl];
-      const uint32_t o = pos & 31u;
-      uint32_t* const dst = win + (pos >> 5);
-      atomicOr(dst, zp.x >> o);
-      atomicOr(dst + 1, __builtin_amdgcn_alignbit(zp.x, zp.y, o));
-      if (o + zp.z > 64u) atomicOr(dst + 2, zp.y << (32u - o));
+      const uint32_t o = pos & 31u, d = (pos >> 5) - base_w;
+      put(d, zp.x >> o);
+      put(d + 1u, __builtin_amdgcn_alignbit(zp.x, zp.y, o));
+      if (o + zp.z > 64u) put(d + 2u, zp.y << (32u - o));
       pos += zp.z;
     }
     const uint32_t o = pos & 31u;
-    if ((rec >> 27) & 1u) {
+    if (!CLIP && ((rec >> 27) & 1u)) {
       // lean walk: len >> 5 full words in the part's quarter, the rest (left-aligned) in tailw
       uint32_t src = blk * kSlotBytes + 32u * q;
       const uint32_t src_end = src + ((len >> 5) << 2);
@@ -1142,82 +1147,82 @@ __global__ __launch_bounds__(kScanThreads, ((KINDX == kKindHisto && SRC == kSrcR
       if (o + (len & 31u) > 32u) atomicOr(reinterpret_cast<uint32_t*>(smem + dst + 4u), tailw << (32u - o));
       return;
     }
-    // checked walk: all words in memory, the first eight in the part's quarter, the rest in its pool row
+    // all words from memory: lean walk -- the full words in the part's quarter, the last (left-aligned) one in
+    // tailw; checked walk -- the first eight in the part's quarter, the rest in its pool row
     const u32_alias* const bw = reinterpret_cast<const u32_alias*>(smem + blk * kSlotBytes) + 8 * q;
+    const bool lean = ((rec >> 27) & 1u) != 0u;
     const bool rowed = ((rec >> 10) & 31u) == 8u;
     const uint32_t nw = (len + 31u) >> 5;          // words of the part, the last one left-aligned
-    uint32_t* const dst = win + (pos >> 5);
+    const uint32_t d0 = (pos >> 5) - base_w;
     uint32_t before = 0;
     for (uint32_t j = 0; j <= nw; ++j) {
       uint32_t v = 0;
-      if (j < nw) v = (j < 8u) ? bw[j] : ((rowed && tailw != kNoRow) ? pool[tailw + j - 8u] : 0u);
-      if (j < nw || o != 0u) atomicOr(dst + j, __builtin_amdgcn_alignbit(before, v, o));
+      if (j < nw) {
+        if (lean) v = (j < (len >> 5)) ? bw[j] : tailw;
+        else v = (j < 8u) ? bw[j] : ((rowed && tailw != kNoRow) ? pool[tailw + j - 8u] : 0u);
+      }
+      if (j < nw || o != 0u) put(d0 + j, __builtin_amdgcn_alignbit(before, v, o));
       before = v;
     }
   };
-  // bits of a part in the stream, ZRL codes in front included (the window test wants an upper bound: 16 each)
+  // bits of a part in the stream, ZRL codes in front included (an upper bound: 16 each)
   auto part_bits = [&](uint32_t rec) { return ((rec >> 17) & 1023u) + 16u * ((rec >> 15) & 3u); };
-  uint32_t pending = 0;                            // bit r: part of round r still has to be placed
-#pragma unroll
-  for (int r = 0; r < 4; ++r) if (ur_get(r) != 0xffffffffu) pending |= 1u << r;
-  // (the loops over the four rounds are NOT unrolled: four inlined copies of place() had the compiler
-  // hoist ~250 instructions of address arithmetic in front of them, most of it for the rare spill path)
-  for (bool first_window = true;; first_window = false) {
-    // the usual case -- the rest of the segment fits the window -- needs no vote
-    const bool all_fit = total <= base + kWinWords * 32u;            // uniform
-    if (!first_window) {                           // (the first window was cleared above)
-      for (int i = tid; i < kWinWords / 4; i += kScanThreads) reinterpret_cast<uint4*>(win)[i] = make_uint4(0, 0, 0, 0);
-      if (tid == 0) win[kWinWords] = 0;
-      if (!all_fit && tid == 0) misc[8] = total;
-      __syncthreads();
+  const uint32_t nw_seg = (total + 31u) >> 5;
+  auto flush = [&](uint32_t base_w, uint32_t nwords) {
+    const uint32_t xbase = misc[9];                // (written before the barriers in front of every flush)
+    for (uint32_t i = tid; i < nwords; i += kScanThreads) {
+      const uint32_t j = base_w + i;
+      if (j < a.slot_words) out_words[j] = win[i];
+      else if (xbase != kNoRow) pool[xbase + (j - a.slot_words)] = win[i];
     }
-    if (tid == 0 && carry != 0) atomicOr(&win[0], carry);
-    uint32_t limit = total;
-    if (!all_fit) {
+  };
+  if (nw_seg <= static_cast<uint32_t>(kWinWords)) {
+    // the usual case: the segment fits the window (cleared above)
 #pragma unroll 1
-      for (int r = 0; r < 4; ++r) {
-        if (pending & (1u << r)) {
-          const uint32_t rec = ur_get(r), st = part_start(rec);
-          if (st + part_bits(rec) > base + kWinWords * 32u) atomicMin(&misc[8], st);
-        }
-      }
-      __syncthreads();
-      // everything that starts before the first non-fitting part (stream order) is placed now
-      limit = misc[8];
+    for (int r = 0; r < 4; ++r) {                  // (NOT unrolled: four inlined copies of place() had the compiler
+      const uint32_t rec = ur_get(r);              // hoist ~250 instructions of address arithmetic in front of them)
+      if (rec != 0xffffffffu) place(std::false_type(), rec, part_start(rec), tw_get(r), 0u);
     }
-#pragma unroll 1
-    for (int r = 0; r < 4; ++r) {
-      if (pending & (1u << r)) {
-        const uint32_t rec = ur_get(r), st = part_start(rec);
-        if (all_fit || (st + part_bits(rec) <= base + kWinWords * 32u && st < limit)) {
-          place(rec, st - base, tw_get(r));
-          pending &= ~(1u << r);
-        }
-      }
-    }
-    if (a.rst && tid == 0 && limit == total && (data_bits & 7u) != 0u) {
-      // the last window: 1-bits from the end of the data to the byte boundary (same word)
-      const uint32_t p = data_bits - base, pad = 8u - (data_bits & 7u);
-      atomicOr(&win[p >> 5], ((1u << pad) - 1u) << (32u - (p & 31u) - pad));
+    if (a.rst && tid == 0 && (data_bits & 7u) != 0u) {
+      // 1-bits from the end of the data to the byte boundary (same word)
+      const uint32_t pad = 8u - (data_bits & 7u);
+      atomicOr(&win[data_bits >> 5], ((1u << pad) - 1u) << (32u - (data_bits & 31u) - pad));
     }
     __syncthreads();
     stamp(6);
     RACE_POINT(10);
-    const uint32_t filled = limit - base;          // bits valid in the window
-    const bool last = (limit == total);
-    const uint32_t nfull = last ? (filled + 31) >> 5 : filled >> 5;
-    {
-      const uint32_t xb = misc[9];                 // (written before the barriers above)
-      for (uint32_t i = tid; i < nfull; i += kScanThreads) {
-        const uint32_t j = (base >> 5) + i;
-        if (j < a.slot_words) out_words[j] = win[i];
-        else if (xb != kNoRow) pool[xb + (j - a.slot_words)] = win[i];
+    flush(0u, nw_seg);
+  } else {
+    // A segment longer than the window is coded window by window: every part places the words of it that fall
+    // into the window at hand (at most two windows see a part of less than 1100 bits), the window is flushed,
+    // cleared, and stands for the next kWinWords words of the segment.  No vote on what fits, no carried word:
+    // two barriers a window.
+    for (uint32_t base_w = 0; base_w < nw_seg; base_w += static_cast<uint32_t>(kWinWords)) {
+      if (base_w != 0u) {
+        for (int i = tid; i < kWinWords / 4; i += kScanThreads) reinterpret_cast<uint4*>(win)[i] = make_uint4(0, 0, 0, 0);
+        __syncthreads();
       }
+      const uint32_t lo = base_w << 5, hi = (base_w + static_cast<uint32_t>(kWinWords)) << 5;   // the window's bits
+#pragma unroll 1
+      for (int r = 0; r < 4; ++r) {
+        const uint32_t rec = ur_get(r);
+        if (rec != 0xffffffffu) {
+          const uint32_t st = part_start(rec);
+          // (a part's last store may go one word past its bits: + 32)
+          if (st < hi && st + part_bits(rec) + 32u > lo) place(std::true_type(), rec, st, tw_get(r), base_w);
+        }
+      }
+      if (a.rst && tid == 0 && (data_bits & 7u) != 0u && data_bits >= lo && data_bits < hi) {
+        const uint32_t pad = 8u - (data_bits & 7u);
+        atomicOr(&win[(data_bits >> 5) - base_w], ((1u << pad) - 1u) << (32u - (data_bits & 31u) - pad));
+      }
+      __syncthreads();
+      RACE_POINT(10);
+      const uint32_t left = nw_seg - base_w;
+      flush(base_w, left < static_cast<uint32_t>(kWinWords) ? left : static_cast<uint32_t>(kWinWords));
+      __syncthreads();                             // (the next window is cleared behind this)
     }
-    if (last) break;
-    carry = win[filled >> 5];                      // partial word carried into the next window
-    base += filled & ~31u;
-    __syncthreads();
+    stamp(6);
   }
   RACE_POINT(11);
   if (tid == 0) a.seg_nbits[static_cast<size_t>(frame) * a.nseg + seg] = total;
