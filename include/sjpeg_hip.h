@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SJPEG_HIP_ABI_VERSION 15
+#define SJPEG_HIP_ABI_VERSION 16
 
 enum {
   SJPEG_HIP_OK = 0,
@@ -280,6 +280,19 @@ int sjpeg_hip_encode_scan_src(sjpeg_hip_engine* engine, const sjpeg_hip_source* 
                               const sjpeg_hip_scan_tables* tables,
                               const void* header, size_t header_size, int append_eoi,
                               void* d_out, size_t out_stride, uint64_t* d_sizes, void* stream);
+/* The same call with PACKED output: frame f is written at d_out + d_offsets[f], the frames back to back, every
+ * one at a multiple of 16 with zero padding behind it; d_offsets[nframes] = the bytes the batch takes.
+ * out_stride (a multiple of 16, as d_out) stays what ONE frame may take -- a frame that needs more reports
+ * size 0 and takes no room --, so d_out needs nframes * out_stride bytes at most.  This is what
+ * sjpeg_hip_compact_streams() makes of a strided batch, without the extra pass over the bytes: the block
+ * d_out[0 .. d_offsets[nframes]) is ready for sjpeg_hip_gather_rows / _bytes (multi-device batch path).
+ * Reference: none (src/enc.cc:391-448 codes one picture into one sink); config #4 of BASELINE.json. */
+int sjpeg_hip_encode_scan_packed_src(sjpeg_hip_engine* engine, const sjpeg_hip_source* src,
+                                     int width, int height, int yuv_mode, int nframes,
+                                     const sjpeg_hip_scan_tables* tables,
+                                     const void* header, size_t header_size, int append_eoi,
+                                     void* d_out, size_t out_stride, uint64_t* d_sizes,
+                                     uint64_t* d_offsets, void* stream);
 int sjpeg_hip_scan_coeffs_src(sjpeg_hip_engine* engine, const sjpeg_hip_source* src,
                               int width, int height, int yuv_mode, int nframes,
                               const sjpeg_hip_scan_tables* tables, int16_t* d_coeffs, void* stream);
@@ -431,10 +444,13 @@ int sjpeg_hip_encode_intervals_src(sjpeg_hip_engine* engine, const sjpeg_hip_sou
  * thread and has no counterpart): packs the `nframes` coded streams an encode call left at
  * d_out + f*out_stride / d_sizes[f] back to back into d_packed, so that ONE collective (RCCL gather over
  * xGMI) or one copy moves them.  Frame f starts at d_offsets[f], a multiple of 16 (the up to 15 bytes
- * of padding behind a frame are zero); d_offsets[nframes] is the number of bytes the batch needs.
- * A frame that would end behind packed_capacity is not copied: compare d_offsets[nframes] with the
- * capacity.  One launch on `stream`, no host synchronisation.  d_out, d_packed and out_stride must be
- * multiples of 16. */
+ * of padding behind a frame are zero); d_offsets[nframes] & ~SJPEG_HIP_PACKED_OVERFLOW is the number of
+ * bytes the batch needs, and bit 63 (SJPEG_HIP_PACKED_OVERFLOW) is set when that is more than
+ * packed_capacity -- a frame that would end behind the capacity is not copied.  The exchange below reads the
+ * flag in the rank's row: every rank then returns SJPEG_HIP_ECAPACITY before anything is sent.  One launch on
+ * `stream`, no host synchronisation.  d_out, d_packed and out_stride must be multiples of 16.
+ * (sjpeg_hip_encode_scan_packed_src() writes this layout directly and needs no second pass.) */
+#define SJPEG_HIP_PACKED_OVERFLOW (1ull << 63)
 int sjpeg_hip_compact_streams(const void* d_out, size_t out_stride, const uint64_t* d_sizes, int nframes,
                               void* d_packed, size_t packed_capacity, uint64_t* d_offsets /* nframes + 1 */,
                               void* stream);
@@ -464,9 +480,10 @@ int sjpeg_hip_compact_streams(const void* d_out, size_t out_stride, const uint64
  * h_rows (host, [world][frames_per_rank_max + 2]) and h_rank_offsets (host, [world + 1]) are filled on
  * every rank; frame k of rank r is at h_rank_offsets[r] + the sum of the 16-aligned sizes of the rank's
  * earlier frames.  Every rank sees the same rows and therefore takes the same decision: a frame of size
- * 0 among the frames of some rank (it did not fit its slot), a rank whose packed total is not the sum of
- * its frames (its d_packed was too small: size it for d_offsets[nframes], e.g. nframes x out_stride), or
- * a total above gathered_capacity, makes the call return SJPEG_HIP_ECAPACITY on EVERY rank before anything is sent (never a hang).
+ * 0 among the frames of some rank (it did not fit its slot), a rank whose d_offsets[nframes] carries
+ * SJPEG_HIP_PACKED_OVERFLOW (its d_packed was too small: size it for nframes x out_stride) or is not the sum
+ * of its frames, or a total above gathered_capacity, makes the call return SJPEG_HIP_ECAPACITY on EVERY rank
+ * before anything is sent (never a hang).
  * d_gathered is only used on the root.  Everything is enqueued on `stream`; the host read waits for that
  * stream, the byte transfers do not.  Returns 0 or SJPEG_HIP_E*. */
 typedef struct sjpeg_hip_comm sjpeg_hip_comm;
@@ -479,9 +496,12 @@ int sjpeg_hip_comm_rank(const sjpeg_hip_comm* comm);
 int sjpeg_hip_comm_world(const sjpeg_hip_comm* comm);
 /* The two halves of sjpeg_hip_gather_streams() for a root that sizes its buffer from the ACTUAL total:
  * steps 1-2 (every rank; h_rank_offsets[world] = bytes the root will receive; SJPEG_HIP_ECAPACITY on every
- * rank for a frame of size 0), then step 3 (every rank; gathered_capacity is checked on the root only, and a
- * root that passes less than the total it was just told is the one error here that leaves the peers' sends
- * unmatched -- size the buffer first). */
+ * rank for a frame of size 0 or an overflowed d_packed), then step 3 (every rank).  Step 3 checks the ROOT's own
+ * arguments on the root only (d_gathered NULL, gathered_capacity below the total it was just told, d_packed NULL):
+ * the peers have queued their sends by then, so such an error leaves them unmatched and the communicator must
+ * be destroyed -- size the buffer from h_rank_offsets[world] first (sjpeg_hip_gather_streams(), which knows the
+ * capacity on every rank, refuses before anybody sends).  A root whose d_packed IS d_gathered +
+ * h_rank_offsets[root] (it coded straight into place with sjpeg_hip_encode_scan_packed_src) copies nothing. */
 int sjpeg_hip_gather_rows(sjpeg_hip_comm* comm, const uint64_t* d_offsets, const uint64_t* d_sizes, int nframes_local,
                           int frames_per_rank_max, uint64_t* d_rows, uint64_t* h_rows, uint64_t* h_rank_offsets,
                           void* stream);

@@ -258,7 +258,7 @@ EXPORTED_C_SYMBOLS = [
     "sjpeg_hip_restart_interval", "sjpeg_hip_header_add_restart", "sjpeg_hip_encode_intervals_src",
     "sjpeg_hip_comm_unique_id", "sjpeg_hip_comm_create", "sjpeg_hip_comm_adopt", "sjpeg_hip_comm_destroy",
     "sjpeg_hip_comm_rank", "sjpeg_hip_comm_world", "sjpeg_hip_gather_rows", "sjpeg_hip_gather_bytes",
-    "sjpeg_hip_gather_streams",
+    "sjpeg_hip_gather_streams", "sjpeg_hip_encode_scan_packed_src",
 ]
 
 
@@ -630,6 +630,28 @@ class Engine:
         if rc != 0:
             raise SjpegError(f"sjpeg_hip_encode_scan: {lib().sjpeg_hip_last_error().decode()}")
         return out, sizes
+
+    def encode_frames_packed(self, frames, tables: ScanTables, header: bytes, yuv_mode: int,
+                             out, sizes, offsets, out_stride, append_eoi=True):
+        """sjpeg_hip_encode_scan_packed_src: like encode_frames(), but frame k is written at out + offsets[k], the
+        frames back to back at multiples of 16 (what compact_streams() makes of a strided batch, without the extra
+        pass).  out: flat uint8 CUDA tensor of at least F * out_stride bytes (16-byte aligned; it may be longer --
+        the root of an exchange codes straight into the buffer the other ranks' streams are gathered behind),
+        sizes [F] int64, offsets [F + 1] int64, out_stride a multiple of 16 = what one frame may take."""
+        self._check_frames(frames)
+        f, h, w, _ = frames.shape
+        assert out.is_cuda and out.dtype.itemsize == 1 and out.numel() >= f * out_stride and offsets.numel() >= f + 1
+        src, _ = make_source(SRC_RGB, [frames.view(f, h, w * 3)])
+        L = lib()
+        L.sjpeg_hip_encode_scan_packed_src.argtypes = [
+            C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_char_p, C.c_size_t, C.c_int,
+            C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
+        rc = L.sjpeg_hip_encode_scan_packed_src(self._h, C.byref(src), w, h, yuv_mode, f, C.byref(tables), header,
+                                                len(header), int(append_eoi), out.data_ptr(), int(out_stride),
+                                                sizes.data_ptr(), offsets.data_ptr(), self._stream())
+        if rc != 0:
+            raise SjpegError(f"sjpeg_hip_encode_scan_packed_src: {lib().sjpeg_hip_last_error().decode()}")
+        return out, sizes, offsets
 
     # ---- any pixel source (sjpeg_hip_source) -------------------------------------------------
     def _chk(self, rc, what):

@@ -207,7 +207,8 @@ int sjpeg_hip_gather_rows(sjpeg_hip_comm* c, const uint64_t* d_offsets, const ui
     total += rk[0];
     // a size of 0 among a rank's frames = a frame that did not fit its slot; a packed total that is not
     // the sum of its (16-aligned) frames = the packed buffer was too small for them
-    if (rk[1] > static_cast<uint64_t>(per_max)) { lost = true; continue; }
+    // (bit 63 of a rank's byte count: sjpeg_hip_compact_streams could not fit the frames into its d_packed)
+    if ((rk[0] >> 63) != 0 || rk[1] > static_cast<uint64_t>(per_max)) { lost = true; continue; }
     uint64_t sum16 = 0;
     for (uint64_t f = 0; f < rk[1]; ++f) {
       if (rk[2 + f] == 0) lost = true;
@@ -217,8 +218,10 @@ int sjpeg_hip_gather_rows(sjpeg_hip_comm* c, const uint64_t* d_offsets, const ui
   }
   h_rank_offsets[c->world] = total;
   if (lost) {
-    return xfail(SJPEG_HIP_ECAPACITY, "sjpeg_hip_gather_rows: a frame of size 0 (it did not fit its output slot or the "
-                                      "packed buffer) -- nothing to send");
+    // (the offsets are still usable as sizes: the flag is not part of them)
+    for (int k = 0; k <= c->world; ++k) h_rank_offsets[k] &= ~(uint64_t(1) << 63);
+    return xfail(SJPEG_HIP_ECAPACITY, "sjpeg_hip_gather_rows: a frame of size 0 (it did not fit its output slot) or a packed "
+                                      "buffer that was too small on some rank -- nothing to send");
   }
   return 0;
 }
@@ -251,7 +254,11 @@ int sjpeg_hip_gather_bytes(sjpeg_hip_comm* c, int root, const void* d_packed, in
   uint8_t* const dst = static_cast<uint8_t*>(d_gathered);
   if (my_bytes > 0) {
     if (d_packed == nullptr) return xfail(SJPEG_HIP_EINVAL, "sjpeg_hip_gather_bytes: d_packed == NULL");
-    XHIP_TRY(hipMemcpyAsync(dst + h_rank_offsets[root], d_packed, my_bytes, hipMemcpyDeviceToDevice, st));
+    // (a root that coded its frames straight into their place -- packed output into d_gathered + its offset,
+    // offset 0 for root 0 -- has nothing to copy)
+    if (static_cast<const uint8_t*>(d_packed) != dst + h_rank_offsets[root]) {
+      XHIP_TRY(hipMemcpyAsync(dst + h_rank_offsets[root], d_packed, my_bytes, hipMemcpyDeviceToDevice, st));
+    }
   }
   RCCL_TRY(r, r->GroupStart());
   ncclResult_t first_bad = ncclSuccess;

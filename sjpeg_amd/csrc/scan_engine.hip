@@ -728,9 +728,13 @@ static int encode_scan_impl(sjpeg_hip_engine* e, const sjpeg_hip_source* src, in
                             int yuv_mode, int nframes, const sjpeg_hip_scan_tables* tables,
                             const void* header, size_t header_size, const size_t* header_offsets,
                             int append_eoi, void* d_out, size_t out_stride, uint64_t* d_sizes,
-                            void* stream, const int* seg_range = nullptr /* restart mode: code only these segments */) {
+                            void* stream, const int* seg_range = nullptr /* restart mode: code only these segments */,
+                            uint64_t* d_pack_off = nullptr /* packed output: [nframes + 1] frame starts */) {
   if (e == nullptr) return fail(SJPEG_HIP_EINVAL, "engine == NULL");
   if (d_out == nullptr || d_sizes == nullptr) return fail(SJPEG_HIP_EINVAL, "d_out/d_sizes == NULL");
+  if (d_pack_off != nullptr && ((out_stride & 15u) != 0 || (reinterpret_cast<uintptr_t>(d_out) & 15u) != 0 || out_stride >= (1ull << 32))) {
+    return fail(SJPEG_HIP_EINVAL, "packed output: d_out and out_stride must be multiples of 16, out_stride below 4 GiB");
+  }
   if (header == nullptr) header_size = 0;
   const bool multi = header_offsets != nullptr;
   hipStream_t st = static_cast<hipStream_t>(stream);
@@ -826,6 +830,7 @@ static int encode_scan_impl(sjpeg_hip_engine* e, const sjpeg_hip_source* src, in
   s.append_eoi = append_eoi;
   s.out = static_cast<uint8_t*>(d_out); s.out_stride = out_stride;
   s.sizes = reinterpret_cast<unsigned long long*>(d_sizes);
+  s.pack_off = reinterpret_cast<unsigned long long*>(d_pack_off);
   s.seg_nbits64 = nullptr; s.total_bits_out = nullptr; s.subs = 1; s.wide_subs = 0;
   // few segments (one 4K frame: 791, one 8K 4:4:4 frame: 6172): one wave per 768 words of a slot instead of
   // one per segment -- a 1030-word segment was two dependent round trips of one wave (8K 4:4:4: K3 38 us)
@@ -876,6 +881,12 @@ static int encode_scan_impl(sjpeg_hip_engine* e, const sjpeg_hip_source* src, in
     e->k3_pending[set] = true;
     e->set = set ^ 1;
   }
+  if (s.pack_off != nullptr) {                     // packed output: the frames' places, then header / EOI / padding
+    hipLaunchKernelGGL(pack_frame_offsets, dim3(1), dim3(kThreads), 0, hs, s);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(pack_frame_edges, dim3(nframes), dim3(kThreads), 0, hs, s);
+    HIP_TRY(hipGetLastError());
+  }
   hipLaunchKernelGGL(stuff_chunks, dim3(gx, nframes), dim3(kThreads), 0, hs, s);
   HIP_TRY(hipGetLastError());
   if (a.rst && g.nseg - 1 + rst_tail > 0) {
@@ -899,6 +910,15 @@ int sjpeg_hip_encode_scan_src(sjpeg_hip_engine* e, const sjpeg_hip_source* src, 
                               size_t out_stride, uint64_t* d_sizes, void* stream) {
   return encode_scan_impl(e, src, width, height, yuv_mode, nframes, tables, header, header_size, nullptr,
                           append_eoi, d_out, out_stride, d_sizes, stream);
+}
+
+int sjpeg_hip_encode_scan_packed_src(sjpeg_hip_engine* e, const sjpeg_hip_source* src, int width, int height,
+                                     int yuv_mode, int nframes, const sjpeg_hip_scan_tables* tables,
+                                     const void* header, size_t header_size, int append_eoi, void* d_out,
+                                     size_t out_stride, uint64_t* d_sizes, uint64_t* d_offsets, void* stream) {
+  if (d_offsets == nullptr) return fail(SJPEG_HIP_EINVAL, "sjpeg_hip_encode_scan_packed_src: d_offsets == NULL");
+  return encode_scan_impl(e, src, width, height, yuv_mode, nframes, tables, header, header_size, nullptr,
+                          append_eoi, d_out, out_stride, d_sizes, stream, nullptr, d_offsets);
 }
 
 int sjpeg_hip_encode_intervals_src(sjpeg_hip_engine* e, const sjpeg_hip_source* src, int width, int height,
@@ -1315,7 +1335,9 @@ __global__ __launch_bounds__(256) void compact_streams_kernel(const uint8_t* out
   const unsigned long long n = sizes[f], n16 = (n + 15ull) & ~15ull;
   if (blockIdx.x == 0 && tid == 0) {
     offsets[f] = off;
-    if (f == nframes - 1) offsets[nframes] = off + n16;       // bytes needed, whether they fit or not
+    // bytes needed, whether they fit or not; bit 63 says they did not (SJPEG_HIP_PACKED_OVERFLOW: the exchange
+    // reads it in the rank's row and refuses on every rank)
+    if (f == nframes - 1) offsets[nframes] = (off + n16) | (off + n16 > capacity ? (1ull << 63) : 0ull);
   }
   if (off + n16 > capacity) return;                            // the caller sees it in offsets[nframes]
   const uint4* const src = reinterpret_cast<const uint4*>(out + static_cast<size_t>(f) * out_stride);

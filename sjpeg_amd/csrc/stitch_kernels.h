@@ -26,6 +26,9 @@ struct StitchArgs {
   uint8_t* out;
   size_t out_stride;
   unsigned long long* sizes;
+  // packed output (sjpeg_hip_encode_scan_packed_src): frame f starts at out + pack_off[f], a multiple of 16, the
+  // frames back to back; NULL: at out + f * out_stride.  out_stride stays the bytes a frame may take.
+  unsigned long long* pack_off = nullptr;
   const unsigned long long* seg_nbits64;   // band stitch: lengths as uint64 (else NULL)
   unsigned long long* total_bits_out;      // band encode: where the bit count of the band goes (else NULL)
   uint32_t subs;                           // K3: waves per segment (1 unless segments are whole bands, or wide_subs)
@@ -358,6 +361,10 @@ __global__ __launch_bounds__(kThreads) void place_segments(const StitchArgs a) {
   if (ff_chunk != 0xffffffffu) ff_flush();
 }
 
+__device__ __forceinline__ uint8_t* frame_out(const StitchArgs& a, int frame) {
+  return a.pack_off != nullptr ? a.out + a.pack_off[frame] : a.out + static_cast<size_t>(frame) * a.out_stride;
+}
+
 // ------------------------------------------------------------------------------------
 // K4: per frame, exclusive scan of per-chunk 0xFF counts; final stream size
 
@@ -405,18 +412,49 @@ __global__ __launch_bounds__(kThreads) void scan_chunk_offsets(const StitchArgs 
     const_cast<uint32_t*>(a.pool_ctr)[2 * frame] = 0u;
     const_cast<uint32_t*>(a.pool_ctr)[2 * frame + 1] = 0u;
   }
+  if (threadIdx.x == 0) a.sizes[frame] = fits ? size : 0ull;
+  // (packed output: where the frame starts is only known once every frame has its size -- pack_frames())
+  if (a.pack_off != nullptr) return;
   uint8_t* dst = a.out + static_cast<size_t>(frame) * a.out_stride;
-  if (threadIdx.x == 0) {
-    if (fits && a.append_eoi) {
-      dst[hsize + body] = 0xff;
-      dst[hsize + body + 1] = 0xd9;
-    }
-    a.sizes[frame] = fits ? size : 0ull;
+  if (threadIdx.x == 0 && fits && a.append_eoi) {
+    dst[hsize + body] = 0xff;
+    dst[hsize + body + 1] = 0xd9;
   }
   // header bytes in front of the entropy segment
   if (fits) {
     for (uint32_t i = threadIdx.x; i < hsize; i += kThreads) dst[i] = a.header[hoff + i];
   }
+}
+
+// K4b (packed output only): where every frame starts -- exclusive scan of the sizes, each rounded up to 16 --,
+// then header, EOI and the zero padding behind it, one workgroup per frame (blockIdx.x - 1; workgroup 0 scans).
+// Two launches: pack_frame_offsets<<<1>>> then pack_frame_edges<<<nframes>>>.
+__global__ __launch_bounds__(kThreads) void pack_frame_offsets(const StitchArgs a) {
+  __shared__ uint32_t scratch[16];
+  unsigned long long running = 0;
+  for (int f0 = 0; f0 < a.nframes; f0 += kThreads) {
+    const int f = f0 + static_cast<int>(threadIdx.x);
+    const unsigned long long mine = f < a.nframes ? ((a.sizes[f] + 15ull) & ~15ull) : 0ull;
+    // (a frame is below 4 GiB: out_stride is checked by the host; the scan runs on 16-byte units in 32 bits)
+    uint32_t total;
+    const uint32_t ex = wg_exclusive_scan<kThreads>(static_cast<uint32_t>(mine >> 4), scratch, &total);
+    if (f < a.nframes) a.pack_off[f] = running + (static_cast<unsigned long long>(ex) << 4);
+    running += static_cast<unsigned long long>(total) << 4;
+  }
+  if (threadIdx.x == 0) a.pack_off[a.nframes] = running;
+}
+
+__global__ __launch_bounds__(kThreads) void pack_frame_edges(const StitchArgs a) {
+  const int frame = blockIdx.x;
+  const unsigned long long size = a.sizes[frame];
+  if (size == 0) return;
+  const uint32_t hoff = a.hdr_off ? a.hdr_off[frame] : 0u;
+  const uint32_t hsize = a.hdr_off ? a.hdr_off[frame + 1] - hoff : a.header_size;
+  uint8_t* const dst = a.out + a.pack_off[frame];
+  for (uint32_t i = threadIdx.x; i < hsize; i += kThreads) dst[i] = a.header[hoff + i];
+  if (threadIdx.x == 0 && a.append_eoi) { dst[size - 2] = 0xff; dst[size - 1] = 0xd9; }
+  const uint32_t pad = static_cast<uint32_t>((16u - (size & 15u)) & 15u);
+  if (threadIdx.x < pad) dst[size + threadIdx.x] = 0;
 }
 
 // ------------------------------------------------------------------------------------
@@ -440,8 +478,8 @@ __global__ __launch_bounds__(kThreads) void stuff_chunks(const StitchArgs a) {
   const uint32_t* ub = a.ubuf + static_cast<size_t>(frame) * a.ubuf_words;
   const unsigned long long* co = a.chunk_off + static_cast<size_t>(frame) * a.max_chunks;
   const uint32_t hsize = a.hdr_off ? a.hdr_off[frame + 1] - a.hdr_off[frame] : a.header_size;
-  uint8_t* const dst0 = a.out + static_cast<size_t>(frame) * a.out_stride + hsize;
   if (a.sizes[frame] == 0) return;                          // did not fit (see K4)
+  uint8_t* const dst0 = frame_out(a, frame) + hsize;
   // the 16 bytes of this thread in the NEXT chunk of the workgroup (and the word behind them) are
   // requested while the current ones are stuffed
   auto fetch = [&](uint32_t chunk, uint4* q, uint32_t* behind, int* valid, unsigned long long* off) {
@@ -561,7 +599,7 @@ __global__ __launch_bounds__(kThreads) void patch_restart_markers(const StitchAr
   for (int d = 32; d > 0; d >>= 1) ffs += __shfl_down(ffs, d, 64);
   if (lane == 0) {
     const uint32_t hsize = a.hdr_off ? a.hdr_off[frame + 1] - a.hdr_off[frame] : a.header_size;
-    uint8_t* dst = a.out + static_cast<size_t>(frame) * a.out_stride + hsize + p +
+    uint8_t* dst = frame_out(a, frame) + hsize + p +
                    a.chunk_off[static_cast<size_t>(frame) * a.max_chunks + chunk] + ffs;
     dst[0] = 0xff;
     dst[1] = static_cast<uint8_t>(0xd0 + ((s + a.seg_first) & 7));

@@ -87,7 +87,8 @@ def _capacity_error(msg):
 
 def gather_streams(out: torch.Tensor, sizes: torch.Tensor, frame_ids: Sequence[int],
                    nframes: int, dst: int = 0, group=None, compact=None,
-                   to_host: bool = True, buffers: Optional[dict] = None, reuse_gathered: bool = True):
+                   to_host: bool = True, buffers: Optional[dict] = None, reuse_gathered: bool = True,
+                   packed_offsets: Optional[torch.Tensor] = None):
     """Gathers variable-length coded frames to `dst`: the exchange step of the batch path.
 
     out [F_local, stride] uint8 and sizes [F_local] int64 as an encode call left them, frame_ids the
@@ -102,6 +103,10 @@ def gather_streams(out: torch.Tensor, sizes: torch.Tensor, frame_ids: Sequence[i
     sizes its buffer from the actual total.  `buffers`: a dict the call keeps its device buffers in (reuse across
     steps); with to_host=False the RESULT lives in the "gathered" buffer, so a caller that keeps the results of
     several calls passes reuse_gathered=False (a fresh buffer per call; only the scratch is reused).
+    packed_offsets ([n_local + 1] int64): `out` is ALREADY packed -- a flat buffer written by
+    Engine.encode_frames_packed (sjpeg_hip_encode_scan_packed_src) -- and no compaction pass runs; on rank 0 as
+    `dst` the other ranks' streams are then received BEHIND its own in that same buffer when it is long enough
+    (and reuse_gathered): the root moves none of its own bytes.
     Returns on `dst` the nframes byte strings in global order (to_host=True) or a GatheredStreams holding
     the device-resident buffer (to_host=False); None elsewhere."""
     world = dist.get_world_size(group)
@@ -121,19 +126,24 @@ def gather_streams(out: torch.Tensor, sizes: torch.Tensor, frame_ids: Sequence[i
 
     if dev.type == "cuda":
         import sjpeg_amd as sj
-        packed = buf("packed", max(n_local, 1) * _align16(stride), torch.uint8)
-        offsets = buf("offsets", per_max + 1, torch.int64)
-        if n_local > 0:
-            sj.compact_streams(out, sizes, n_local, packed=packed, offsets=offsets[:n_local + 1])
+        if packed_offsets is not None:
+            packed, offsets = out.reshape(-1), packed_offsets
         else:
-            offsets[:1].zero_()
+            packed = buf("packed", max(n_local, 1) * _align16(stride), torch.uint8)
+            offsets = buf("offsets", per_max + 1, torch.int64)
+            if n_local > 0:
+                sj.compact_streams(out, sizes, n_local, packed=packed, offsets=offsets[:n_local + 1])
+            else:
+                offsets[:1].zero_()
         rows_dev = buf("rows", (world + 1) * (per_max + 2), torch.int64)
         comm = rccl_comm(group)
         rows, offs = comm.gather_rows(offsets, sizes, n_local, per_max, rows_dev)
         # the root sizes its buffer from the actual total (kept between steps, grown by halves)
         total = int(offs[world])
         gathered = None
-        if rank == dst and not reuse_gathered:
+        if rank == dst and packed_offsets is not None and reuse_gathered and int(offs[dst]) == 0 and packed.numel() >= total:
+            gathered = packed                       # the root's own streams are where they belong already
+        elif rank == dst and not reuse_gathered:
             gathered = torch.empty(max(total, 16), dtype=torch.uint8, device=dev)
         elif rank == dst:
             have = buffers.get("gathered")
@@ -227,19 +237,23 @@ def overlapped_steps(nsteps: int, encode, exchange, use_streams: bool, keep: str
 
 
 def exchange_loop(nsteps: int, encode, outs, sizes, frame_ids: Sequence[int], nframes: int,
-                  use_streams: bool, dst: int = 0, group=None, compact=None, keep: str = "all"):
+                  use_streams: bool, dst: int = 0, group=None, compact=None, keep: str = "all",
+                  packed_offsets=None):
     """bench.py's timed multi-rank region, as a function so that the CPU/gloo test runs exactly
     this code: `nsteps` encode calls, double buffered (outs[b], sizes[b], b = 0 / 1), the streams
     of every step gathered to `dst` (device resident there) under the next step's kernels.
     Returns the GatheredStreams of every step on `dst` (keep="last": of the last step only), a list of None
     elsewhere.  The exchange's scratch (packed block, offsets, rows) is held per output set and reused; the
     buffer a result lives in is reused only with keep="last" -- with keep="all" every step gets its own, or the
-    streams of step s would be overwritten by step s + 2."""
+    streams of step s would be overwritten by step s + 2.  packed_offsets (two tensors, one per output set):
+    encode(b) wrote PACKED output into outs[b] (Engine.encode_frames_packed): no compaction pass, and a root that
+    is rank 0 receives the others behind its own streams in outs[b] itself."""
     held = [{}, {}]                                 # device buffers of the exchange, one set per output set
     return overlapped_steps(
         nsteps, encode,
         lambda b: gather_streams(outs[b], sizes[b], frame_ids, nframes, dst=dst, group=group,
-                                 compact=compact, to_host=False, buffers=held[b], reuse_gathered=(keep == "last")),
+                                 compact=compact, to_host=False, buffers=held[b], reuse_gathered=(keep == "last"),
+                                 packed_offsets=None if packed_offsets is None else packed_offsets[b]),
         use_streams, keep)
 
 

@@ -913,7 +913,8 @@ def test_compact_streams_vs_restatement(engine):
         if n > 2:
             small = int(woffs[n - 1])                    # room for all but the last frame
             p2, o2 = sj.compact_streams(out, sizes, n, small)
-            assert int(o2[-1]) == need and torch.equal(p2.cpu(), want[:small])
+            # (bit 63 = SJPEG_HIP_PACKED_OVERFLOW: the batch did not fit; the low bits are still the bytes needed)
+            assert int(o2[-1]) < 0 and int(o2[-1]) & ((1 << 63) - 1) == need and torch.equal(p2.cpu(), want[:small])
     # the real thing: a batch of coded frames survives the packing
     imgs = [synth.g_struct(160, 96, 70 + k) for k in range(5)]
     frames = torch.from_numpy(np.stack(imgs)).cuda()
@@ -1374,3 +1375,94 @@ def test_every_block_makes_four_parts(engine, oracle):
         for rep in range(8):
             got = sj.encode_device(d, 92.0, mode, engine=engine)[0]
             assert got == want, (mode, rep)
+
+
+def test_packed_output_equals_the_strided_frames(engine, oracle):
+    """sjpeg_hip_encode_scan_packed_src: the frames back to back at multiples of 16 (zero padding), offsets = the
+    running sum of the 16-aligned sizes -- what sjpeg_hip_compact_streams makes of the strided batch, byte for
+    byte --; frames of different sizes, restart mode, a frame that does not fit its share (size 0, no room)."""
+    rng = np.random.RandomState(5)
+    w, h, nf = 200, 120, 7
+    imgs = [synth.g_struct(w, h, 70 + k) if k % 3 else rng.randint(0, 256, (h, w, 3)).astype(np.uint8) for k in range(nf)]
+    frames = torch.from_numpy(np.stack(imgs)).cuda()
+    for q, flags in ((75.0, 0), (95.0, 0), (60.0, sj.RESTART_MARKERS)):
+        tables, quant = sj.make_tables(quality=q)
+        tables.flags = flags
+        header = sj.make_header(w, h, sj.YUV_420, quant)
+        if flags:
+            header = sj.header_add_restart(header, sj.YUV_420)
+        out, sizes = engine.encode_frames(frames, tables, header, sj.YUV_420)
+        stride = int(out.stride(0))
+        want_packed, want_offsets = sj.compact_streams(out, sizes)
+        flat = torch.full((nf * stride + 4096,), 0xA5, dtype=torch.uint8, device="cuda")
+        sizes2 = torch.zeros(nf, dtype=torch.int64, device="cuda")
+        offs2 = torch.zeros(nf + 1, dtype=torch.int64, device="cuda")
+        engine.encode_frames_packed(frames, tables, header, sj.YUV_420, flat, sizes2, offs2, stride)
+        torch.cuda.synchronize()
+        assert torch.equal(sizes, sizes2) and torch.equal(offs2, want_offsets)
+        total = int(offs2[nf])
+        assert torch.equal(flat[:total], want_packed[:total])
+        assert int((flat[total:] != 0xA5).sum()) == 0                       # nothing behind the batch is touched
+        if not flags:
+            o = offs2.cpu().numpy()
+            for k in range(nf):
+                assert flat[int(o[k]):int(o[k]) + int(sizes2[k])].cpu().numpy().tobytes() == oracle.encode(imgs[k], q, 1), k
+    # the noise frames do not fit 12 000 bytes, the structured ones do: size 0, and the next frame follows at once
+    tables, quant = sj.make_tables(quality=95.0)
+    header = sj.make_header(w, h, sj.YUV_420, quant)
+    _, full = engine.encode_frames(frames, tables, header, sj.YUV_420)
+    full = sorted(int(v) for v in full.cpu().numpy())
+    stride = ((full[3] + full[4]) // 2) & ~15          # between the four structured frames and the three of noise
+    assert full[3] + 64 < stride < full[4] - 64
+    flat = torch.zeros(nf * stride, dtype=torch.uint8, device="cuda")
+    sizes2 = torch.zeros(nf, dtype=torch.int64, device="cuda")
+    offs2 = torch.zeros(nf + 1, dtype=torch.int64, device="cuda")
+    engine.encode_frames_packed(frames, tables, header, sj.YUV_420, flat, sizes2, offs2, stride)
+    torch.cuda.synchronize()
+    sz, o = sizes2.cpu().numpy(), offs2.cpu().numpy()
+    assert (sz == 0).any() and (sz > 0).any()
+    for k in range(nf):
+        assert int(o[k + 1] - o[k]) == ((int(sz[k]) + 15) & ~15)
+        if sz[k]:
+            assert flat[int(o[k]):int(o[k]) + int(sz[k])].cpu().numpy().tobytes() == oracle.encode(imgs[k], 95.0, 1), k
+
+
+def test_exchange_of_packed_output_and_the_overflow_flag(engine, oracle):
+    """One rank: the root codes PACKED output straight into the buffer the exchange gathers into -- gather_bytes has
+    nothing to copy (d_packed == d_gathered + its offset) --; and a d_packed that was too small for
+    sjpeg_hip_compact_streams shows as SJPEG_HIP_PACKED_OVERFLOW in d_offsets[nframes], which the rows carry to
+    every rank: refused before anything is sent (the old check could not see it)."""
+    w, h, nf = 200, 120, 5
+    tables, quant = sj.make_tables(quality=75.0)
+    header = sj.make_header(w, h, sj.YUV_420, quant)
+    imgs = [synth.g_struct(w, h, 900 + k) for k in range(nf)]
+    frames = torch.from_numpy(np.stack(imgs)).cuda()
+    stride = sj.frame_bound(w, h, sj.YUV_420, len(header))
+    flat = torch.zeros(nf * stride, dtype=torch.uint8, device="cuda")
+    sizes = torch.zeros(nf, dtype=torch.int64, device="cuda")
+    offs = torch.zeros(nf + 1, dtype=torch.int64, device="cuda")
+    engine.encode_frames_packed(frames, tables, header, sj.YUV_420, flat, sizes, offs, stride)
+    comm = sj.Comm(sj.comm_unique_id(), 0, 1)
+    try:
+        rows_dev = torch.zeros(2 * (nf + 2), dtype=torch.int64, device="cuda")
+        rows, ro = comm.gather_rows(offs, sizes, nf, nf, rows_dev)
+        before = flat.clone()
+        comm.gather_bytes(0, flat, nf, rows, ro, flat)                    # in place: nothing moves
+        torch.cuda.synchronize()
+        assert torch.equal(before, flat)
+        host, o = flat.cpu().numpy(), 0
+        for k in range(nf):
+            n = int(rows[0][2 + k])
+            assert host[o:o + n].tobytes() == oracle.encode(imgs[k], 75.0, 1), k
+            o += (n + 15) & ~15
+        # compact_streams into a buffer that is one frame short
+        out, sizes_s = engine.encode_frames(frames, tables, header, sj.YUV_420)
+        need = int(offs[nf])
+        small = torch.zeros(need - 16, dtype=torch.uint8, device="cuda")
+        _, offs_s = sj.compact_streams(out, sizes_s, packed=small)
+        torch.cuda.synchronize()
+        assert int(offs_s[nf]) & ((1 << 63) - 1) == need and int(offs_s[nf]) < 0        # (int64 view of bit 63)
+        with pytest.raises(sj.SjpegError):
+            comm.gather_rows(offs_s, sizes_s, nf, nf, rows_dev)
+    finally:
+        comm.close()
