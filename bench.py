@@ -663,6 +663,39 @@ def main():
             with_gather = {"error": repr(exc)}
         if rank == 0:
             res["with_gather"] = with_gather
+        # the non-rooted end: every rank brings its own streams to its own (pinned) host memory over its own PCIe
+        # link, under the next step's kernels -- no collective, nothing converges on rank 0
+        try:
+            from sjpeg_amd.dist import overlapped_steps, sink_streams_local
+            pins = [torch.empty(F * per_frame, dtype=torch.uint8).pin_memory() for _ in range(2)]
+            last = {}
+
+            def sink(b):
+                last["n"], last["offs"] = sink_streams_local(pouts[b], poffs[b], F, pins[b])
+                last["b"] = b
+
+            overlapped_steps(2, encode_packed, sink, True, keep="last")
+            fence()
+            sts = []
+            for _ in range(min(args.regions, 5)):
+                fence()
+                g0 = time.perf_counter()
+                overlapped_steps(args.steps, encode_packed, sink, True, keep="last")
+                fence()
+                sts.append(max_over_ranks(time.perf_counter() - g0))
+            sdt = float(np.median(sts))
+            hb, ho, hs = pins[last["b"]].numpy(), last["offs"].numpy(), sizes_b[last["b"]].cpu().numpy()
+            ok = all(hb[int(ho[k]):int(ho[k]) + int(hs[k])].tobytes() == coded[k] for k in range(F))
+            local_sink = {"value": round(W * H * F * world * args.steps / sdt / 1e6, 1), "unit": "Mpixels/s",
+                          "ms_per_step": round(sdt / args.steps * 1e3, 4), "verified": bool(ok),
+                          "host_GBps_per_rank": round(last["n"] * args.steps / sdt / 1e9, 1),
+                          "what": "every rank: encode with packed output, then ONE device-to-host copy of its own streams into "
+                                  "its own pinned buffer (sjpeg_amd.dist.sink_streams_local) under the next step's kernels; no "
+                                  "collective -- what a rank's PCIe link carries bounds it (about 0.25 B per pixel here)"}
+        except Exception as exc:
+            local_sink = {"error": repr(exc)}
+        if rank == 0:
+            res["with_local_sink"] = local_sink
         try:                                      # config #4 as written: 64 x 1080p, 64 / N per rank, gathered to rank 0
             c4 = c4_region(sj, torch, eng, rank, world, args.steps, min(args.regions, 5), digests, fence, max_over_ranks)
         except Exception as exc:

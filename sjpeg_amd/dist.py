@@ -189,6 +189,24 @@ def gather_streams(out: torch.Tensor, sizes: torch.Tensor, frame_ids: Sequence[i
     return got.frames() if to_host else got
 
 
+def sink_streams_local(packed: torch.Tensor, offsets: torch.Tensor, n_local: int, host: torch.Tensor):
+    """The NON-ROOTED end of the batch path ("spread sinks"): every rank brings the streams IT
+    coded to ITS OWN host buffer -- one device-to-host copy of the packed block over the rank's own PCIe link --
+    instead of funnelling them through rank 0's xGMI links and rank 0's one PCIe link.  No collective at all: a
+    consumer that needs the whole batch in one place reads the ranks' host buffers (one node: shared memory).
+    `packed` / `offsets` as Engine.encode_frames_packed (or compact_streams) left them, `host` a pinned uint8
+    tensor.  One small read of the offsets (the byte count is a host value for the copy), then the copy,
+    asynchronous on the current stream.  Returns (bytes, offsets on the host); frame k of this rank is
+    host[offsets[k] : offsets[k] + sizes[k]] once the stream has been waited for."""
+    offs = offsets[:n_local + 1].cpu()
+    total = int(offs[n_local])
+    if total < 0 or total > host.numel():
+        raise _capacity_error(f"sink_streams_local: {total & ((1 << 63) - 1)} bytes, host buffer {host.numel()}")
+    if total > 0:
+        host[:total].copy_(packed.reshape(-1)[:total], non_blocking=True)
+    return total, offs
+
+
 def overlapped_steps(nsteps: int, encode, exchange, use_streams: bool, keep: str = "all"):
     """The multi-rank step loop of bench.py: step s is coded into buffer set s & 1 while the streams
     of step s - 1 are exchanged.  encode(buf) enqueues one encode call into set `buf`;

@@ -293,3 +293,24 @@ def test_gather_bands_two_ranks():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert ok
+
+
+def test_sink_streams_local_brings_a_rank_its_own_frames():
+    """The non-rooted end of the batch path: a rank's packed block to its own host buffer, the offsets read once."""
+    import pytest
+    import sjpeg_amd as sj
+    from sjpeg_amd.dist import sink_streams_local
+    rng = np.random.RandomState(3)
+    frames = [rng.randint(0, 256, n).astype(np.uint8) for n in (40, 1, 33, 160)]
+    out = torch.zeros((4, 176), dtype=torch.uint8)
+    sizes = torch.tensor([len(f) for f in frames], dtype=torch.int64)
+    for i, f in enumerate(frames):
+        out[i, :len(f)] = torch.from_numpy(f)
+    packed, offs = _compact_torch(out, sizes, 4, 4 * 176)
+    host = torch.zeros(1024, dtype=torch.uint8)
+    total, ho = sink_streams_local(packed, offs, 4, host)
+    assert total == int(offs[4]) == 48 + 16 + 48 + 160
+    for i, f in enumerate(frames):
+        assert host[int(ho[i]):int(ho[i]) + len(f)].numpy().tobytes() == f.tobytes()
+    with pytest.raises(sj.SjpegError):
+        sink_streams_local(packed, offs, 4, torch.zeros(64, dtype=torch.uint8))
