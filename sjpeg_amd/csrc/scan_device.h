@@ -77,6 +77,7 @@ struct ScanArgs {
   int16_t* coeffs;         // kKindTap: quantized coefficients
   uint32_t* partial;       // kKindHisto / kKindStats: per-workgroup partial statistics
   unsigned long long* stamps;  // profiling (env SJPEG_HIP_STAMPS): 8 cycle stamps per workgroup
+  int stamp_real;              // ... taken from the device-wide 100 MHz counter instead
   int ablate;              // profiling knob (env SJPEG_HIP_ABLATE): stop after phase 1/2/3; 0 = full
 };
 

@@ -401,6 +401,9 @@ int prepare_scan(sjpeg_hip_engine* e, const sjpeg_hip_source* src,
   if (e->want_stamps) {
     if (int rc2 = e->stamps.ensure(total_segs * 8)) return rc2;
     a->stamps = e->stamps.p;
+    // SJPEG_HIP_STAMPS=2: the 100 MHz real-time counter (one clock for the whole device: when workgroups start
+    // and end relative to each other) instead of the shader-clock cycle counter (per CU: phase durations)
+    a->stamp_real = atoi(getenv("SJPEG_HIP_STAMPS")) == 2 ? 1 : (atoi(getenv("SJPEG_HIP_STAMPS")) == 3 ? 2 : 0);
     e->stamps_n = total_segs * 8;
   }
   return 0;

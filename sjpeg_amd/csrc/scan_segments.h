@@ -65,7 +65,8 @@ __global__ __launch_bounds__(kScanThreads, ((KINDX == kKindHisto && SRC == kSrcR
   const int seg = blockIdx.x, frame = blockIdx.y;
   auto stamp = [&](int k) {
     if (a.stamps != nullptr && tid == 0) {
-      a.stamps[(static_cast<size_t>(frame) * a.nseg + seg) * 8 + k] = __builtin_readcyclecounter();
+      a.stamps[(static_cast<size_t>(frame) * a.nseg + seg) * 8 + k] =
+          a.stamp_real ? __builtin_amdgcn_s_memrealtime() : __builtin_readcyclecounter();
     }
   };
   stamp(0);
@@ -1208,8 +1209,12 @@ __global__ __launch_bounds__(kScanThreads, ((KINDX == kKindHisto && SRC == kSrcR
         const uint32_t rec = ur_get(r);
         if (rec != 0xffffffffu) {
           const uint32_t st = part_start(rec);
-          // (a part's last store may go one word past its bits: + 32)
-          if (st < hi && st + part_bits(rec) + 32u > lo) place(std::true_type(), rec, st, tw_get(r), base_w);
+          // (a part's last store may go one word past its bits: + 32).  Nearly every part lies inside ONE window
+          // and takes the plain path with its position relative to that window; the few that straddle a window's
+          // end are placed word by word, clipped, once in each of the two windows
+          const uint32_t end = st + part_bits(rec) + 32u;
+          if (st >= lo && end <= hi) place(std::false_type(), rec, st - lo, tw_get(r), 0u);
+          else if (st < hi && end > lo) place(std::true_type(), rec, st, tw_get(r), base_w);
         }
       }
       if (a.rst && tid == 0 && (data_bits & 7u) != 0u && data_bits >= lo && data_bits < hi) {
@@ -1227,5 +1232,7 @@ __global__ __launch_bounds__(kScanThreads, ((KINDX == kKindHisto && SRC == kSrcR
   RACE_POINT(11);
   if (tid == 0) a.seg_nbits[static_cast<size_t>(frame) * a.nseg + seg] = total;
   stamp(7);
+  // (SJPEG_HIP_STAMPS=3: the last stamp is the segment's bit count instead -- which segments stitch slowly?)
+  if (a.stamps != nullptr && a.stamp_real == 2 && tid == 0) a.stamps[(static_cast<size_t>(frame) * a.nseg + seg) * 8 + 7] = total;
 }
 

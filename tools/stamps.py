@@ -5,8 +5,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import sjpeg_amd as sj
 from oracle import synth
-os.environ["SJPEG_HIP_STAMPS"] = "1"
-F = 16
+os.environ["SJPEG_HIP_STAMPS"] = os.environ.get("STAMP_MODE", "1")     # 2: device-wide 100 MHz clock
+F = int(os.environ.get("STAMP_FRAMES", "16"))
 gen = synth.g_noise if len(sys.argv) > 1 and sys.argv[1] == "noise" else synth.g_struct
 host = [gen(3840, 2160, 7654321 + k) for k in range(4)]
 frames = torch.empty((F, 2160, 3840, 3), dtype=torch.uint8, device="cuda")
@@ -32,3 +32,21 @@ for i, nm in enumerate(names):
     print(f"  {nm:14s} mean {d[:, i].mean():9.0f}  p50 {np.median(d[:, i]):9.0f}  p95 {np.percentile(d[:, i], 95):9.0f}")
 span = st[:, 7].max() - st[:, 0].min()
 print("launch span cycles", span)
+if os.environ.get("STAMP_MODE") == "3":
+    # the last stamp is the segment's bit count: stitch time (cycles) against segment length
+    bits = st[:, 7]; stitch = st[:, 6] - st[:, 5]
+    order = np.argsort(stitch)
+    print("stitch cycles vs segment bits: slowest 12:", [(int(stitch[i]), int(bits[i]), int(i)) for i in order[-12:]])
+    print("                               median ones:", [(int(stitch[i]), int(bits[i]), int(i)) for i in order[len(order) // 2 - 3:len(order) // 2 + 3]])
+    print("corr(stitch, bits) = %.3f; segments over %d bits (one window): %d of %d" % (
+        np.corrcoef(stitch, bits)[0, 1], 1112 * 32, int((bits > 1112 * 32).sum()), len(bits)))
+    sys.exit(0)
+if os.environ.get("STAMP_MODE") == "2":
+    # device-wide clock, 10 ns ticks: when the workgroups of the launch start and end
+    t0 = st[:, 0].min()
+    starts = np.sort(st[:, 0] - t0) / 100.0; ends = np.sort(st[:, 7] - t0) / 100.0
+    pc = lambda v, p: np.percentile(v, p)
+    print("starts (us): p0 %.2f p10 %.2f p50 %.2f p90 %.2f p100 %.2f" % (starts[0], pc(starts, 10), pc(starts, 50), pc(starts, 90), starts[-1]))
+    print("ends   (us): p0 %.2f p10 %.2f p50 %.2f p90 %.2f p100 %.2f" % (ends[0], pc(ends, 10), pc(ends, 50), pc(ends, 90), ends[-1]))
+    life = (st[:, 7] - st[:, 0]) / 100.0
+    print("lifetime (us): p10 %.2f p50 %.2f p90 %.2f max %.2f" % (pc(life, 10), pc(life, 50), pc(life, 90), life.max()))
