@@ -115,6 +115,8 @@ template <> struct Lds<false> {
   static constexpr int kOffZrl = kOffAcm + 2 * 160 * 4;          // uint4[2][4]: ZRL patterns
   static constexpr int kOffMisc = kOffZrl + 128;                 // scan scratch
   static constexpr int kLdsBytes = kOffMisc + 64;                // 48592: three workgroups per CU
+  // kKindStats only: the symbol counters u32[2][256 AC + 16 DC], in TWO copies picked by lane parity, behind everything
+  static constexpr int kOffStats = kLdsBytes, kStatsCopies = 2;
   static_assert(kOffHist >= kOffTlen + 512 && kOffList >= kOffHist + 128 && kOffDcw >= kOffList + 2048 &&
                 kOffDcw + 4 * kScanThreads <= kOffWin + kWinWords * 4, "bookkeeping behind the tables, inside the window");
 };
@@ -130,6 +132,8 @@ template <> struct Lds<true> {
   static constexpr int kOffDc = kOffWin + 2048;                  // uint32[24] + safe masks [2] + EOB / ZRL words [4]
   static constexpr int kOffTlen = -1, kOffAc = -1;               // (no trellis kind, no raw AC table in this layout)
   static constexpr int kOffAcm = kOffWin + 2176;
+  // kKindStats (which has no merged code words, DC code words, ZRL patterns or window): ONE copy of the counters
+  static constexpr int kOffStats = kOffAcm, kStatsCopies = 1;
   static constexpr int kOffDcw = kOffWin + 3456;                 // u32 [252]
   static constexpr int kOffZrl = kOffWin + 4464;                 // (read by the stitch: behind the window, like misc)
   static constexpr int kOffMisc = kOffZrl + 128;
@@ -138,8 +142,8 @@ template <> struct Lds<true> {
                 kOffZrl >= kOffDcw + 4 * kSlots && (kWinWords + 1) * 4 <= kOffZrl - kOffWin, "compact carve");
   static_assert(4 * kLdsBytes <= 160 * 1024, "four workgroups per CU");
 };
-constexpr int kOffStats = Lds<false>::kLdsBytes;                 // kKindStats only: u32[2 replicas][2][272]
-constexpr int kLdsBytesStats = kOffStats + 2 * 2 * 272 * 4;
+constexpr int kLdsBytesStats = Lds<false>::kOffStats + 2 * 2 * 272 * 4;     // (the roomy layout of the statistics kind)
+static_assert(Lds<true>::kOffStats + 2 * 272 * 4 <= Lds<true>::kOffZrl, "compact carve, statistics kind");
 constexpr int kSamplesBytes = Lds<false>::kSamplesBytes;
 static_assert(3 * kLdsBytesStats <= 160 * 1024, "three workgroups per CU (statistics kind)");
 static_assert(3 * Lds<false>::kLdsBytes <= 160 * 1024, "three workgroups per CU");

@@ -33,7 +33,7 @@ __device__ __forceinline__ void race_point(int code, int n) {
 // smaller LDS block)
 // the compact LDS layout (scan_device.h): four workgroups per CU
 template <int MODE, int KINDX, int SRC>
-constexpr bool kCompactLds = (KINDX == kKindEncode || KINDX == kKindEncodeReplay);
+constexpr bool kCompactLds = (KINDX == kKindEncode || KINDX == kKindEncodeReplay || KINDX == kKindStats);
 
 template <int MODE, int KINDX, int SRC>
 __global__ __launch_bounds__(kScanThreads, ((KINDX == kKindHisto && SRC == kSrcRgb24) || kCompactLds<MODE, KINDX, SRC>) ? 4 : 1) void scan_segments(const ScanArgs a) {
@@ -51,7 +51,7 @@ __global__ __launch_bounds__(kScanThreads, ((KINDX == kKindHisto && SRC == kSrcR
   static_assert(2 * 4 * G::kSegMcus * BPM <= L::kListBytes, "the part list holds four parts of every coded block");
   // static, not `extern __shared__`: the address of a dynamic block is resolved after instruction
   // selection and leaves a `+ 0` in ~65 address computations of this kernel
-  __shared__ __attribute__((aligned(16))) unsigned char smem[(KIND == kKindStats) ? kLdsBytesStats : (KIND == kKindHisto && SRC == kSrcRgb24) ? kSamplesBytes : L::kLdsBytes];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[(KIND == kKindStats && !COMPACT) ? kLdsBytesStats : (KIND == kKindHisto && SRC == kSrcRgb24) ? kSamplesBytes : L::kLdsBytes];
   uint32_t* const win = reinterpret_cast<uint32_t*>(smem + L::kOffWin);
   uint4* const lq = reinterpret_cast<uint4*>(smem + L::kOffQ);
   uint32_t* const ldc = reinterpret_cast<uint32_t*>(smem + L::kOffDc);
@@ -95,8 +95,10 @@ __global__ __launch_bounds__(kScanThreads, ((KINDX == kKindHisto && SRC == kSrcR
       constexpr int kAcm16 = kTablesA16 + 128;       // group B: 128 uint4 of raw AC codes in front of the merged ones
       if (tid < 64) reinterpret_cast<uint4*>(smem + L::kOffQ)[tid] = t16[tid];
       else if (tid < kTablesA16) reinterpret_cast<uint4*>(smem + L::kOffDc)[tid - 64] = t16[tid];
-      if (tid >= 128 && tid < 128 + 80) reinterpret_cast<uint4*>(smem + L::kOffAcm)[tid - 128] = t16[kAcm16 + tid - 128];
-      else if (tid >= 128 + 80 && tid < 128 + 88) reinterpret_cast<uint4*>(smem + L::kOffZrl)[tid - 208] = t16[kAcm16 + tid - 128];
+      if (KIND != kKindStats) {                    // (the statistics kind codes nothing: its counters lie where the merged code words would)
+        if (tid >= 128 && tid < 128 + 80) reinterpret_cast<uint4*>(smem + L::kOffAcm)[tid - 128] = t16[kAcm16 + tid - 128];
+        else if (tid >= 128 + 80 && tid < 128 + 88) reinterpret_cast<uint4*>(smem + L::kOffZrl)[tid - 208] = t16[kAcm16 + tid - 128];
+      }
     } else {
       if (tid < kTablesB16) reinterpret_cast<uint4*>(smem + L::kOffAc)[tid] = t16[kTablesA16 + tid];
       if (tid < kTablesA16) reinterpret_cast<uint4*>(smem + L::kOffQ)[tid] = t16[tid];
@@ -108,8 +110,8 @@ __global__ __launch_bounds__(kScanThreads, ((KINDX == kKindHisto && SRC == kSrcR
       if (tid == 32) misc[10] = 0;
     }
     if (KIND == kKindStats) {                      // the symbol counters (their own LDS behind everything else)
-      uint32_t* const lf0 = reinterpret_cast<uint32_t*>(smem + kOffStats);
-      for (int i = tid; i < 2 * kStatsWords; i += kScanThreads) lf0[i] = 0;
+      uint32_t* const lf0 = reinterpret_cast<uint32_t*>(smem + L::kOffStats);
+      for (int i = tid; i < L::kStatsCopies * kStatsWords; i += kScanThreads) lf0[i] = 0;
     }
   };
 
@@ -737,13 +739,13 @@ __global__ __launch_bounds__(kScanThreads, ((KINDX == kKindHisto && SRC == kSrcR
     }
   } else {
     // (the statistics kind counts a part's symbols out of the two whole masks)
-    *reinterpret_cast<uint4*>(tail) = make_uint4(nz_lo, nz_hi, dc_word | (static_cast<uint32_t>(tbl) << 30), 0u);
+    if (has_slot) *reinterpret_cast<uint4*>(tail) = make_uint4(nz_lo, nz_hi, dc_word | (static_cast<uint32_t>(tbl) << 30), 0u);
   }
 
   // kKindStats: [2][272] counters, 256 AC then 16 DC, in TWO copies picked by lane parity: the lanes of a
   // wave count the same few symbols most of the time and an LDS atomic serialises the lanes that hit one
   // word; the copies are added up at the flush
-  uint32_t* const lf = reinterpret_cast<uint32_t*>(smem + kOffStats) + (KIND == kKindStats ? (tid & 1) * kStatsWords : 0);
+  uint32_t* const lf = reinterpret_cast<uint32_t*>(smem + L::kOffStats) + ((KIND == kKindStats && L::kStatsCopies == 2) ? (tid & 1) * kStatsWords : 0);
   if (KIND == kKindStats) {
     // Symbol statistics for optimised Huffman tables (reference AddEntropyStats,
     // src/entropy.cc:208-227): per table, counts of AC symbols (run << 4 | size, ZRL, EOB) and
@@ -832,8 +834,8 @@ __global__ __launch_bounds__(kScanThreads, ((KINDX == kKindHisto && SRC == kSrcR
     RACE_POINT(20);
     __syncthreads();
     uint32_t* const dst = a.partial + (static_cast<size_t>(frame) * a.nseg + seg) * kStatsWords;
-    const uint32_t* const lf_all = reinterpret_cast<const uint32_t*>(smem + kOffStats);
-    for (int i = tid; i < kStatsWords; i += kScanThreads) dst[i] = lf_all[i] + lf_all[kStatsWords + i];
+    const uint32_t* const lf_all = reinterpret_cast<const uint32_t*>(smem + L::kOffStats);
+    for (int i = tid; i < kStatsWords; i += kScanThreads) dst[i] = lf_all[i] + (L::kStatsCopies == 2 ? lf_all[kStatsWords + i] : 0u);
     return;
   }
 
