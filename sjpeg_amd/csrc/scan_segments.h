@@ -950,7 +950,12 @@ __global__ __launch_bounds__(kScanThreads, ((KINDX == kKindHisto && SRC == kSrcR
     // positions are local to the quarter from here on; the ZRLs of the first run are taken out of it
     // (only the first symbol of a part can have a run of 16 or more, and never in quarter 0)
     const uint32_t nzrl = (inf >> 4) & 3u;
-    int prevl = __builtin_ctz(m | 0x10000u) - static_cast<int>(inf & 15u);   // local position after the previous non-zero; may be negative
+    // bit 16 set for good: a guard behind the part's 16 positions, so that "the next non-zero" is a bare v_ffbl
+    uint32_t ms = m | 0x10000u;
+    // local position OF the previous non-zero (may be negative); a symbol's row of merged code words is picked by
+    // pos - prevp = run + 1, with the table base one row down: one subtraction instead of a three-operand form
+    int prevp = __builtin_ctz(ms) - static_cast<int>(inf & 15u) - 1;
+    const uint32_t tbm = tb - 40u;
     // (the two code words the end of the part may need: fetched here, under the symbols' round trips)
     const uint2 ez = *reinterpret_cast<const uint2*>(ldc + 26 + 2 * b_tbl);
     const uint32_t eob = ez.x, zrl = ez.y;
@@ -977,8 +982,8 @@ __global__ __launch_bounds__(kScanThreads, ((KINDX == kKindHisto && SRC == kSrcR
     };
     // first half of a symbol: its level bits and the address of its merged code word
     auto stage = [&](int pos, uint32_t e, uint32_t& lv, uint32_t& cw_at) {
-      const uint32_t run = static_cast<uint32_t>(pos - prevl);      // 0 .. 15
-      prevl = pos + 1;
+      const uint32_t run1 = static_cast<uint32_t>(pos - prevp);     // run + 1: 1 .. 16
+      prevp = pos;
       const uint32_t mag = e & 0x7fffu;                            // 1 .. 1023
       const uint32_t nl = static_cast<uint32_t>(__builtin_clz(mag));   // 32 - n (mag != 0: a bare v_ffbh_u32)
       const uint32_t ones = 0xffffffffu >> nl;
@@ -986,21 +991,21 @@ __global__ __launch_bounds__(kScanThreads, ((KINDX == kKindHisto && SRC == kSrcR
       asm("v_bfe_i32 %0, %1, 15, 1" : "=v"(sgn) : "v"(e));
       lv = mag ^ (ones & sgn);
       uint32_t row;                                // tb + 40 run in one operation (the compiler makes it mul + shift + add3)
-      asm("v_mad_u32_u24 %0, %1, 40, %2" : "=v"(row) : "v"(run), "v"(tb));
+      asm("v_mad_u32_u24 %0, %1, 40, %2" : "=v"(row) : "v"(run1), "v"(tbm));
       cw_at = row + nl * 4u;
     };
     if (m) {
-      int i = __builtin_ctz(m);
+      int i = __builtin_ctz(ms);
       uint32_t e = entry_at(i);
-      m &= m - 1u;
-      int i_next = __builtin_ctz(m | 0x10000u);
+      ms &= ms - 1u;
+      int i_next = __builtin_ctz(ms);
       uint32_t e_next = entry_at(i_next);
       uint32_t lv, cw_at;
       stage(i, e, lv, cw_at);
       uint32_t cw = *reinterpret_cast<const uint32_t*>(smem + cw_at);
-      while (m) {                                  // (i_next, e_next) is a symbol
-        m &= m - 1u;
-        const int i_after = __builtin_ctz(m | 0x10000u);
+      while (ms != 0x10000u) {                     // (i_next, e_next) is a symbol
+        ms &= ms - 1u;
+        const int i_after = __builtin_ctz(ms);
         const uint32_t e_after = entry_at(i_after);
         uint32_t lv_next, cw_at_next;
         stage(i_next, e_next, lv_next, cw_at_next);
