@@ -20,7 +20,7 @@ ordered kernels, and `roofline.kernel_ms` the dominant kernel alone.
 Methodology: after W warm-up steps, `--regions` R (default 11) timed regions of
 EXACTLY K steps each, every one bracketed by barrier + device synchronise, the maximum over ranks taken
 per region; `ms_per_step` / `value` are the MEDIAN region, `ms_per_step_min` / `_max` the spread, and
-`clocks` the device's sclk / mclk before the first and after the last region (boxes differ by a few per cent).
+`clocks` the device's sclk / mclk read while the first and the last region run (boxes differ by a few per cent).
 
 Rank 0 prints ONE JSON line.
 * `roofline` prices the dominant kernel (scan_segments) against the HBM read roofline with
@@ -66,7 +66,7 @@ W, H, QUALITY = 3840, 2160, 75.0
 HBM_PEAK = 8.0e12          # B/s, MI355X HBM3E spec (MI355X_MICROARCH.md)
 N_SIMD, CLOCK_HZ = 256 * 4, 2.4e9
 # the PMC pass of this build the static figures (HBM traffic, VALU instructions per wave) come from
-PMC_SUMMARY = os.path.join("profiles", "r03", "final_pmc_summary.txt")
+PMC_SUMMARY = os.path.join("profiles", "r04", "final_pmc_summary.txt")
 
 
 def cpu_baseline(frames_np, budget_s=12.0):
@@ -224,13 +224,16 @@ def device_clocks(index=0):
     tables (pp_dpm_sclk / pp_dpm_mclk), else rocm-smi; None where neither can be read."""
     import glob
     out = {}
-    cards = []
-    for d in sorted(glob.glob("/sys/class/drm/card[0-9]*/device")):
-        try:
-            if open(os.path.join(d, "vendor")).read().strip() == "0x1002" and os.path.exists(os.path.join(d, "pp_dpm_sclk")):
-                cards.append(d)
-        except OSError:
-            pass
+    cards = getattr(device_clocks, "cards", None)
+    if cards is None:                             # (found once: the read itself must stay far below a region's time)
+        cards = []
+        for d in sorted(glob.glob("/sys/class/drm/card[0-9]*/device"), key=lambda p: int(re.search(r"card(\d+)", p).group(1))):
+            try:
+                if open(os.path.join(d, "vendor")).read().strip() == "0x1002" and os.path.exists(os.path.join(d, "pp_dpm_sclk")):
+                    cards.append(d)
+            except OSError:
+                pass
+        device_clocks.cards = cards
     if index < len(cards):
         for key, name in (("sclk_mhz", "pp_dpm_sclk"), ("mclk_mhz", "pp_dpm_mclk")):
             try:
@@ -467,17 +470,21 @@ def main():
     for _ in range(args.warmup):
         encode()
     fence()
-    clocks = {"start": device_clocks(local)} if rank == 0 else None
+    # (the clocks are read while the steps of a region are queued on the device -- between regions it idles and
+    # the shader clock drops to ~100 MHz within microseconds; the read costs the host ~0.1 ms, the device nothing)
+    clocks = {} if rank == 0 else None
+    if rank == 0:
+        device_clocks(local)                      # (finds the sysfs files: outside the timed regions)
     region_s = []
-    for _ in range(args.regions):                 # every region: EXACTLY --steps steps between two fences
+    for reg in range(args.regions):               # every region: EXACTLY --steps steps between two fences
         fence()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             encode()
+        if rank == 0 and reg in (0, args.regions - 1):
+            clocks["first_region" if reg == 0 else "last_region"] = device_clocks(local)
         fence()
         region_s.append(max_over_ranks(time.perf_counter() - t0))
-    if rank == 0:
-        clocks["end"] = device_clocks(local)
     dt = float(np.median(region_s))
     # what the timed steps left behind is what gets checked (fence() waited for the engine's stream too)
     sz = sizes.cpu().numpy()
@@ -734,6 +741,24 @@ def main():
                     sj, torch, eng, g4k, 32, sj.YUV_420, 0, digests["recompress|r90|m0"], quant=c5q)
                 oc["C5 4K recompress r=90 default parameters x32"] = run_batch_config(
                     sj, torch, eng, g4k, 32, sj.YUV_420, 4, digests["recompress|r90|default"], quant=c5q)
+                # the two host-API kinds that are "correct, not fast" by DESIGN.md: trellis quantization (method 7)
+                # and the sharp-YUV conversion, ONE 1080p picture each, host memory to host memory (PCIe included)
+                from oracle import orc
+                o = orc.oracle()
+                p1080 = synth.g_struct(1920, 1080, 7654321)
+                for name, method, mode, omode in (("trellis (method 7) 1080p, host API", 7, sj.YUV_420, 1),
+                                                  ("sharp YUV (method 4) 1080p, host API", 4, sj.YUV_SHARP, 2)):
+                    got = sj.SjpegEncode(p1080, 75.0, method, mode)
+                    ts = []
+                    for _ in range(5):
+                        t0 = time.perf_counter()
+                        sj.SjpegEncode(p1080, 75.0, method, mode)
+                        ts.append(time.perf_counter() - t0)
+                    dt = float(np.median(ts))
+                    oc[name] = {"frames": 1, "width": 1920, "height": 1080, "method": method,
+                                "mpix_s": round(1920 * 1080 / dt / 1e6, 1), "ms_per_call": round(dt * 1e3, 3),
+                                "bytes_per_frame": len(got or b""),
+                                "bit_exact": bool(got is not None and got == o.encode_method(p1080, 75.0, omode, method))}
             except Exception as exc:
                 oc["error"] = repr(exc)
             res["other_configs"] = oc

@@ -550,7 +550,8 @@ struct OpenNodes {
 };
 
 // T.81 K.2 (Figure K.3): no code longer than `limit` bits.  count[l] = codes of length l + 1.
-void LimitCodeLengths(uint8_t* count, int longest, int limit) {
+// false: the histogram was no prefix code (see below) -- the caller falls back to a flat code.
+bool LimitCodeLengths(uint8_t* count, int longest, int limit) {
   for (int len = longest; len > limit; --len) {
     while (count[len - 1] > 0) {
       int shorter = len - 2;                  // a leaf at least two levels up becomes an inner node
@@ -558,13 +559,14 @@ void LimitCodeLengths(uint8_t* count, int longest, int limit) {
       // (only a histogram that is no prefix code any more gets here: depths beyond 32 bits were
       // clamped, which takes Fibonacci-like counts over 33+ symbols; the reference reads in front
       // of its array in that case, src/entropy.cc:396-398)
-      if (shorter < 1) return;
+      if (shorter < 1) return false;
       count[len - 1] -= 2;                    // a pair of deepest leaves: one moves up one level,
       count[len - 2] += 1;
       count[shorter - 1] -= 1;                // the other joins the split leaf one level below it
       count[shorter] += 2;
     }
   }
+  return true;
 }
 
 }  // namespace
@@ -628,9 +630,19 @@ void BuildOptimalSpec(const uint32_t* freq, int size, HuffSpec* out) {
   for (int sym = 0; sym < size; ++sym) {
     if (length_of[sym] > 0) out->syms[next_of[length_of[sym]]++] = static_cast<uint8_t>(sym);
   }
-  LimitCodeLengths(count, longest, kLimit);
+  if (!LimitCodeLengths(count, longest, kLimit)) {
+    // Depths beyond 32 bits were clamped and the histogram is no prefix code (Fibonacci-like counts over 33 or
+    // more symbols; the reference's behaviour is undefined there).  A VALID table instead of a wrong
+    // one: every leaf -- the reserved one included -- gets the same length, the symbols in the order of their values.
+    memset(count, 0, sizeof(count));
+    int flat = 1;
+    while ((1 << flat) < leaves) ++flat;      // <= 9 bits for 257 leaves
+    count[flat - 1] = static_cast<uint8_t>(leaves);
+    int k = 0;
+    for (int sym = 0; sym < size; ++sym) if (freq[sym] > 0) out->syms[k++] = static_cast<uint8_t>(sym);
+  }
   int last = kLimit;                          // the reserved leaf is the last code of the longest length
-  while (count[last - 1] == 0) --last;
+  while (last > 1 && count[last - 1] == 0) --last;
   --count[last - 1];
   for (int l = 0; l < kLimit; ++l) out->bits[l] = count[l];
 }

@@ -206,6 +206,27 @@ def test_optimal_huffman_ties_and_long_codes_match_oracle(oracle):
                 assert list(sp.syms[:n]) == [int(x) for x in syms][:n]
 
 
+def test_optimal_huffman_survives_counts_that_break_the_depth_clamp():
+    """Fibonacci-like counts over 40 symbols make a tree deeper than the 32 levels the builder keeps: the length
+    histogram is no prefix code any more and K.2's limiter cannot repair it (the reference is undefined there).
+    The table must still be a VALID one: every used symbol listed once, Kraft's sum at most 1 with the reserved
+    all-ones code, no length over 16 (the early return left codes of more than 16 bits behind)."""
+    f = np.zeros((2, 272), np.uint32)
+    a, b = 1, 2
+    for k in range(44):
+        f[:, k] = min(a, (1 << 32) - 1)
+        a, b = b, a + b
+    f[:, 256] = 1
+    t = sj.ScanTables()
+    specs = sj.optimize_huffman(f, 1, t)
+    for tbl in range(2):
+        sp = specs[2 + tbl]
+        bits = [int(x) for x in sp.bits]
+        assert sp.nsyms == 44 and sum(bits) == 44
+        assert sorted(sp.syms[:44]) == list(range(44))
+        assert sum((c + (1 if l == max(i for i, v in enumerate(bits) if v) else 0)) * 2.0 ** -(l + 1) for l, c in enumerate(bits)) <= 1.0 + 1e-12
+
+
 def test_shipped_riskiness_table_is_the_reference_table():
     """sjpeg_amd/csrc/riskiness.bin (reference DATA, shipped with attribution: riskiness.NOTICE) is the table
     of the reference build, where there is one; its digest is pinned either way."""
