@@ -20,7 +20,9 @@ ordered kernels, and `roofline.kernel_ms` the dominant kernel alone.
 Methodology: after W warm-up steps, `--regions` R (default 11) timed regions of
 EXACTLY K steps each, every one bracketed by barrier + device synchronise, the maximum over ranks taken
 per region; `ms_per_step` / `value` are the MEDIAN region, `ms_per_step_min` / `_max` the spread, and
-`clocks` the device's sclk / mclk read while the first and the last region run (boxes differ by a few per cent).
+`clocks`: the shader clock a wave measures right behind the first and the last region (cycle counter against the
+device's 100 MHz counter: sjpeg_hip_debug_shader_clock) and what sysfs reports for sclk / mclk while they run -- on
+these boxes the sysfs sclk lags and shows ~100 MHz, the measured figure is the one to read (boxes differ by a few per cent).
 
 Rank 0 prints ONE JSON line.
 * `roofline` prices the dominant kernel (scan_segments) against the HBM read roofline with
@@ -485,6 +487,16 @@ def main():
             clocks["first_region" if reg == 0 else "last_region"] = device_clocks(local)
         fence()
         region_s.append(max_over_ranks(time.perf_counter() - t0))
+        if rank == 0 and reg in (0, args.regions - 1):
+            # outside the timed region, right behind its last kernel: the shader clock as a wave measures it
+            # (the sysfs figure above lags and shows ~100 MHz whenever it samples an empty queue)
+            try:
+                import ctypes as C
+                mhz = C.c_float(0)
+                if sj.lib().sjpeg_hip_debug_shader_clock(C.byref(mhz), C.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0:
+                    clocks["shader_mhz_after_first_region" if reg == 0 else "shader_mhz_after_last_region"] = round(mhz.value, 1)
+            except Exception:
+                pass
     dt = float(np.median(region_s))
     # what the timed steps left behind is what gets checked (fence() waited for the engine's stream too)
     sz = sizes.cpu().numpy()

@@ -553,6 +553,9 @@ size_t sjpeg_hip_host_trim(void);
  * f32 instructions).  Synchronises on `stream`. */
 int sjpeg_hip_debug_stream_read(const void* d_buf, size_t bytes, uint32_t* d_sink, void* stream);
 int sjpeg_hip_debug_valu_rate(float cycles[2], void* stream);
+/* sjpeg_hip_debug_shader_clock: the shader clock in MHz as a wave on `stream` measures it (cycle counter against the
+ * device-wide 100 MHz counter over 20 us), i.e. the clock of the work that was just queued there.  Synchronises. */
+int sjpeg_hip_debug_shader_clock(float* mhz, void* stream);
 
 #ifdef __cplusplus
 }

@@ -254,7 +254,7 @@ EXPORTED_C_SYMBOLS = [
     "sjpeg_hip_segment_count", "sjpeg_hip_band_bound", "sjpeg_hip_encode_band_src", "sjpeg_hip_stitch_bands",
     "sjpeg_hip_engine_set_timing", "sjpeg_hip_engine_last_scan_ms",
     "sjpeg_hip_engine_last_total_ms", "sjpeg_hip_engine_scratch_bytes", "sjpeg_hip_compact_streams",
-    "sjpeg_hip_debug_stream_read", "sjpeg_hip_debug_valu_rate",
+    "sjpeg_hip_debug_stream_read", "sjpeg_hip_debug_valu_rate", "sjpeg_hip_debug_shader_clock",
     "sjpeg_hip_restart_interval", "sjpeg_hip_header_add_restart", "sjpeg_hip_encode_intervals_src",
     "sjpeg_hip_comm_unique_id", "sjpeg_hip_comm_create", "sjpeg_hip_comm_adopt", "sjpeg_hip_comm_destroy",
     "sjpeg_hip_comm_rank", "sjpeg_hip_comm_world", "sjpeg_hip_gather_rows", "sjpeg_hip_gather_bytes",

@@ -1416,6 +1416,36 @@ __global__ __launch_bounds__(256) void NAME(uint32_t a, uint32_t b, uint32_t* si
 SJPEG_VALU_RATE_KERNEL(valu_rate_kernel_slow, "v_perm_b32 %0, %0, %1, %2")
 SJPEG_VALU_RATE_KERNEL(valu_rate_kernel_fast, "v_add_u32 %0, %0, %1")
 
+// The shader clock as the shaders see it: a wave spins for `ticks` ticks of the device-wide 100 MHz counter and
+// counts the cycles of the shader-clock counter meanwhile.  Enqueued on the stream of the work it is to describe,
+// it runs right behind that work, before the clocks have come down (sysfs / rocm-smi show ~100 MHz the moment the
+// queue is empty, and lag behind when it is not).
+__global__ void clock_probe_kernel(unsigned long long* out, unsigned long long ticks) {
+  if (threadIdx.x != 0) return;
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime(), c0 = __builtin_readcyclecounter();
+  unsigned long long r1 = r0;
+  while (r1 - r0 < ticks) { __builtin_amdgcn_s_sleep(8); r1 = __builtin_amdgcn_s_memrealtime(); }
+  const unsigned long long c1 = __builtin_readcyclecounter();
+  out[0] = c1 - c0;
+  out[1] = r1 - r0;
+}
+
+int sjpeg_hip_debug_shader_clock(float* mhz, void* stream) {
+  if (mhz == nullptr) return SJPEG_HIP_EINVAL;
+  unsigned long long* d = nullptr;
+  unsigned long long h[2] = {0, 0};
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d), sizeof(h)));
+  const hipStream_t st = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, st, d, 2000ull);      // 20 us
+  const hipError_t e0 = hipGetLastError();
+  const hipError_t e1 = hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, st);
+  const hipError_t e2 = hipStreamSynchronize(st);
+  (void)hipFree(d);
+  if (e0 != hipSuccess || e1 != hipSuccess || e2 != hipSuccess || h[1] == 0) return SJPEG_HIP_ERUNTIME;
+  *mhz = static_cast<float>(static_cast<double>(h[0]) / static_cast<double>(h[1]) * 100.0);
+  return 0;
+}
+
 int sjpeg_hip_debug_valu_rate(float cycles[2], void* stream) {
   if (cycles == nullptr) return SJPEG_HIP_EINVAL;
   int dev = 0;
