@@ -382,6 +382,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=64, help="device-resident 4K frames per GPU per step")
     ap.add_argument("--input", choices=["struct", "noise"], default="struct")
+    ap.add_argument("--slot-bpp", type=float, default=0.75, help="bytes per pixel of every frame's output slot")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true")
     ap.add_argument("--exchange", action="store_true",
@@ -442,7 +443,9 @@ def main():
         frames[k] = torch.from_numpy(host[k % distinct]).cuda()
     tables, quant = sj.make_tables(quality=QUALITY)
     header = sj.make_header(W, H, sj.YUV_420, quant)
-    out_stride = ((W * H * 3) // 2 + len(header) + 4095) & ~4095       # 1.5 B/px slots
+    # output slots of --slot-bpp bytes per pixel (default 0.75: three times what the structured frames take, a quarter
+    # more than the noise frames); the engine's segment scratch follows the caller's slot size
+    out_stride = (int(W * H * args.slot_bpp) + len(header) + 4095) & ~4095
     nsets = 2 if exchange else 1                  # the exchange of step s overlaps the encode of step s + 1
     outs = [torch.empty((F, out_stride), dtype=torch.uint8, device="cuda") for _ in range(nsets)]
     sizes_b = [torch.zeros(F, dtype=torch.int64, device="cuda") for _ in range(nsets)]
