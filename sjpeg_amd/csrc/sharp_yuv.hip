@@ -5,16 +5,19 @@
 // resolution; up to four sweeps upsample the chroma (9:3:3:1), compare the result with the
 // gamma-correct targets and feed the differences back.  A sweep walks the row pairs top to bottom
 // and updates the chroma rows IN PLACE -- the row above a pair already belongs to this sweep, the
-// row below still to the previous one -- so the row pairs of one picture are inherently
-// sequential; the parallelism is across the width of a row pair (one workgroup per picture,
-// barriers between row pairs) and across the pictures of a batch.  The import and the final
-// conversion have no such dependency and run one thread per chroma sample.
+// row below still to the previous one -- so the row pairs of one sweep are inherently
+// sequential; the parallelism is across the width of a row pair (one workgroup per picture and sweep,
+// barriers between row pairs), across the SWEEPS of a picture (sharp_sweeps_piped: sweep t + 1 runs a few
+// row pairs behind sweep t in a workgroup of its own, on versioned planes instead of in place) and across
+// the pictures of a batch.  The import and the final conversion have no such dependency and run one
+// thread per chroma sample.
 //
 // Everything is integer arithmetic on the reference's fixed-point formats; the two gamma tables
 // are built on the host with libm's pow() exactly as the reference builds them (:114-152).
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -45,6 +48,12 @@ struct SharpArgs {
   uint16_t* best_y;  uint16_t* target_y;          // [nframes][h][w]
   int16_t* best_uv;  int16_t* target_uv;          // [nframes][uv_h][3][uv_w]
   int16_t* row_uv;                                // [nframes][3][uv_w]: chroma of the row pair in flight
+  // Pipelined sweeps (sharp_sweeps_piped): plane p of frame f of the W / chroma buffers is at
+  // best_y + (p * nframes + f) * w * h (plane 0 = what the import wrote = best_y itself), sweep t reads plane
+  // t % 3 and writes plane (t + 1) % 3; ctrl[f][32]: progress[4] (row pairs done), done[4], sum[4] (two words
+  // each), cancel, final sweep.  nplanes == 1: the in-place kernels, everything in plane 0.
+  uint32_t* ctrl;
+  int nframes, nplanes;
   uint8_t* y; uint8_t* u; uint8_t* v;
   long long y_frame_stride, uv_frame_stride;
   int stress;                                     // race stress builds only (SJPEG_HIP_ABLATE), else 0
@@ -412,12 +421,244 @@ __global__ __launch_bounds__(kSweepThreads) void sharp_sweeps_fast(const SharpAr
   }
 }
 
+// ---- the sweeps as a PIPELINE of workgroups (pictures up to 2 x 1024 chroma columns wide).  A sweep is sequential
+// down the picture, but sweep t + 1 needs of sweep t only the rows down to two below the row pair it is at: the four
+// sweeps of a picture run as four workgroups, each a few row pairs behind the one before.  No sweep updates in
+// place any more: sweep t reads plane t % 3 of the W / chroma buffers and writes plane (t + 1) % 3 (its own row
+// above travels through LDS as before).  Plane (t + 1) % 3 is also what sweep t - 2 read -- rows that sweep passed
+// four row pairs ago -- and what sweep t + 3 would write, which does not exist.  The reference stops after the first
+// sweep t >= 1 whose sum of |dW| is below a threshold or above its predecessor's (:660-666): here every sweep starts
+// speculatively, the first one that meets the condition names itself the final one and raises `cancel`, which the
+// later ones poll with their row dependencies; what they wrote by then lies in planes that are not the final
+// sweep's (it would take sweep s + 3 to overwrite the output of sweep s, and sweep 0 never stops).
+// Hand-over between workgroups: a counter of finished row pairs per sweep, released (agent scope) behind a full
+// barrier of the producer and acquired by every thread of the consumer behind its own barrier.
+// Grid (8, 4, ceil(nframes / 8)): frame = z * 8 + x, sweep = y -- a producer always has a smaller linear index than
+// its consumers (it is resident or done when they start spinning), and with the round-robin placement of
+// workgroups on the eight XCDs the four sweeps of a picture share one L2.
+__global__ __launch_bounds__(kSweepThreads) void sharp_sweeps_piped(const SharpArgs a) {
+  __shared__ uint32_t g2l[kMaxY + 1];
+  __shared__ uint32_t l2g[kGammaTab + 2];
+  __shared__ unsigned long long red[kSweepThreads / 64];
+  __shared__ int go;
+  __shared__ int16_t above[2][3][kFastCols * kSweepThreads];   // the updated row above, ping-pong
+  const int frame = blockIdx.z * 8 + blockIdx.x, t = blockIdx.y, tid = threadIdx.x;
+  if (frame >= a.nframes) return;
+  for (int i = tid; i <= kMaxY; i += kSweepThreads) g2l[i] = a.tab->g2l[i];
+  if (tid < kGammaTab + 2) l2g[tid] = a.tab->l2g[tid];
+  const int w = a.w, h = a.h, uv_w = a.uv_w, uv_h = a.uv_h;
+  const size_t ysz = static_cast<size_t>(w) * h, usz = static_cast<size_t>(uv_h) * 3 * uv_w;
+  const int pin = t % 3, pout = (t + 1) % 3;
+  const uint16_t* const in_y = a.best_y + (static_cast<size_t>(pin) * a.nframes + frame) * ysz;
+  uint16_t* const out_y = a.best_y + (static_cast<size_t>(pout) * a.nframes + frame) * ysz;
+  const int16_t* const in_uv = a.best_uv + (static_cast<size_t>(pin) * a.nframes + frame) * usz;
+  int16_t* const out_uv = a.best_uv + (static_cast<size_t>(pout) * a.nframes + frame) * usz;
+  const uint16_t* const target_y = a.target_y + static_cast<size_t>(frame) * ysz;
+  const int16_t* const target_uv = a.target_uv + static_cast<size_t>(frame) * usz;
+  uint32_t* const ctrl = a.ctrl + static_cast<size_t>(frame) * 32;
+  const unsigned long long threshold = static_cast<unsigned long long>(3.0 * w * h);
+
+  struct RowData {                                  // what one row pair needs from global memory, per column
+    int uv[3][3];                                   // chroma row: [channel][left, centre, right]
+    uint32_t wy[2], ty[2];                          // W and its target: two pixels per word, two rows
+    int tuv[3];                                     // chroma target
+  };
+  auto load_uv = [&](int row, int c, int (&dst)[3][3]) {
+    const int cl = c > 0 ? c - 1 : 0, cr = c < uv_w - 1 ? c + 1 : uv_w - 1;
+    const int16_t* r = in_uv + static_cast<size_t>(row) * 3 * uv_w;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { dst[k][0] = r[k * uv_w + cl]; dst[k][1] = r[k * uv_w + c]; dst[k][2] = r[k * uv_w + cr]; }
+  };
+  auto load_rest = [&](int ry, int c, RowData& d) {
+    const uint32_t* by0 = reinterpret_cast<const uint32_t*>(in_y + static_cast<size_t>(2 * ry) * w);
+    const uint32_t* by1 = reinterpret_cast<const uint32_t*>(in_y + static_cast<size_t>(2 * ry + 1) * w);
+    const uint32_t* ty0 = reinterpret_cast<const uint32_t*>(target_y + static_cast<size_t>(2 * ry) * w);
+    const uint32_t* ty1 = reinterpret_cast<const uint32_t*>(target_y + static_cast<size_t>(2 * ry + 1) * w);
+    d.wy[0] = by0[c]; d.wy[1] = by1[c]; d.ty[0] = ty0[c]; d.ty[1] = ty1[c];
+    const int16_t* tu = target_uv + static_cast<size_t>(ry) * 3 * uv_w;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) d.tuv[k] = tu[k * uv_w + c];
+  };
+  // Waits until the sweep before this one has finished `need` row pairs (all of them visible here), or a sweep
+  // before it has been named the final one.  Returns false in that case: this sweep's work is not wanted.
+  // A look at the other workgroup's counter is a round trip through the memory fabric (about as long as a row pair
+  // takes to compute), so it is not taken per row pair: the sweep waits until its producer is kAhead row pairs
+  // further than it needs and then runs that far on what it knows.
+  constexpr int kAhead = 16;
+  int known = t == 0 ? uv_h : 0;                    // row pairs of the producer known to be done (uniform)
+  auto wait_for = [&](int need) -> bool {
+    if (need > uv_h) need = uv_h;
+    if (known >= need) return true;
+    const int want = need + kAhead < uv_h ? need + kAhead : uv_h;
+    if (tid == 0) {
+      int seen = -1;
+      for (;;) {
+        if (__hip_atomic_load(&ctrl[16], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+        const int p = static_cast<int>(__hip_atomic_load(&ctrl[t - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT));
+        if (p >= want) { seen = p; break; }
+        __builtin_amdgcn_s_sleep(8);
+      }
+      go = seen;
+    }
+    __syncthreads();
+    const int g = go;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");     // every wave's loads behind this see the producer's rows
+    __syncthreads();                                // (`go` is rewritten by the next call)
+    if (g < 0) return false;
+    known = g;
+    return true;
+  };
+  SHARP_RACE_POINT(40);
+  __syncthreads();
+  if (tid == 0) ctrl[18 + 2 * t] = static_cast<uint32_t>(__builtin_amdgcn_s_memrealtime());   // (debug: SJPEG_HIP_SHARP_DEBUG)
+  unsigned long long diff = 0;
+  bool wanted = wait_for(2);                        // rows 0 and 1 of the input plane
+  if (wanted) {
+    RowData now[kFastCols], ahead[kFastCols];
+    int nxt[kFastCols][3][3];                       // chroma row ry + 1 (the sweep before's values)
+#pragma unroll
+    for (int s = 0; s < kFastCols; ++s) {
+      const int c = tid + s * kSweepThreads;
+      if (c < uv_w) {
+        load_uv(0, c, now[s].uv);
+        load_rest(0, c, now[s]);
+        load_uv(uv_h > 1 ? 1 : 0, c, nxt[s]);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) above[0][k][c] = static_cast<int16_t>(now[s].uv[k][1]);   // row pair 0: "above" is the row itself
+      }
+    }
+    SHARP_RACE_POINT(42);
+    __syncthreads();
+    for (int ry = 0; ry < uv_h; ++ry) {
+      const int pp = ry & 1;
+      SHARP_RACE_POINT(43);
+      // what the NEXT row pair needs: rows ry + 1 and ry + 2 of the input plane
+      if (ry + 1 < uv_h) {
+        wanted = wait_for(ry + 3);
+        if (!wanted) break;
+#pragma unroll
+        for (int s = 0; s < kFastCols; ++s) {
+          const int c = tid + s * kSweepThreads;
+          if (c < uv_w) {
+            load_rest(ry + 1, c, ahead[s]);
+            load_uv(ry + 2 < uv_h ? ry + 2 : ry + 1, c, ahead[s].uv);     // becomes `nxt` of the next step
+          }
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < kFastCols; ++s) {
+        const int c = tid + s * kSweepThreads;
+        if (c < uv_w) {
+          const int cl = c > 0 ? c - 1 : 0, cr = c < uv_w - 1 ? c + 1 : uv_w - 1;
+          const int wy[2][2] = {{static_cast<int>(now[s].wy[0] & 0xffffu), static_cast<int>(now[s].wy[0] >> 16)},
+                                {static_cast<int>(now[s].wy[1] & 0xffffu), static_cast<int>(now[s].wy[1] >> 16)}};
+          const int ty[2][2] = {{static_cast<int>(now[s].ty[0] & 0xffffu), static_cast<int>(now[s].ty[0] >> 16)},
+                                {static_cast<int>(now[s].ty[1] & 0xffffu), static_cast<int>(now[s].ty[1] >> 16)}};
+          int px[2][2][3];
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            const int A = now[s].uv[k][1], Al = now[s].uv[k][0], Ar = now[s].uv[k][2];
+            const int P = above[pp][k][c], Pl = above[pp][k][cl], Pr = above[pp][k][cr];
+            const bool has_next = ry + 1 < uv_h;                   // last row pair: next == cur
+            const int N = has_next ? nxt[s][k][1] : A, Nl = has_next ? nxt[s][k][0] : Al, Nr = has_next ? nxt[s][k][2] : Ar;
+            int up0, up1, dn0, dn1;
+            if (c == 0) { up0 = (A * 3 + P + 2) >> 2; dn0 = (A * 3 + N + 2) >> 2; }
+            else { up0 = (A * 9 + Al * 3 + P * 3 + Pl + 8) >> 4; dn0 = (A * 9 + Al * 3 + N * 3 + Nl + 8) >> 4; }
+            if (c == uv_w - 1) { up1 = (A * 3 + P + 2) >> 2; dn1 = (A * 3 + N + 2) >> 2; }
+            else { up1 = (A * 9 + Ar * 3 + P * 3 + Pr + 8) >> 4; dn1 = (A * 9 + Ar * 3 + N * 3 + Nr + 8) >> 4; }
+            px[0][0][k] = clip_y(wy[0][0] + up0); px[0][1][k] = clip_y(wy[0][1] + up1);
+            px[1][0][k] = clip_y(wy[1][0] + dn0); px[1][1][k] = clip_y(wy[1][1] + dn1);
+          }
+          int wt[2][2], uv[3];
+          eval_group(g2l, l2g, px, wt, uv);
+          uint32_t newy[2];
+#pragma unroll
+          for (int r = 0; r < 2; ++r) {
+            int ny[2];
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc) {
+              const int d = ty[r][cc] - wt[r][cc];
+              ny[cc] = clip_y(wy[r][cc] + d);
+              diff += static_cast<unsigned long long>(d < 0 ? -d : d);
+            }
+            newy[r] = static_cast<uint32_t>(ny[0]) | (static_cast<uint32_t>(ny[1]) << 16);
+          }
+          reinterpret_cast<uint32_t*>(out_y + static_cast<size_t>(2 * ry) * w)[c] = newy[0];
+          reinterpret_cast<uint32_t*>(out_y + static_cast<size_t>(2 * ry + 1) * w)[c] = newy[1];
+          // SharpUpdateRGB: the row becomes this sweep's; the neighbours of the next row pair read it from the
+          // other LDS buffer, the next sweep from this sweep's output plane
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            const int16_t nv = static_cast<int16_t>(now[s].uv[k][1] + (now[s].tuv[k] - uv[k]));
+            out_uv[static_cast<size_t>(ry) * 3 * uv_w + k * uv_w + c] = nv;
+            above[pp ^ 1][k][c] = nv;
+          }
+        }
+      }
+      SHARP_RACE_POINT(44);
+      __syncthreads();                              // (a full barrier: every thread's stores of this row pair are done)
+      SHARP_RACE_POINT(45);
+      if (tid == 0) {                               // hand the row pair to the next sweep
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __hip_atomic_store(&ctrl[t], static_cast<uint32_t>(ry + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      // rotate: cur <- next (old values), next <- the row requested above
+#pragma unroll
+      for (int s = 0; s < kFastCols; ++s) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+#pragma unroll
+          for (int q = 0; q < 3; ++q) { now[s].uv[k][q] = nxt[s][k][q]; nxt[s][k][q] = ahead[s].uv[k][q]; }
+          now[s].tuv[k] = ahead[s].tuv[k];
+        }
+        now[s].wy[0] = ahead[s].wy[0]; now[s].wy[1] = ahead[s].wy[1];
+        now[s].ty[0] = ahead[s].ty[0]; now[s].ty[1] = ahead[s].ty[1];
+      }
+    }
+  }
+  if (tid == 0) ctrl[19 + 2 * t] = static_cast<uint32_t>(__builtin_amdgcn_s_memrealtime());
+  if (!wanted) return;                              // (uniform: an earlier sweep is the final one)
+  // exit test (:660-666): sum of |dW| over the picture, against the sweep before
+  for (int d = 32; d > 0; d >>= 1) diff += __shfl_down(diff, d, 64);
+  if ((tid & 63) == 0) red[tid >> 6] = diff;
+  SHARP_RACE_POINT(46);
+  __syncthreads();
+  if (tid == 0) {
+    unsigned long long sum = 0;
+    for (int i = 0; i < kSweepThreads / 64; ++i) sum += red[i];
+    bool cancelled = false;
+    unsigned long long prev = ~0ull;
+    if (t > 0) {
+      // the sweep before has finished (its last row was waited for) -- but its verdict comes behind its rows
+      while (__hip_atomic_load(&ctrl[4 + t - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+        if (__hip_atomic_load(&ctrl[16], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+        __builtin_amdgcn_s_sleep(4);
+      }
+      cancelled = __hip_atomic_load(&ctrl[16], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+      prev = static_cast<unsigned long long>(ctrl[8 + 2 * (t - 1)]) | (static_cast<unsigned long long>(ctrl[9 + 2 * (t - 1)]) << 32);
+    }
+    if (!cancelled) {
+      const bool stop = t > 0 && (sum < threshold || sum > prev);
+      ctrl[8 + 2 * t] = static_cast<uint32_t>(sum);
+      ctrl[9 + 2 * t] = static_cast<uint32_t>(sum >> 32);
+      if (stop || t == 3) {
+        ctrl[17] = static_cast<uint32_t>(t);
+        __hip_atomic_store(&ctrl[16], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      __hip_atomic_store(&ctrl[4 + t], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
 // ---- back to 8-bit planes (:543-575; this file's own -11058 / -5328 constants)
 __global__ __launch_bounds__(256) void sharp_export(const SharpArgs a) {
   const int frame = blockIdx.z;
   const int c = blockIdx.x * 256 + threadIdx.x, ry = blockIdx.y;
   if (c >= a.uv_w) return;
-  const size_t uo = (static_cast<size_t>(frame) * a.uv_h + ry) * 3 * a.uv_w;
+  // (pipelined sweeps: the plane the last sweep that counts wrote)
+  const int plane = a.nplanes == 3 ? static_cast<int>((a.ctrl[frame * 32 + 17] + 1u) % 3u) : 0;
+  const size_t pf = static_cast<size_t>(plane) * a.nframes + frame;
+  const size_t uo = (pf * a.uv_h + ry) * 3 * a.uv_w;
   const int r = a.best_uv[uo + c], g = a.best_uv[uo + a.uv_w + c], b = a.best_uv[uo + 2 * a.uv_w + c];
   const int rnd = 1 << 18 >> 1;
   const int cw = (a.W + 1) >> 1;
@@ -427,7 +668,7 @@ __global__ __launch_bounds__(256) void sharp_export(const SharpArgs a) {
     up[c] = static_cast<uint8_t>(clip8(128 + ((-11058 * r - 21709 * g + 32768 * b + rnd) >> 18)));
     vp[c] = static_cast<uint8_t>(clip8(128 + ((32768 * r - 27439 * g - 5328 * b + rnd) >> 18)));
   }
-  const size_t yo = static_cast<size_t>(frame) * a.w * a.h;
+  const size_t yo = pf * a.w * a.h;
 #pragma unroll
   for (int rr = 0; rr < 2; ++rr) {
 #pragma unroll
@@ -512,7 +753,9 @@ extern "C" {
 size_t sjpeg_hip_sharp_workspace(int width, int height, int nframes) {
   if (width <= 0 || height <= 0 || width > 65535 || height > 65535 || nframes <= 0) return 0;
   const size_t w = (static_cast<size_t>(width) + 1) & ~size_t(1), h = (static_cast<size_t>(height) + 1) & ~size_t(1);
-  const size_t per = 2 * align256(w * h * 2) + 2 * align256(3 * (w / 2) * (h / 2) * 2) + align256(3 * (w / 2) * 2);
+  // (three planes of W and chroma for the pipelined sweeps + the two target arrays, the side row of the in-place
+  // kernel, the sweeps' control words)
+  const size_t per = 4 * align256(w * h * 2) + 4 * align256(3 * (w / 2) * (h / 2) * 2) + align256(3 * (w / 2) * 2) + 256;
   return align256(sizeof(GammaTables)) + per * static_cast<size_t>(nframes);
 }
 
@@ -555,16 +798,33 @@ int sjpeg_hip_sharp_yuv(const sjpeg_hip_source* src, int width, int height, int 
   p += align256(sizeof(GammaTables));
   const size_t ysz = align256(static_cast<size_t>(a.w) * a.h * 2) , usz = align256(static_cast<size_t>(3) * a.uv_w * a.uv_h * 2);
   // per-frame arrays are addressed as [frame][...] with the un-padded sizes: keep them contiguous
-  a.best_y = reinterpret_cast<uint16_t*>(p); p += ysz * nframes;
+  // (plane p of frame f: base + (p * nframes + f) * elements of a frame; the in-place kernels use plane 0 only)
+  a.nframes = nframes;
+  a.best_y = reinterpret_cast<uint16_t*>(p); p += 3 * ysz * nframes;
   a.target_y = reinterpret_cast<uint16_t*>(p); p += ysz * nframes;
-  a.best_uv = reinterpret_cast<int16_t*>(p); p += usz * nframes;
+  a.best_uv = reinterpret_cast<int16_t*>(p); p += 3 * usz * nframes;
   a.target_uv = reinterpret_cast<int16_t*>(p); p += usz * nframes;
-  a.row_uv = reinterpret_cast<int16_t*>(p);
+  a.row_uv = reinterpret_cast<int16_t*>(p); p += align256(static_cast<size_t>(3) * a.uv_w * 2) * nframes;
+  a.ctrl = reinterpret_cast<uint32_t*>(p);
   const dim3 grid((a.uv_w + 255) / 256, a.uv_h, nframes);
+  // SJPEG_HIP_SHARP_INPLACE=1: round 3's one-workgroup-per-picture sweeps (A/B, and the fallback for very wide pictures)
+  static const bool inplace = getenv("SJPEG_HIP_SHARP_INPLACE") != nullptr && atoi(getenv("SJPEG_HIP_SHARP_INPLACE")) != 0;
+  const bool piped = !inplace && a.uv_w <= kFastCols * kSweepThreads;
+  a.nplanes = piped ? 3 : 1;
+  if (piped && hipMemsetAsync(a.ctrl, 0, static_cast<size_t>(nframes) * 32 * sizeof(uint32_t), st) != hipSuccess) return SJPEG_HIP_ERUNTIME;
   hipLaunchKernelGGL(sharp_import, grid, dim3(256), 0, st, a);
-  if (a.uv_w <= kFastCols * kSweepThreads) hipLaunchKernelGGL(sharp_sweeps_fast, dim3(nframes), dim3(kSweepThreads), 0, st, a);
+  if (piped) hipLaunchKernelGGL(sharp_sweeps_piped, dim3(8, 4, (nframes + 7) / 8), dim3(kSweepThreads), 0, st, a);
+  else if (a.uv_w <= kFastCols * kSweepThreads) hipLaunchKernelGGL(sharp_sweeps_fast, dim3(nframes), dim3(kSweepThreads), 0, st, a);
   else hipLaunchKernelGGL(sharp_sweeps, dim3(nframes), dim3(kSweepThreads), 0, st, a);
   hipLaunchKernelGGL(sharp_export, grid, dim3(256), 0, st, a);
+  if (piped && getenv("SJPEG_HIP_SHARP_DEBUG") != nullptr) {        // when the four sweeps of frame 0 ran (10 ns ticks), who was final
+    uint32_t c[32];
+    if (hipMemcpyAsync(c, a.ctrl, sizeof(c), hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess) {
+      fprintf(stderr, "sharp sweeps: final %u, rows done %u %u %u %u of %d;", c[17], c[0], c[1], c[2], c[3], a.uv_h);
+      for (int t = 0; t < 4; ++t) fprintf(stderr, " [%d] %.1f..%.1f us", t, (c[18 + 2 * t] - c[18]) / 100.0, (c[19 + 2 * t] - c[18]) / 100.0);
+      fprintf(stderr, "\n");
+    }
+  }
   return hipGetLastError() == hipSuccess ? 0 : SJPEG_HIP_ERUNTIME;
 }
 

@@ -819,6 +819,29 @@ def test_sharp_yuv_batch_and_bgra_planes(oracle):
                 np.array_equal(v4[k].cpu().numpy(), wv), (w, h, k, "bgra")
 
 
+def test_sharp_sweeps_as_a_pipeline_of_workgroups(oracle):
+    """The four sweeps of a picture run as four workgroups a few row pairs apart (sharp_yuv.hip, round 4), each a
+    speculation on its predecessors not being the last: pictures that stop after the second sweep, after a later one,
+    and never (saturated noise), short pictures (fewer row pairs than the pipeline is deep), batches that span more
+    than one group of eight frames, repeated calls on one workspace."""
+    rng = np.random.RandomState(44)
+    def sat(h, w):
+        return (rng.randint(0, 2, (h, w, 3)) * 255).astype(np.uint8)
+    for (w, h, n) in ((96, 80, 19), (640, 6, 3), (33, 180, 9), (512, 300, 2)):
+        imgs = []
+        for k in range(n):
+            kind = k % 4
+            imgs.append(synth.g_struct(w, h, 60 + k) if kind == 0 else rng.randint(0, 256, (h, w, 3)).astype(np.uint8) if kind == 1
+                        else sat(h, w) if kind == 2 else np.full((h, w, 3), 40 + 9 * k, np.uint8))
+        batch = torch.from_numpy(np.stack(imgs).reshape(n, h, 3 * w)).cuda()
+        want = [oracle.sharp_yuv(im) for im in imgs]
+        for rep in range(3):
+            y, u, v = sj.sharp_yuv(sj.SRC_RGB, batch)
+            for k in range(n):
+                assert np.array_equal(y[k].cpu().numpy(), want[k][0]) and np.array_equal(u[k].cpu().numpy(), want[k][1]) and \
+                    np.array_equal(v[k].cpu().numpy(), want[k][2]), (w, h, k, rep)
+
+
 def test_adaptive_analysis_on_device_equals_host(engine):
     """AnalyseHisto's bin loops on the GPU (sjpeg_hip_adapt_sums) + the float half on the host ==
     the all-host analysis (which the CPU tests pin against the oracle), incl. min-quant limits."""
