@@ -436,12 +436,14 @@ __global__ __launch_bounds__(kSweepThreads) void sharp_sweeps_fast(const SharpAr
 // Grid (8, 4, ceil(nframes / 8)): frame = z * 8 + x, sweep = y -- a producer always has a smaller linear index than
 // its consumers (it is resident or done when they start spinning), and with the round-robin placement of
 // workgroups on the eight XCDs the four sweeps of a picture share one L2.
+// COLS: chroma columns per thread -- 1 for pictures up to 2048 pixels wide (half the registers: no spills), else 2
+template <int COLS>
 __global__ __launch_bounds__(kSweepThreads) void sharp_sweeps_piped(const SharpArgs a) {
   __shared__ uint32_t g2l[kMaxY + 1];
   __shared__ uint32_t l2g[kGammaTab + 2];
   __shared__ unsigned long long red[kSweepThreads / 64];
   __shared__ int go;
-  __shared__ int16_t above[2][3][kFastCols * kSweepThreads];   // the updated row above, ping-pong
+  __shared__ int16_t above[2][3][COLS * kSweepThreads];   // the updated row above, ping-pong
   const int frame = blockIdx.z * 8 + blockIdx.x, t = blockIdx.y, tid = threadIdx.x;
   if (frame >= a.nframes) return;
   for (int i = tid; i <= kMaxY; i += kSweepThreads) g2l[i] = a.tab->g2l[i];
@@ -514,10 +516,10 @@ __global__ __launch_bounds__(kSweepThreads) void sharp_sweeps_piped(const SharpA
   unsigned long long diff = 0;
   bool wanted = wait_for(2);                        // rows 0 and 1 of the input plane
   if (wanted) {
-    RowData now[kFastCols], ahead[kFastCols];
-    int nxt[kFastCols][3][3];                       // chroma row ry + 1 (the sweep before's values)
+    RowData now[COLS], ahead[COLS];
+    int nxt[COLS][3][3];                       // chroma row ry + 1 (the sweep before's values)
 #pragma unroll
-    for (int s = 0; s < kFastCols; ++s) {
+    for (int s = 0; s < COLS; ++s) {
       const int c = tid + s * kSweepThreads;
       if (c < uv_w) {
         load_uv(0, c, now[s].uv);
@@ -537,7 +539,7 @@ __global__ __launch_bounds__(kSweepThreads) void sharp_sweeps_piped(const SharpA
         wanted = wait_for(ry + 3);
         if (!wanted) break;
 #pragma unroll
-        for (int s = 0; s < kFastCols; ++s) {
+        for (int s = 0; s < COLS; ++s) {
           const int c = tid + s * kSweepThreads;
           if (c < uv_w) {
             load_rest(ry + 1, c, ahead[s]);
@@ -546,7 +548,7 @@ __global__ __launch_bounds__(kSweepThreads) void sharp_sweeps_piped(const SharpA
         }
       }
 #pragma unroll
-      for (int s = 0; s < kFastCols; ++s) {
+      for (int s = 0; s < COLS; ++s) {
         const int c = tid + s * kSweepThreads;
         if (c < uv_w) {
           const int cl = c > 0 ? c - 1 : 0, cr = c < uv_w - 1 ? c + 1 : uv_w - 1;
@@ -596,15 +598,19 @@ __global__ __launch_bounds__(kSweepThreads) void sharp_sweeps_piped(const SharpA
         }
       }
       SHARP_RACE_POINT(44);
-      __syncthreads();                              // (a full barrier: every thread's stores of this row pair are done)
+      // Row pairs are handed to the next sweep eight at a time: a hand-over needs every thread's stores to be DONE (a
+      // full barrier: it waits for the memory counter, i.e. a store's round trip, about as long as the row pair's
+      // arithmetic), the seven steps between only order the LDS row above and leave stores and loads in flight.
+      const bool hand_over = (ry & 7) == 7 || ry + 1 == uv_h;
+      if (hand_over) __syncthreads(); else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
       SHARP_RACE_POINT(45);
-      if (tid == 0) {                               // hand the row pair to the next sweep
+      if (hand_over && tid == 0) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         __hip_atomic_store(&ctrl[t], static_cast<uint32_t>(ry + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
       }
       // rotate: cur <- next (old values), next <- the row requested above
 #pragma unroll
-      for (int s = 0; s < kFastCols; ++s) {
+      for (int s = 0; s < COLS; ++s) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
 #pragma unroll
@@ -813,7 +819,8 @@ int sjpeg_hip_sharp_yuv(const sjpeg_hip_source* src, int width, int height, int 
   a.nplanes = piped ? 3 : 1;
   if (piped && hipMemsetAsync(a.ctrl, 0, static_cast<size_t>(nframes) * 32 * sizeof(uint32_t), st) != hipSuccess) return SJPEG_HIP_ERUNTIME;
   hipLaunchKernelGGL(sharp_import, grid, dim3(256), 0, st, a);
-  if (piped) hipLaunchKernelGGL(sharp_sweeps_piped, dim3(8, 4, (nframes + 7) / 8), dim3(kSweepThreads), 0, st, a);
+  if (piped && a.uv_w <= kSweepThreads) hipLaunchKernelGGL(sharp_sweeps_piped<1>, dim3(8, 4, (nframes + 7) / 8), dim3(kSweepThreads), 0, st, a);
+  else if (piped) hipLaunchKernelGGL(sharp_sweeps_piped<2>, dim3(8, 4, (nframes + 7) / 8), dim3(kSweepThreads), 0, st, a);
   else if (a.uv_w <= kFastCols * kSweepThreads) hipLaunchKernelGGL(sharp_sweeps_fast, dim3(nframes), dim3(kSweepThreads), 0, st, a);
   else hipLaunchKernelGGL(sharp_sweeps, dim3(nframes), dim3(kSweepThreads), 0, st, a);
   hipLaunchKernelGGL(sharp_export, grid, dim3(256), 0, st, a);
