@@ -20,7 +20,8 @@ ordered kernels, and `roofline.kernel_ms` the dominant kernel alone.
 Methodology: after W warm-up steps, `--regions` R (default 11) timed regions of
 EXACTLY K steps each, every one bracketed by barrier + device synchronise, the maximum over ranks taken
 per region; `ms_per_step` / `value` are the MEDIAN region, `ms_per_step_min` / `_max` the spread, and
-`clocks`: the shader clock a wave measures right behind the first and the last region (cycle counter against the
+`clocks`: the shader clock a probe wave measures WHILE the last region runs (`shader_mhz_under_load`: the chip clocks
+down under this kernel's sustained VALU load) and right behind the first and the last region (cycle counter against the
 device's 100 MHz counter: sjpeg_hip_debug_shader_clock) and what sysfs reports for sclk / mclk while they run -- on
 these boxes the sysfs sclk lags and shows ~100 MHz, the measured figure is the one to read (boxes differ by a few per cent).
 
@@ -478,6 +479,7 @@ def main():
     # (the clocks are read while the steps of a region are queued on the device -- between regions it idles and
     # the shader clock drops to ~100 MHz within microseconds; the read costs the host ~0.1 ms, the device nothing)
     clocks = {} if rank == 0 else None
+    probe_stream = torch.cuda.Stream() if rank == 0 else None
     if rank == 0:
         device_clocks(local)                      # (finds the sysfs files: outside the timed regions)
     region_s = []
@@ -488,6 +490,17 @@ def main():
             encode()
         if rank == 0 and reg in (0, args.regions - 1):
             clocks["first_region" if reg == 0 else "last_region"] = device_clocks(local)
+        if rank == 0 and reg == args.regions - 1:
+            # the shader clock UNDER this load: a probe wave on a side stream while the region's steps are queued and
+            # running (K1 leaves half of a CU's wave slots free); 20 us of one wave, the host waits for it only
+            try:
+                import ctypes as C
+                mhz = C.c_float(0)
+                with torch.cuda.stream(probe_stream):
+                    if sj.lib().sjpeg_hip_debug_shader_clock(C.byref(mhz), C.c_void_p(probe_stream.cuda_stream)) == 0:
+                        clocks["shader_mhz_under_load"] = round(mhz.value, 1)
+            except Exception:
+                pass
         fence()
         region_s.append(max_over_ranks(time.perf_counter() - t0))
         if rank == 0 and reg in (0, args.regions - 1):
