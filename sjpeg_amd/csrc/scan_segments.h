@@ -1036,19 +1036,25 @@ __global__ __launch_bounds__(kScanThreads, ((KINDX == kKindHisto && SRC == kSrcR
   // the waves in boustrophedon order instead (0 1 2 3 / 7 6 5 4 / ...), which is static: a thread
   // knows its (up to) four parts at once and fetches their list entries and block tails together,
   // instead of one dependent chain of LDS round trips in front of every walk.
-  uint32_t un[4], pws[4], dws[4];
+  // (rounds: 256 parts each; the ordinary segment has two -- the rounds behind the last are skipped by everybody)
+  const int nrounds = static_cast<int>((n_units + 255u) >> 8);           // uniform
+  uint32_t un[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu}, pws[4] = {0, 0, 0, 0}, dws[4] = {0, 0, 0, 0};
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const uint32_t grp = static_cast<uint32_t>(4 * r) + ((r & 1) ? 3u - (tid >> 6) : (tid >> 6));
-    const uint32_t idx = grp * 64u + (tid & 63u);
-    un[r] = idx < n_units ? ulist[idx] : 0xffffffffu;
+    if (r < nrounds) {
+      const uint32_t grp = static_cast<uint32_t>(4 * r) + ((r & 1) ? 3u - (tid >> 6) : (tid >> 6));
+      const uint32_t idx = grp * 64u + (tid & 63u);
+      un[r] = idx < n_units ? ulist[idx] : 0xffffffffu;
+    }
   }
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    // (no part: some word inside the kernel's LDS is read and not used)
-    const uint32_t blk = un[r] & 255u, q = (un[r] >> 8) & 3u;
-    pws[r] = *reinterpret_cast<const u32_alias*>(smem + blk * kSlotBytes + 128u + 4u * q);
-    dws[r] = dcw[blk];
+    if (r < nrounds) {
+      // (no part: some word inside the kernel's LDS is read and not used)
+      const uint32_t blk = un[r] & 255u, q = (un[r] >> 8) & 3u;
+      pws[r] = *reinterpret_cast<const u32_alias*>(smem + blk * kSlotBytes + 128u + 4u * q);
+      dws[r] = dcw[blk];
+    }
   }
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
@@ -1187,7 +1193,7 @@ __global__ __launch_bounds__(kScanThreads, ((KINDX == kKindHisto && SRC == kSrcR
   if (nw_seg <= static_cast<uint32_t>(kWinWords)) {
     // the usual case: the segment fits the window (cleared above)
 #pragma unroll 1
-    for (int r = 0; r < 4; ++r) {                  // (NOT unrolled: four inlined copies of place() had the compiler
+    for (int r = 0; r < nrounds; ++r) {            // (NOT unrolled: four inlined copies of place() had the compiler
       const uint32_t rec = ur_get(r);              // hoist ~250 instructions of address arithmetic in front of them)
       if (rec != 0xffffffffu) place(std::false_type(), rec, part_start(rec), tw_get(r), 0u);
     }
@@ -1212,7 +1218,7 @@ __global__ __launch_bounds__(kScanThreads, ((KINDX == kKindHisto && SRC == kSrcR
       }
       const uint32_t lo = base_w << 5, hi = (base_w + static_cast<uint32_t>(kWinWords)) << 5;   // the window's bits
 #pragma unroll 1
-      for (int r = 0; r < 4; ++r) {
+      for (int r = 0; r < nrounds; ++r) {
         const uint32_t rec = ur_get(r);
         if (rec != 0xffffffffu) {
           const uint32_t st = part_start(rec);
