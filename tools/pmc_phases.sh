@@ -1,6 +1,6 @@
 #!/bin/bash
 # VALU / SALU / LDS instructions and wave cycles of K1 per ablation level (GPU box).
-#   tools/pmc_phases.sh TAG "1 2 3 0" [lib.so]
+#   tools/pmc_phases.sh TAG "1 2 3 0" [lib.so]      (PHASE_CMD="python tools/profile_workload.py c3x4 3": another workload)
 set -u
 export TMPDIR=/tmp
 TAG=$1; LEVELS=$2
@@ -10,7 +10,7 @@ mkdir -p $OUT
 ROOT=$PWD
 cd /tmp
 for A in $LEVELS; do
-  SJPEG_HIP_ABLATE=$A rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_INSTS_VMEM_WR -d $OUT/a$A -o pmc -- python $ROOT/bench.py --steps 3 --warmup 1 --regions 1 --timed-only ${BENCH_EXTRA:-} > $OUT/a$A.log 2>&1
+  SJPEG_HIP_ABLATE=$A rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_INSTS_VMEM_WR -d $OUT/a$A -o pmc -- ${PHASE_CMD:-python $ROOT/bench.py --steps 3 --warmup 1 --regions 1 --timed-only ${BENCH_EXTRA:-}} > $OUT/a$A.log 2>&1
 done
 python - <<PY
 import csv, glob, collections, os
