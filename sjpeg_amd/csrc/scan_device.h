@@ -380,14 +380,11 @@ __device__ constexpr int kInvZig(int j) {
 // non-zero flags into the zig-zag-ordered 64-bit mask.
 //   level = ((|c| + bias) * iquant) >> 20 == (|c|*iquant + bias*iquant) >> 20
 // The reference's qthresh test is implied: |c| >= qthresh <=> level > 0 (quantize.cc:144-145).
-template <int ROW, int C1, int C2, int C3, int C4, int C5, int C6, int C7>
-__device__ __forceinline__ void row_quant(const uint32_t* row, const uint4* qt, uint32_t* ent, uint32_t* nzq) {
-  int acc[8];
-  fdct_row8_pk<C1, C2, C3, C4, C5, C6, C7>(row, acc);
+template <int ROW>
+__device__ __forceinline__ void quant_row(const uint32_t* cps, const uint4* qt, uint32_t* ent, uint32_t* nzq) {
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    const uint32_t cp = __builtin_amdgcn_perm(static_cast<uint32_t>(acc[2 * k + 1]),
-                                              static_cast<uint32_t>(acc[2 * k]), 0x07060302u);
+    const uint32_t cp = cps[k];                   // coefficients 2k, 2k + 1 of the row as an int16 pair
     const s16x2 c = as_pk(cp);
     const uint32_t ap = as_u32(__builtin_elementwise_max(c, pk_const(0, 0) - c));
     const uint4 t = qt[4 * ROW + k];
@@ -407,6 +404,17 @@ __device__ __forceinline__ void row_quant(const uint32_t* row, const uint4* qt, 
       nzq[z1 >> 4] = mad_u16_hi_k(f, 1u << (z1 & 15), nzq[z1 >> 4]);
     }
   }
+}
+template <int ROW, int C1, int C2, int C3, int C4, int C5, int C6, int C7>
+__device__ __forceinline__ void row_quant(const uint32_t* row, const uint4* qt, uint32_t* ent, uint32_t* nzq) {
+  int acc[8];
+  fdct_row8_pk<C1, C2, C3, C4, C5, C6, C7>(row, acc);
+  uint32_t cps[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    cps[k] = __builtin_amdgcn_perm(static_cast<uint32_t>(acc[2 * k + 1]), static_cast<uint32_t>(acc[2 * k]), 0x07060302u);
+  }
+  quant_row<ROW>(cps, qt, ent, nzq);
 }
 
 // One row, transform only: the raw coefficients (int16 pairs, natural order) for the trellis.

@@ -39,6 +39,7 @@
 #include <new>
 #include <type_traits>
 #include <string>
+#include <chrono>
 #include <vector>
 
 #include "sjpeg_hip.h"
@@ -126,6 +127,10 @@ struct sjpeg_hip_engine {
   // A batch coded in parts (sjpeg_hip_encode_batch_src): the statistics / replay calls of a part address the
   // kept blocks of frames [replay_first, replay_first + nframes) of a buffer for replay_total frames.
   int replay_first = 0, replay_total = 0;
+  // ... and when the call runs a histogram pass in front of its statistics pass (the adaptive methods with
+  // optimized Huffman tables), the histogram pass leaves every block's DCT coefficients in `replay` and the
+  // statistics pass starts from them (kKindStatsCoef): set by sjpeg_hip_encode_batch_src for the length of the call
+  bool coefs_keep = false, coefs_use = false;
   // ... and their per-workgroup partial statistics likewise live in a buffer for replay_total frames, summed on
   // `reduce_stream` (behind an event) instead of the call's stream: the sums of one part run under the device
   // pass of the next
@@ -615,7 +620,14 @@ static int scan_statistics(sjpeg_hip_engine* e, const sjpeg_hip_source* src, int
   if ((rc = e->partial.ensure(static_cast<size_t>(part_total) * g.nseg * words))) return rc;
   uint32_t* const partial = e->partial.p + static_cast<size_t>(part_first) * g.nseg * words;
   a.partial = partial;
-  if (!histogram && (tables->flags & SJPEG_HIP_QUANT_KEEP)) {
+  const bool coefs_in = !histogram && e->coefs_use && (tables->flags & SJPEG_HIP_QUANT_KEEP) && !(tables->flags & SJPEG_HIP_QUANT_TRELLIS);
+  if (coefs_in) {
+    const int total = e->replay_total > 0 ? e->replay_total : nframes;
+    if (e->replay.p == nullptr || e->replay_w != width || e->replay_h != height || e->replay_mode != yuv_mode || e->replay_nframes != total) {
+      return fail(SJPEG_HIP_EINVAL, "no histogram pass of these frames left its coefficients behind");
+    }
+  }
+  if ((!histogram && (tables->flags & SJPEG_HIP_QUANT_KEEP)) || (histogram && e->coefs_keep)) {
     const size_t per_frame = static_cast<size_t>(g.nseg) * kScanThreads * 36;
     const int total = e->replay_total > 0 ? e->replay_total : nframes;
     const int first = e->replay_total > 0 ? e->replay_first : 0;
@@ -626,6 +638,7 @@ static int scan_statistics(sjpeg_hip_engine* e, const sjpeg_hip_source* src, int
   }
   if (histogram) rc = launch_scan<kKindHisto>(yuv_mode, cls, dim3(g.nseg, nframes), st, a);
   else if (tables != nullptr && (tables->flags & SJPEG_HIP_QUANT_TRELLIS)) rc = launch_scan<kKindStatsTrellis>(yuv_mode, cls, dim3(g.nseg, nframes), st, a);
+  else if (coefs_in) rc = launch_scan_src<kKindStatsCoef, kSrcRgb24>(yuv_mode, dim3(g.nseg, nframes), st, a);   // (reads no pixel)
   else rc = launch_scan<kKindStats>(yuv_mode, cls, dim3(g.nseg, nframes), st, a);
   if (rc) return rc;
   // Slices of the segments meet in the output with device-scope atomics, and those are what the summing
@@ -1177,7 +1190,7 @@ int sjpeg_hip_encode_batch_src(sjpeg_hip_engine* engine, const sjpeg_hip_source*
   if (method > 6) return fail(SJPEG_HIP_EINVAL, "sjpeg_hip_encode_batch_src: methods 0..6 (trellis goes through the host API)");
   struct PartsGuard {                              // the engine addresses whole calls again when this returns
     sjpeg_hip_engine* e;
-    ~PartsGuard() { e->replay_first = 0; e->replay_total = 0; e->reduce_stream = nullptr; e->reduce_ev = nullptr; }
+    ~PartsGuard() { e->replay_first = 0; e->replay_total = 0; e->reduce_stream = nullptr; e->reduce_ev = nullptr; e->coefs_keep = e->coefs_use = false; }
   } parts_guard{engine};
   try {
     const bool adaptive = method >= 3, optimize = (method != 0) && (method != 3);
@@ -1238,6 +1251,8 @@ int sjpeg_hip_encode_batch_src(sjpeg_hip_engine* engine, const sjpeg_hip_source*
       engine->replay_total = nframes;
       rs = sc.side;
     }
+    static const bool no_coefs = getenv("SJPEG_HIP_NO_COEF_KEEP") != nullptr;       // (A/B: every pass from the pixels)
+    engine->coefs_keep = adaptive && optimize && !no_coefs;
     if (adaptive) {
       int64_t* const d_sums = static_cast<int64_t*>(sc.d_sums);
       int32_t* const d_tot = reinterpret_cast<int32_t*>(static_cast<uint8_t*>(sc.d_sums) + n * kSums);
@@ -1257,12 +1272,22 @@ int sjpeg_hip_encode_batch_src(sjpeg_hip_engine* engine, const sjpeg_hip_source*
         HIP_TRY(hipEventRecord(sc.ev[p], rs));
       }
     }
+    static const bool batch_debug = getenv("SJPEG_HIP_BATCH_DEBUG") != nullptr;      // (measurement aid: host timeline on stderr)
+    const auto t_start = std::chrono::steady_clock::now();
+    auto mark = [&](const char* what, int p) {
+      static const auto t_epoch = std::chrono::steady_clock::now();
+      if (batch_debug) fprintf(stderr, "batch %-18s part %d  %8.1f us  (abs %10.1f)\n", what, p, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_start).count(),
+                               std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_epoch).count());
+    };
+    mark("hist launched", -1);
     std::vector<sjpeg_hip_huffman_spec> specs(optimize ? n * 4 : 0);
     // (part p's regression runs while the device works on the histogram of part p + 1 / the statistics of part p - 1)
     for (int p = 0; p < nparts; ++p) {
       const size_t f0 = part_lo[p], nf = part_lo[p + 1] - f0;
       if (adaptive) {
+        mark("wait sums", p);
         HIP_TRY(hipEventSynchronize(sc.ev[p]));
+        mark("sums here", p);
         for (size_t f = f0; f < f0 + nf; ++f) {
           sjpeg_hip_adapt_quant_sums(reinterpret_cast<const int64_t*>(h_sums + f * kSums),
                                      reinterpret_cast<const int32_t*>(h_sums + n * kSums + f * kTot), yuv_mode,
@@ -1270,18 +1295,21 @@ int sjpeg_hip_encode_batch_src(sjpeg_hip_engine* engine, const sjpeg_hip_source*
                                      qdelta_max_luma, qdelta_max_chroma, &tables[f]);
         }
       }
+      mark("adapted", p);
       if (optimize) {
         // the statistics pass leaves its quantized blocks behind (144 B each) and the encode pass
         // replays them: no second colour conversion / DCT / quantization (the reference's stored
         // run/levels, src/enc.cc:121-129,374-386)
         for (size_t f = f0; f < f0 + nf; ++f) tables[f].flags |= SJPEG_HIP_QUANT_KEEP;
         engine->replay_total = nframes; engine->replay_first = static_cast<int>(f0);
+        engine->coefs_use = engine->coefs_keep;
         const sjpeg_hip_source ps = part_source(f0);
         uint32_t* const d_freq = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(sc.d_freq) + f0 * kFreq);
         const int rc = sjpeg_hip_scan_symbol_stats_multi(engine, &ps, width, height, yuv_mode, static_cast<int>(nf), &tables[f0], d_freq, stream);
         if (rc != 0) return rc;
         HIP_TRY(hipMemcpyAsync(h_freq + f0 * kFreq, d_freq, nf * kFreq, hipMemcpyDeviceToHost, rs));
         HIP_TRY(hipEventRecord(sc.ev[kMaxParts + p], rs));
+        mark("stats launched", p);
       }
     }
     // (part p's table builder runs while the device counts the symbols of part p + 1 / codes part p - 1)
@@ -1290,13 +1318,16 @@ int sjpeg_hip_encode_batch_src(sjpeg_hip_engine* engine, const sjpeg_hip_source*
     for (int p = 0; p < nparts; ++p) {
       const size_t f0 = part_lo[p], nf = part_lo[p + 1] - f0;
       if (optimize) {
+        mark("wait freq", p);
         HIP_TRY(hipEventSynchronize(sc.ev[kMaxParts + p]));
+        mark("freq here", p);
         for (size_t f = f0; f < f0 + nf; ++f) {
           tables[f].flags = (tables[f].flags & ~SJPEG_HIP_QUANT_KEEP) | SJPEG_HIP_QUANT_REPLAY;
           sjpeg_hip_optimize_huffman(reinterpret_cast<const uint32_t*>(h_freq + f * kFreq), yuv_mode, &specs[f * 4], &tables[f]);
         }
         engine->replay_total = nframes; engine->replay_first = static_cast<int>(f0);
       }
+      mark("tables built", p);
       headers.clear();
       offs.assign(nf + 1, 0);
       uint8_t one[2048];
@@ -1312,6 +1343,7 @@ int sjpeg_hip_encode_batch_src(sjpeg_hip_engine* engine, const sjpeg_hip_source*
                                                      offs.data(), /*append_eoi=*/1, static_cast<uint8_t*>(d_out) + f0 * out_stride,
                                                      out_stride, d_sizes + f0, stream);
       if (rc_enc != 0) return rc_enc;
+      mark("encode launched", p);
     }
     return 0;
   } catch (...) {

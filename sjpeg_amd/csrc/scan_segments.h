@@ -7,7 +7,8 @@
 
 enum { kKindEncode = 0, kKindTap = 1, kKindHisto = 2, kKindStats = 3, kKindError = 4,
        kKindEncodeTrellis = 5, kKindStatsTrellis = 6,     // the same two with trellis quantization
-       kKindEncodeReplay = 7 };   // entropy-code the coefficients a statistics pass left behind
+       kKindEncodeReplay = 7,     // entropy-code the coefficients a statistics pass left behind
+       kKindStatsCoef = 8 };      // statistics from the DCT coefficients a histogram pass left behind
 constexpr int kHistoWords = 2 * 64 * 32;          // per-workgroup partial: u8 counters [2][64][128]
 constexpr int kStatsWords = 2 * 272;              // per-workgroup partial: u32 [2][256 AC + 16 DC]
 
@@ -33,13 +34,16 @@ __device__ __forceinline__ void race_point(int code, int n) {
 // smaller LDS block)
 // the compact LDS layout (scan_device.h): four workgroups per CU
 template <int MODE, int KINDX, int SRC>
-constexpr bool kCompactLds = (KINDX == kKindEncode || KINDX == kKindEncodeReplay || KINDX == kKindStats);
+constexpr bool kCompactLds = (KINDX == kKindEncode || KINDX == kKindEncodeReplay || KINDX == kKindStats || KINDX == kKindStatsCoef);
 
 template <int MODE, int KINDX, int SRC>
 __global__ __launch_bounds__(kScanThreads, ((KINDX == kKindHisto && SRC == kSrcRgb24) || kCompactLds<MODE, KINDX, SRC>) ? 4 : 1) void scan_segments(const ScanArgs a) {
   constexpr bool TRELLIS = (KINDX == kKindEncodeTrellis || KINDX == kKindStatsTrellis);
   constexpr bool REPLAY = (KINDX == kKindEncodeReplay);
-  constexpr int KIND = (KINDX == kKindEncodeTrellis || KINDX == kKindEncodeReplay) ? kKindEncode : (KINDX == kKindStatsTrellis) ? kKindStats : KINDX;
+  // the block's unquantized coefficients come from the histogram pass of the same call (the adaptive methods run
+  // one before they know the quantizer): no second colour conversion / DCT
+  constexpr bool COEF = (KINDX == kKindStatsCoef);
+  constexpr int KIND = (KINDX == kKindEncodeTrellis || KINDX == kKindEncodeReplay) ? kKindEncode : (KINDX == kKindStatsTrellis || COEF) ? kKindStats : KINDX;
   constexpr bool COMPACT = kCompactLds<MODE, KINDX, SRC>;
   using L = Lds<COMPACT>;
   constexpr int kWinWords = L::kWinWords;
@@ -130,8 +134,8 @@ __global__ __launch_bounds__(kScanThreads, ((KINDX == kKindHisto && SRC == kSrcR
 
   // ---- P1: colour conversion, strips of 8 pixels (x2 rows for 4:2:0) --------------------
   // local MCU index ml: 0 = halo, 1..n_coded = coded MCUs; block slot = ml*BPM + k
-  if (REPLAY) stage_tables();
-  if (!REPLAY) {
+  if (REPLAY || COEF) stage_tables();
+  if (!REPLAY && !COEF) {
     const int ml_lo = 1 - halo;
     const int n_proc = n_coded + halo;
     constexpr int kRowsPerStrip = (MODE == SJPEG_HIP_YUV420) ? 2 : 1;
@@ -321,29 +325,33 @@ __global__ __launch_bounds__(kScanThreads, ((KINDX == kKindHisto && SRC == kSrcR
   // the bound depends on the AC table of the pass that CODES it, not of the pass that quantized it
   uint32_t any_ac = 0;
   // what a statistics pass keeps for the replay kind: the slot as P2 leaves it + masks + DC value
+  // (row-major over the workgroup -- row r of thread t at [r * 256 + t] --: one store or load instruction of a
+  // wave covers 1 KiB in one piece.  Thread-major (144 B apart) made every one of them touch 64 cache lines.)
   uint4* const keep = (a.replay == nullptr) ? nullptr
-      : reinterpret_cast<uint4*>(a.replay) + ((static_cast<size_t>(frame) * a.nseg + seg) * kScanThreads + tid) * 9;
+      : reinterpret_cast<uint4*>(a.replay) + (static_cast<size_t>(frame) * a.nseg + seg) * kScanThreads * 9 + tid;
+  constexpr int kKeepRow = kScanThreads;
   if (REPLAY) {
     if (has_slot) {
 #pragma unroll
-      for (int r = 0; r < 8; ++r) *reinterpret_cast<uint4*>(slot + 16 * r) = keep[r];
+      for (int r = 0; r < 8; ++r) *reinterpret_cast<uint4*>(slot + 16 * r) = keep[r * kKeepRow];
     }
-    const uint4 t = keep[8];
+    const uint4 t = keep[8 * kKeepRow];
     nzq[0] = t.x & 0xffffu; nzq[1] = t.x >> 16; nzq[2] = t.y & 0xffffu; nzq[3] = t.y >> 16;
     dc_val = static_cast<int>(t.z);
     any_ac = t.w;
   }
   if (!REPLAY) {
   // rows as packed int16 pairs, straight from the slot, in slot order: (s0,s1) (s3,s2) (s4,s5) (s7,s6)
+  // (COEF: the coefficients themselves, natural order, as the histogram kind below leaves them)
   uint32_t p[8][4];
 #pragma unroll
   for (int r = 0; r < 8; ++r) {
     uint4 q = make_uint4(0, 0, 0, 0);
-    if (has_block) q = *reinterpret_cast<const uint4*>(slot + 16 * r);
+    if (has_block) q = COEF ? keep[r * kKeepRow] : *reinterpret_cast<const uint4*>(slot + 16 * r);
     p[r][0] = q.x; p[r][1] = q.y; p[r][2] = q.z; p[r][3] = q.w;
   }
 
-  if (MODE == SJPEG_HIP_YUV420 && !interior) {
+  if (MODE == SJPEG_HIP_YUV420 && !interior && !COEF) {
     // AverageExtraLuma (src/encoders.cc:107-125): luma blocks wholly outside the picture
     // become flat at (sum + 32) >> 6 of a neighbouring real block.
     int sum = 0;
@@ -380,9 +388,11 @@ __global__ __launch_bounds__(kScanThreads, ((KINDX == kKindHisto && SRC == kSrcR
   }
 
   // forward DCT: two columns per op, then row by row fused with quantization
+  if (!COEF) {
 #pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    fdct_col8_pk(p[0][c], p[1][c], p[2][c], p[3][c], p[4][c], p[5][c], p[6][c], p[7][c]);
+    for (int c = 0; c < 4; ++c) {
+      fdct_col8_pk(p[0][c], p[1][c], p[2][c], p[3][c], p[4][c], p[5][c], p[6][c], p[7][c]);
+    }
   }
   if (KIND == kKindError) {
     // Quantization error of the picture (reference QuantizeError, src/quantize.cc:553-565):
@@ -447,10 +457,15 @@ __global__ __launch_bounds__(kScanThreads, ((KINDX == kKindHisto && SRC == kSrcR
     const uint32_t one = emits ? 1u : 0u;          // (blocks that are not coded add zero)
     const uint32_t rep_off = static_cast<uint32_t>(tid & (kReps - 1)) * 4u;
     auto bump = [&](int row, const int* ac8) {
+      uint32_t cq[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) cq[k] = __builtin_amdgcn_perm(static_cast<uint32_t>(ac8[2 * k + 1]), static_cast<uint32_t>(ac8[2 * k]), 0x07060302u);
+      // the coefficients stay behind for the statistics pass of the same call (kKindStatsCoef)
+      if (keep != nullptr) keep[row * kKeepRow] = make_uint4(cq[0], cq[1], cq[2], cq[3]);
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         // both coefficients of a pair at once: |c| >> 2, clamped to 128 (packed 16-bit operations)
-        const s16x2 c = as_pk(__builtin_amdgcn_perm(static_cast<uint32_t>(ac8[2 * k + 1]), static_cast<uint32_t>(ac8[2 * k]), 0x07060302u));
+        const s16x2 c = as_pk(cq[k]);
         const u16x2 mag = __builtin_bit_cast(u16x2, __builtin_elementwise_max(c, pk_const(0, 0) - c));
         uint32_t bins;
         asm("v_pk_min_u16 %0, %1, %2" : "=v"(bins) : "v"(__builtin_bit_cast(uint32_t, mag >> u16x2{2, 2})), "v"(0x00800080u));
@@ -495,7 +510,12 @@ __global__ __launch_bounds__(kScanThreads, ((KINDX == kKindHisto && SRC == kSrcR
   {
     const uint4* qt = lq + tbl * 32;
     // cos(k*pi/16)/sqrt(2) tables, rows 1/7, 2/6, 3/5 pre-scaled (src/fdct.cc:28-35,599-606)
-    if (!TRELLIS) {
+    if (COEF) {
+      quant_row<0>(p[0], qt, ent + 0, nzq); quant_row<1>(p[1], qt, ent + 4, nzq);
+      quant_row<2>(p[2], qt, ent + 8, nzq); quant_row<3>(p[3], qt, ent + 12, nzq);
+      quant_row<4>(p[4], qt, ent + 16, nzq); quant_row<5>(p[5], qt, ent + 20, nzq);
+      quant_row<6>(p[6], qt, ent + 24, nzq); quant_row<7>(p[7], qt, ent + 28, nzq);
+    } else if (!TRELLIS) {
       row_quant<0, 22725, 21407, 19266, 16384, 12873, 8867, 4520>(p[0], qt, ent + 0, nzq);
       row_quant<1, 31521, 29692, 26722, 22725, 17855, 12299, 6270>(p[1], qt, ent + 4, nzq);
       row_quant<2, 29692, 27969, 25172, 21407, 16819, 11585, 5906>(p[2], qt, ent + 8, nzq);
@@ -641,8 +661,8 @@ __global__ __launch_bounds__(kScanThreads, ((KINDX == kKindHisto && SRC == kSrcR
   nzq[0] &= ~1u;                                // DC is coded separately
   if (KIND == kKindStats && keep != nullptr) {   // leave the quantized block behind for the replay kind
 #pragma unroll
-    for (int r = 0; r < 8; ++r) keep[r] = *reinterpret_cast<const uint4*>(slot + 16 * r);
-    keep[8] = make_uint4(nzq[0] | (nzq[1] << 16), nzq[2] | (nzq[3] << 16), static_cast<uint32_t>(dc_val), any_ac);
+    for (int r = 0; r < 8; ++r) keep[r * kKeepRow] = *reinterpret_cast<const uint4*>(slot + 16 * r);
+    keep[8 * kKeepRow] = make_uint4(nzq[0] | (nzq[1] << 16), nzq[2] | (nzq[3] << 16), static_cast<uint32_t>(dc_val), any_ac);
   }
   }   // !REPLAY
   const uint32_t nz_lo = nzq[0] | (nzq[1] << 16), nz_hi = nzq[2] | (nzq[3] << 16);
@@ -819,14 +839,22 @@ __global__ __launch_bounds__(kScanThreads, ((KINDX == kKindHisto && SRC == kSrcR
         const unsigned long long below = m_all & ((1ull << sh) - 1ull);
         const bool is_last = (q == 3) || ((m_all >> (sh + 16)) == 0ull);
         int prev = below ? 64 - __builtin_clzll(below) : 1;
+        // The entry of the NEXT symbol is read before the counter of this one is bumped: LDS operations return in
+        // order, and a read issued behind an atomic waits for it -- with the lanes of a wave bumping the same few
+        // counters that was most of the time this loop took.  (Past the part's last symbol the read lands on the
+        // next quarter or the slot's tail: in the slot, never used.)
+        int i = sh + __builtin_ctz(m | 0x10000u);
+        uint32_t e = zz[i];
         while (m) {
-          const int i = sh + __builtin_ctz(m);
           m &= m - 1;
-          const uint32_t mag = zz[i] & 0x7fffu;
+          const int i_next = sh + __builtin_ctz(m | 0x10000u);
+          const uint32_t e_next = zz[i_next];
+          const uint32_t mag = e & 0x7fffu;
           const int run = i - prev;
           prev = i + 1;
           if (run >> 4) atomicAdd(&f[0xf0], static_cast<uint32_t>(run >> 4));
           atomicAdd(&f[((run & 15) << 4) | (32 - __clz(mag))], 1u);
+          i = i_next; e = e_next;
         }
         if (is_last && prev <= 63) atomicAdd(&f[0x00], 1u);
       }

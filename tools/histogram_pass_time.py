@@ -3,7 +3,7 @@ import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import sjpeg_amd as sj
 from oracle import synth
-n = 32
+n = 16
 base = [synth.g_struct(3840, 2160, 100 + k) for k in range(4)]
 frames = torch.from_numpy(np.stack([base[k % 4] for k in range(n)])).cuda()
 eng = sj.Engine(0)
