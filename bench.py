@@ -183,7 +183,7 @@ def run_config(sj, torch, eng, frames_np, tile, q, mode, want_md5, reps=10):
             "bit_exact": bool(ok)}
 
 
-def run_batch_config(sj, torch, eng, frames_np, tile, mode, method, want, quality=75.0, quant=None, reps=7):
+def run_batch_config(sj, torch, eng, frames_np, tile, mode, method, want, quality=75.0, quant=None, reps=20):
     """A configuration that goes through the per-picture analysis of the reference (adaptive quantization,
     optimised Huffman tables: sjpeg_hip_encode_batch_src, device passes + host analysis in between), or
     through caller-supplied matrices (C5): `tile` copies resident in HBM, whole call timed, frame 0
@@ -203,23 +203,32 @@ def run_batch_config(sj, torch, eng, frames_np, tile, mode, method, want, qualit
     out = torch.empty((F, stride), dtype=torch.uint8, device="cuda")
     sizes = torch.zeros(F, dtype=torch.int64, device="cuda")
     step = lambda: eng.encode_batch(src, F, w, h, mode, qm, method, min_quant=quant, out_stride=stride, out=out, sizes=sizes)
-    for _ in range(3):                            # (the first calls of a geometry allocate: 10 and 7 ms)
+    for _ in range(5):                            # (the first calls of a geometry allocate: 10 and 7 ms)
         step()
     torch.cuda.synchronize()
+    # Timed like every other configuration: `reps` calls back to back, one synchronise behind them (a call returns
+    # when its last pass is launched; the next call's first pass queues behind it).  Beside it the call taken alone
+    # -- synchronised after each, nothing of the next one under its tail --, median: the latency of one batch.
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
     per_call = []
-    for _ in range(reps):                         # the call waits for its own read-backs: timed one by one, median
+    for _ in range(15):
         t0 = time.perf_counter()
         step()
         torch.cuda.synchronize()
         per_call.append(time.perf_counter() - t0)
-    dt = float(np.median(per_call))
+    dt_alone = float(np.median(per_call))
     sz = sizes.cpu().numpy()
     # every frame (all are copies of one picture; a batch of 24 frames or more is coded in two parts: both are checked)
     ok = len(frames_np) == 1 and all(int(n) == want["size"] for n in sz)
     for k in range(F):
         ok = ok and hashlib.md5(bytes(out[k, :int(sz[k])].cpu().numpy())).hexdigest() == want["md5"]
     return {"frames": F, "width": w, "height": h, "method": method, "mpix_s": round(F * w * h / dt / 1e6, 1),
-            "ms_per_step": round(dt * 1e3, 4), "bytes_per_frame": int(sz[0]), "bit_exact": bool(ok)}
+            "ms_per_step": round(dt * 1e3, 4), "ms_per_call_alone": round(dt_alone * 1e3, 4),
+            "bytes_per_frame": int(sz[0]), "bit_exact": bool(ok)}
 
 
 def device_clocks(index=0):

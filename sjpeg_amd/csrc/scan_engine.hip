@@ -119,6 +119,12 @@ struct sjpeg_hip_engine {
   // what the two buffers hold, and the stream that put it there: a call with the same tables /
   // header on the same stream skips the upload (two of the ~6 runtime calls of a small encode)
   std::vector<DevTables> tables_held;
+  // Host-to-device uploads of more than a few KB (the tables and headers of a batch) go through pinned blocks the
+  // engine owns: hipMemcpyAsync from pageable memory pins the caller's pages for the length of the copy -- tens of
+  // microseconds of host time per upload and, now and then, several milliseconds (seen as one call in twenty of a
+  // 32-frame default-parameter batch taking 8 ms instead of 1.6).
+  struct Stage { void* p = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; bool busy = false; } stage[4];
+  int stage_next = 0;
   std::vector<uint8_t> header_held;
   const void* tables_held_at = nullptr; const void* header_held_at = nullptr;
   hipStream_t tables_stream = nullptr, header_stream = nullptr;
@@ -272,6 +278,30 @@ int order_on_stream(sjpeg_hip_engine* e, hipStream_t st) {
   return 0;
 }
 
+// dst <- src on the stream, through one of the engine's pinned blocks when the copy is not tiny (see sjpeg_hip_engine::stage)
+int upload(sjpeg_hip_engine* e, void* dst, const void* src, size_t bytes, hipStream_t st) {
+  if (bytes < 4096) {
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st));
+    return 0;
+  }
+  sjpeg_hip_engine::Stage& s = e->stage[e->stage_next];
+  e->stage_next = (e->stage_next + 1) & 3;
+  if (s.busy) { HIP_TRY(hipEventSynchronize(s.ev)); s.busy = false; }       // (four uploads ago: long done)
+  if (s.cap < bytes) {
+    if (s.p) (void)hipHostFree(s.p);
+    s.p = nullptr; s.cap = 0;
+    const size_t want = (bytes + 65535) & ~static_cast<size_t>(65535);
+    if (hipHostMalloc(&s.p, want, hipHostMallocDefault) != hipSuccess) { s.p = nullptr; return fail(SJPEG_HIP_ENOMEM, "hipHostMalloc(upload block) failed"); }
+    s.cap = want;
+  }
+  if (s.ev == nullptr && hipEventCreateWithFlags(&s.ev, hipEventDisableTiming) != hipSuccess) { s.ev = nullptr; return fail(SJPEG_HIP_ERUNTIME, "hipEventCreate failed"); }
+  memcpy(s.p, src, bytes);
+  HIP_TRY(hipMemcpyAsync(dst, s.p, bytes, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipEventRecord(s.ev, st));
+  s.busy = true;
+  return 0;
+}
+
 // Segment scratch of an encode call, sized from the bytes the caller gives every frame (out_stride)
 // instead of for the worst case: a frame's un-stuffed stream is never longer than its stuffed one, so
 // `budget` words hold it whenever the frame fits its output slot -- and a frame that does not fit
@@ -379,7 +409,7 @@ int prepare_scan(sjpeg_hip_engine* e, const sjpeg_hip_source* src,
                       memcmp(e->tables_held.data(), host_tables.data(), sizeof(DevTables) * ntab) == 0;
     if (!held) {
       e->tables_held_at = nullptr;
-      HIP_TRY(hipMemcpyAsync(e->tables.p, host_tables.data(), sizeof(DevTables) * ntab, hipMemcpyHostToDevice, st));
+      if (int rcu = upload(e, e->tables.p, host_tables.data(), sizeof(DevTables) * ntab, st)) return rcu;
       if (ntab <= 16) {                            // (a big batch of per-frame tables is not worth holding)
         e->tables_held.swap(host_tables);
         e->tables_held_at = e->tables.p; e->tables_stream = st;
@@ -466,6 +496,11 @@ void sjpeg_hip_engine_destroy(sjpeg_hip_engine* e) {
   e->tables.release(); e->header.release(); e->seg_words.release(); e->seg_nbits.release(); e->pool.release(); e->pool_ctr.release(); e->seg_xbase.release(); e->replay.release();
   e->ubuf.release(); e->chunk_ff.release(); e->partial.release(); e->seg_off.release(); e->chunk_off.release(); e->hdr_off.release(); e->stamps.release();
   for (auto& ev : e->ev) if (ev) (void)hipEventDestroy(ev);
+  for (auto& sg : e->stage) {
+    if (sg.busy) (void)hipEventSynchronize(sg.ev);
+    if (sg.ev) (void)hipEventDestroy(sg.ev);
+    if (sg.p) (void)hipHostFree(sg.p);
+  }
   e->seg_words2.release(); e->seg_nbits2.release(); e->pool2.release(); e->pool_ctr2.release(); e->seg_xbase2.release();
   if (e->side) { (void)hipStreamSynchronize(e->side); (void)hipStreamDestroy(e->side); }
   for (hipEvent_t ev : {e->k1_done, e->side_done, e->k3_done[0], e->k3_done[1], e->cross_ev}) if (ev) (void)hipEventDestroy(ev);
@@ -790,7 +825,7 @@ static int encode_scan_impl(sjpeg_hip_engine* e, const sjpeg_hip_source* src, in
       if (f > 0 && header_offsets[f] - header_offsets[f - 1] > largest_header) largest_header = header_offsets[f] - header_offsets[f - 1];
     }
     if ((rc = e->hdr_off.ensure(static_cast<size_t>(nframes) + 1))) return rc;
-    HIP_TRY(hipMemcpyAsync(e->hdr_off.p, offs.data(), offs.size() * sizeof(uint32_t), hipMemcpyHostToDevice, hs));
+    if (int rcu = upload(e, e->hdr_off.p, offs.data(), offs.size() * sizeof(uint32_t), hs)) return rcu;
   }
   header_size = header == nullptr ? 0 : header_size;
   if (out_stride < largest_header + 2 + 64) {
@@ -809,7 +844,7 @@ static int encode_scan_impl(sjpeg_hip_engine* e, const sjpeg_hip_source* src, in
                       e->header_held.size() == header_size && memcmp(e->header_held.data(), hb, header_size) == 0;
     if (!held) {
       e->header_held_at = nullptr;
-      HIP_TRY(hipMemcpyAsync(e->header.p, header, header_size, hipMemcpyHostToDevice, hs));
+      if (int rcu = upload(e, e->header.p, header, header_size, hs)) return rcu;
       e->header_held.assign(hb, hb + header_size);
       e->header_held_at = e->header.p; e->header_stream = hs;
     }
