@@ -330,15 +330,53 @@ __global__ __launch_bounds__(kScanThreads, ((KINDX == kKindHisto && SRC == kSrcR
   uint4* const keep = (a.replay == nullptr) ? nullptr
       : reinterpret_cast<uint4*>(a.replay) + (static_cast<size_t>(frame) * a.nseg + seg) * kScanThreads * 9 + tid;
   constexpr int kKeepRow = kScanThreads;
+  // A kept block is 64 + 16 bytes when no AC level of it exceeds 127 (every ordinary block): its entries as BYTES --
+  // sign in bit 7, level in bits 0..6 --, rows 0..3, and the tail (masks, DC value, OR of the AC entries) in row 4.
+  // A block with a larger level keeps the low bytes there and the high bytes (sign, level bits 8..14) in rows 5..8.
+  // Entry 0, the quantized DC, is not kept in either: the tail has the value.  (16-bit entries, 144 bytes, until
+  // round 4: the statistics pass wrote more than the pixels it read, and the replay pass read it all back.)
+  constexpr uint32_t kWideLevels = 0x7f807f80u;     // (of the OR of the entries: some level is 128 or more)
   if (REPLAY) {
-    if (has_slot) {
+    uint4 lo[4], hi[4];
 #pragma unroll
-      for (int r = 0; r < 8; ++r) *reinterpret_cast<uint4*>(slot + 16 * r) = keep[r * kKeepRow];
-    }
-    const uint4 t = keep[8 * kKeepRow];
+    for (int j = 0; j < 4; ++j) lo[j] = keep[j * kKeepRow];
+    const uint4 t = keep[4 * kKeepRow];
     nzq[0] = t.x & 0xffffu; nzq[1] = t.x >> 16; nzq[2] = t.y & 0xffffu; nzq[3] = t.y >> 16;
     dc_val = static_cast<int>(t.z);
     any_ac = t.w;
+    const bool wide = (any_ac & kWideLevels) != 0u;
+    if (wide) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) hi[j] = keep[(5 + j) * kKeepRow];
+    }
+    if (has_slot) {
+      const uint32_t dm = static_cast<uint32_t>(dc_val < 0 ? -dc_val : dc_val);
+      const uint32_t dc_entry = dm | (dc_val < 0 ? 0x8000u : 0u);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint32_t b[4] = {lo[j].x, lo[j].y, lo[j].z, lo[j].w};
+        uint32_t e[8];
+        if (!wide) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            // bytes -> 16-bit entries: (b0, 0, b1, 0), then bit 7 of each half moves to bit 15: x + (x & 0x80) * 255
+            const uint32_t x0 = __builtin_amdgcn_perm(0u, b[k], 0x0c010c00u), x1 = __builtin_amdgcn_perm(0u, b[k], 0x0c030c02u);
+            e[2 * k] = __umul24(x0 & 0x00800080u, 255u) + x0;
+            e[2 * k + 1] = __umul24(x1 & 0x00800080u, 255u) + x1;
+          }
+        } else {
+          const uint32_t h[4] = {hi[j].x, hi[j].y, hi[j].z, hi[j].w};
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            e[2 * k] = __builtin_amdgcn_perm(h[k], b[k], 0x05010400u);
+            e[2 * k + 1] = __builtin_amdgcn_perm(h[k], b[k], 0x07030602u);
+          }
+        }
+        if (j == 0) e[0] = (e[0] & 0xffff0000u) | dc_entry;
+        *reinterpret_cast<uint4*>(slot + 32 * j) = make_uint4(e[0], e[1], e[2], e[3]);
+        *reinterpret_cast<uint4*>(slot + 32 * j + 16) = make_uint4(e[4], e[5], e[6], e[7]);
+      }
+    }
   }
   if (!REPLAY) {
   // rows as packed int16 pairs, straight from the slot, in slot order: (s0,s1) (s3,s2) (s4,s5) (s7,s6)
@@ -660,9 +698,22 @@ __global__ __launch_bounds__(kScanThreads, ((KINDX == kKindHisto && SRC == kSrcR
   }
   nzq[0] &= ~1u;                                // DC is coded separately
   if (KIND == kKindStats && keep != nullptr) {   // leave the quantized block behind for the replay kind
+    const bool wide = (any_ac & kWideLevels) != 0u;
 #pragma unroll
-    for (int r = 0; r < 8; ++r) keep[r * kKeepRow] = *reinterpret_cast<const uint4*>(slot + 16 * r);
-    keep[8 * kKeepRow] = make_uint4(nzq[0] | (nzq[1] << 16), nzq[2] | (nzq[3] << 16), static_cast<uint32_t>(dc_val), any_ac);
+    for (int j = 0; j < 4; ++j) {
+      const uint4 ra = *reinterpret_cast<const uint4*>(slot + 32 * j), rb = *reinterpret_cast<const uint4*>(slot + 32 * j + 16);
+      const uint32_t p[4] = {ra.x, ra.z, rb.x, rb.z}, q[4] = {ra.y, ra.w, rb.y, rb.w};
+      uint32_t lb[4], hb[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        lb[k] = __builtin_amdgcn_perm(q[k], p[k], 0x06040200u);        // low bytes of entries 4k .. 4k + 3 of the row pair
+        hb[k] = __builtin_amdgcn_perm(q[k], p[k], 0x07050301u);        // high bytes: sign, level bits 8..14
+        if (!wide) lb[k] |= hb[k] & 0x80808080u;
+      }
+      keep[j * kKeepRow] = make_uint4(lb[0], lb[1], lb[2], lb[3]);
+      if (wide) keep[(5 + j) * kKeepRow] = make_uint4(hb[0], hb[1], hb[2], hb[3]);
+    }
+    keep[4 * kKeepRow] = make_uint4(nzq[0] | (nzq[1] << 16), nzq[2] | (nzq[3] << 16), static_cast<uint32_t>(dc_val), any_ac);
   }
   }   // !REPLAY
   const uint32_t nz_lo = nzq[0] | (nzq[1] << 16), nz_hi = nzq[2] | (nzq[3] << 16);

@@ -414,6 +414,35 @@ def test_batch_in_parts_equals_per_picture_encodes(engine, oracle):
         assert got[k] == oracle.encode_method(imgs[k], 75.0, 1, 4), k
 
 
+def test_kept_blocks_narrow_and_wide(engine, oracle):
+    """The statistics pass keeps a quantized block as bytes when no AC level exceeds 127 and adds a second plane
+    of high bytes when one does (scan_segments.h); the replay kind rebuilds the 16-bit entries.  A batch that mixes
+    both kinds of block in one workgroup -- noise at q 97..100 (levels of several hundred) beside flat and smooth
+    pictures, DC differences beyond 127 beside tiny ones, negative coefficients that quantize to zero -- must still
+    be the reference's per-picture encodes, with the statistics pass fed from the pixels (methods 1, 2: no
+    histogram pass) and from the histogram pass' coefficients (methods 4, 6)."""
+    rng = np.random.RandomState(4242)
+    for (w, h) in ((64, 48), (97, 61), (336, 200)):
+        imgs = []
+        for k in range(6):
+            if k % 3 == 0:
+                imgs.append(rng.randint(0, 256, (h, w, 3)).astype(np.uint8))                     # noise: wide blocks at high q
+            elif k % 3 == 1:
+                img = synth.g_struct(w, h, 900 + k)
+                img[: h // 2, : w // 2] = rng.randint(0, 256, (h // 2, w // 2, 3))              # both kinds in one picture
+                imgs.append(img)
+            else:
+                img = np.zeros((h, w, 3), np.uint8)
+                img[:, ::16] = 255                                                                # large DC steps, sparse AC
+                img[::7] //= 2
+                imgs.append(img)
+        frames = torch.from_numpy(np.stack(imgs)).cuda()
+        for mode, q, method in ((1, 100.0, 4), (3, 98.0, 6), (4, 100.0, 2), (1, 97.0, 1), (3, 100.0, 4), (1, 60.0, 4)):
+            got = sj.encode_device_method(frames, q, mode, method, engine=engine)
+            for k in range(len(imgs)):
+                assert got[k] == oracle.encode_method(imgs[k], q, mode, method), (w, h, k, mode, q, method)
+
+
 def test_saturated_primaries_chroma_plus_128(engine, oracle):
     """Pure blue makes Cb = +128 and pure red Cr = +128 (one past the int8 range the other samples stay in):
     four such columns in a block put the row pass' even sum at 32768, one past int16 -- solid red and blue
