@@ -896,6 +896,7 @@ __global__ __launch_bounds__(kScanThreads, ((KINDX == kKindHisto && SRC == kSrcR
         // next quarter or the slot's tail: in the slot, never used.)
         int i = sh + __builtin_ctz(m | 0x10000u);
         uint32_t e = zz[i];
+        uint32_t zrls = 0;
         while (m) {
           m &= m - 1;
           const int i_next = sh + __builtin_ctz(m | 0x10000u);
@@ -903,10 +904,11 @@ __global__ __launch_bounds__(kScanThreads, ((KINDX == kKindHisto && SRC == kSrcR
           const uint32_t mag = e & 0x7fffu;
           const int run = i - prev;
           prev = i + 1;
-          if (run >> 4) atomicAdd(&f[0xf0], static_cast<uint32_t>(run >> 4));
+          zrls += static_cast<uint32_t>(run >> 4);           // (counted once behind the loop: no branch in it)
           atomicAdd(&f[((run & 15) << 4) | (32 - __clz(mag))], 1u);
           i = i_next; e = e_next;
         }
+        if (zrls != 0u) atomicAdd(&f[0xf0], zrls);
         if (is_last && prev <= 63) atomicAdd(&f[0x00], 1u);
       }
     }
