@@ -517,6 +517,10 @@ int sjpeg_hip_engine_trim(sjpeg_hip_engine* e) {
   e->ubuf.release(); e->chunk_ff.release(); e->partial.release(); e->replay.release();
   e->seg_off.release(); e->chunk_off.release(); e->hdr_off.release(); e->stamps.release();
   e->tables.release(); e->header.release();        // (per-frame tables of a large batch are scratch like the rest)
+  for (auto& sg : e->stage) {                      // ... and so are the pinned blocks they were uploaded through
+    if (sg.p) (void)hipHostFree(sg.p);
+    sg.p = nullptr; sg.cap = 0; sg.busy = false;
+  }
   e->tables_held_at = nullptr; e->header_held_at = nullptr;
   e->replay_w = e->replay_h = e->replay_mode = e->replay_nframes = 0;
   e->stamps_n = 0;
