@@ -154,7 +154,7 @@ def run_config(sj, torch, eng, frames_np, tile, q, mode, want_md5, reps=10):
     out = torch.empty((F, stride), dtype=torch.uint8, device="cuda")
     sizes = torch.zeros(F, dtype=torch.int64, device="cuda")
     step = lambda: eng.encode_frames(frames, tables, header, mode, out=out, sizes=sizes, out_stride=stride)
-    for _ in range(2):
+    for _ in range(6):                            # (K1 of a new geometry gets 5 % faster over its first dozen calls)
         step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -162,11 +162,24 @@ def run_config(sj, torch, eng, frames_np, tile, q, mode, want_md5, reps=10):
         step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
+    # the same calls in the engine's pipelined mode (the mode of the headline: K1 of call n + 1 beside the stitch of call n)
+    eng.set_pipelined(True)
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        step()
+    torch.cuda.synchronize()
+    dt_piped = (time.perf_counter() - t0) / reps
+    eng.set_pipelined(False)
+    torch.cuda.synchronize()
     eng.set_timing(True)
     k1 = []
-    for _ in range(5):
+    for _ in range(8):
         step()
         k1.append(eng.last_scan_ms())
+    k1 = k1[3:]
     eng.set_timing(False)
     sz = sizes.cpu().numpy()
     if isinstance(want_md5, dict):                       # whole batch, concatenated
@@ -178,12 +191,13 @@ def run_config(sj, torch, eng, frames_np, tile, q, mode, want_md5, reps=10):
         ok = hashlib.md5(bytes(out[0, :int(sz[0])].cpu().numpy())).hexdigest() == want_md5
     k1_s = float(np.mean(k1)) * 1e-3
     return {"frames": F, "width": w, "height": h, "mpix_s": round(F * w * h / dt / 1e6, 1),
-            "ms_per_step": round(dt * 1e3, 4), "kernel_ms": round(k1_s * 1e3, 4),
+            "ms_per_step": round(dt * 1e3, 4), "mpix_s_pipelined": round(F * w * h / dt_piped / 1e6, 1),
+            "ms_per_step_pipelined": round(dt_piped * 1e3, 4), "kernel_ms": round(k1_s * 1e3, 4),
             "frac": round(3.0 * w * h * F / k1_s / HBM_PEAK, 4), "bytes_per_frame": int(sz[0]),
             "bit_exact": bool(ok)}
 
 
-def run_batch_config(sj, torch, eng, frames_np, tile, mode, method, want, quality=75.0, quant=None, reps=20):
+def run_batch_config(sj, torch, eng, frames_np, tile, mode, method, want, quality=75.0, quant=None, reps=25):
     """A configuration that goes through the per-picture analysis of the reference (adaptive quantization,
     optimised Huffman tables: sjpeg_hip_encode_batch_src, device passes + host analysis in between), or
     through caller-supplied matrices (C5): `tile` copies resident in HBM, whole call timed, frame 0
@@ -206,14 +220,17 @@ def run_batch_config(sj, torch, eng, frames_np, tile, mode, method, want, qualit
     for _ in range(5):                            # (the first calls of a geometry allocate: 10 and 7 ms)
         step()
     torch.cuda.synchronize()
-    # Timed like every other configuration: `reps` calls back to back, one synchronise behind them (a call returns
+    # Timed like every other configuration: calls back to back, one synchronise behind a group of them (a call returns
     # when its last pass is launched; the next call's first pass queues behind it).  Beside it the call taken alone
     # -- synchronised after each, nothing of the next one under its tail --, median: the latency of one batch.
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        step()
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / reps
+    groups = []
+    for _ in range(5):                            # (median of five groups: one call of a process, some tens of calls in,
+        t0 = time.perf_counter()                  # takes 6-8 ms in the runtime -- DESIGN.md section 4 --, and a mean would carry it)
+        for _ in range(max(reps // 5, 1)):
+            step()
+        torch.cuda.synchronize()
+        groups.append((time.perf_counter() - t0) / max(reps // 5, 1))
+    dt = float(np.median(groups))
     per_call = []
     for _ in range(15):
         t0 = time.perf_counter()

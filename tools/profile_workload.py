@@ -20,7 +20,8 @@ from oracle import synth  # noqa: E402
 cfg = sys.argv[1]
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 eng = sj.Engine(0)
-
+if os.environ.get("PIPELINED"):          # the engine's pipelined mode (K1 of call n + 1 beside the stitch of call n)
+    eng.set_pipelined(True)
 
 def plain(frames_np, q, mode, quant=None):
     F = len(frames_np)
@@ -34,7 +35,6 @@ def plain(frames_np, q, mode, quant=None):
     sizes = torch.zeros(F, dtype=torch.int64, device="cuda")
     step = lambda: eng.encode_frames(frames, tables, header, mode, out=out, sizes=sizes, out_stride=stride)
     return step, F * w * h, sizes
-
 
 def batch(frames_np, mode, method, q=75.0, quant=None):
     F = len(frames_np)
@@ -55,12 +55,10 @@ def batch(frames_np, mode, method, q=75.0, quant=None):
                                            out_stride=stride, out=out, sizes=sizes))
     return step, F * w * h, sizes
 
-
 def c5_quant():
     d = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "digests.json")))
     src = np.array(d["recompress|r90|m0"]["source_quant"], np.uint8).reshape(2, 64)
     return np.clip((src.astype(np.float64) * 100.0 / 90.0 + 0.5).astype(np.int64), 1, 255).astype(np.uint8)
-
 
 if cfg == "c2noise":
     step, px, sizes = plain([synth.g_noise(3840, 2160, 7654321 + k) for k in range(4)] * 4, 75.0, 1)
@@ -88,6 +86,7 @@ torch.cuda.synchronize()
 t0 = time.perf_counter()
 for _ in range(reps):
     step()
+
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / reps
 assert int(sizes.min().item()) > 0
