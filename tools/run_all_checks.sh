@@ -8,6 +8,7 @@ N=2 run python -m pytest tests -m gpu -x -q
 N=1 run python tools/gpu_fuzz.py 1 240
 N=3 run python tools/low_entropy_fuzz.py 1 "${LOWENT:-120}"
 N=3 run python tools/extremes_fuzz.py 1 "${LOWENT:-120}"
+N=1 run python tools/batch_fuzz.py 1 "${LOWENT:-120}"
 N=1 run python tools/gpu_soak.py 1 "${SOAK:-120}"
 N=1 run python tools/sharp_soak.py "${SOAK:-60}" 1
 N=1 run python tools/thread_soak.py 16 100
