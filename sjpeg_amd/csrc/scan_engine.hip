@@ -280,7 +280,9 @@ int order_on_stream(sjpeg_hip_engine* e, hipStream_t st) {
 
 // dst <- src on the stream, through one of the engine's pinned blocks when the copy is not tiny (see sjpeg_hip_engine::stage)
 int upload(sjpeg_hip_engine* e, void* dst, const void* src, size_t bytes, hipStream_t st) {
-  if (bytes < 4096) {
+  // (tiny copies are staged by the runtime itself; for a very large one -- the per-frame tables of a batch of tens of
+  // thousands of frames -- the pinning is small beside the copy, and four pinned blocks of that size would not be)
+  if (bytes < 4096 || bytes > (static_cast<size_t>(8) << 20)) {
     HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st));
     return 0;
   }
