@@ -72,9 +72,39 @@ N_SIMD, CLOCK_HZ = 256 * 4, 2.4e9
 PMC_SUMMARY = os.path.join("profiles", "r04", "final_pmc_summary.txt")
 
 
+def host_cpus():
+    """(model string, one logical CPU per PHYSICAL core this process may run on, logical CPUs it may run on):
+    /proc/cpuinfo's (physical id, core id) pairs, restricted to the affinity mask."""
+    model, cores, cur = None, {}, {}
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        allowed = list(range(os.cpu_count() or 1))
+    try:
+        for line in open("/proc/cpuinfo"):
+            if ":" not in line:
+                if "processor" in cur:
+                    key = (cur.get("physical id", "0"), cur.get("core id", cur["processor"]))
+                    if int(cur["processor"]) in allowed:
+                        cores.setdefault(key, int(cur["processor"]))
+                cur = {}
+                continue
+            k, v = (t.strip() for t in line.split(":", 1))
+            cur[k] = v
+            if k == "model name" and model is None:
+                model = v
+        if "processor" in cur and int(cur["processor"]) in allowed:
+            cores.setdefault((cur.get("physical id", "0"), cur.get("core id", cur["processor"])), int(cur["processor"]))
+    except OSError:
+        pass
+    one_per_core = sorted(cores.values()) or allowed
+    return model, one_per_core, allowed
+
+
 def cpu_baseline(frames_np, budget_s=12.0):
-    """Reference CPU encoder on this host: 1 thread (the reference has no intra-encode
-    threading), plus all cores frame-parallel for information."""
+    """Reference CPU encoder on this host: 1 thread (the reference has no intra-encode threading), plus one
+    independent frame stream per PHYSICAL core, every worker pinned to its own core ("all
+    physical cores, one independent frame per thread; state nproc and CPU model")."""
     from oracle import orc, refso
     kind, enc = "port", None
     try:
@@ -87,6 +117,7 @@ def cpu_baseline(frames_np, budget_s=12.0):
     if enc is None:
         o = orc.oracle()
         enc = lambda im: o.encode(im, QUALITY, orc.YUV_420)
+    model, core_cpus, allowed = host_cpus()
     enc(frames_np[0])                                   # warm-up
     n, t0 = 0, time.perf_counter()
     while True:
@@ -96,19 +127,29 @@ def cpu_baseline(frames_np, budget_s=12.0):
         if dt > budget_s * 0.5 or n >= 400:
             break
     single = n * W * H / dt / 1e6
-    # all cores, one independent frame per thread (ctypes releases the GIL)
+    # one independent frame stream per physical core (ctypes releases the GIL), each worker on its own core
     from concurrent.futures import ThreadPoolExecutor
-    cores = os.cpu_count() or 1
+    cores = len(core_cpus)
     per = max(2, int(budget_s * 0.5 / max(dt / n, 1e-3)))
     per = min(per, 16)
+
+    def worker(i):
+        try:
+            os.sched_setaffinity(0, {core_cpus[i]})     # (pid 0: the calling thread)
+        except (AttributeError, OSError):
+            pass
+        for j in range(per):
+            enc(frames_np[(i + j) % len(frames_np)])
+
     t0 = time.perf_counter()
     with ThreadPoolExecutor(cores) as ex:
-        list(ex.map(lambda i: [enc(frames_np[(i + j) % len(frames_np)]) for j in range(per)],
-                    range(cores)))
+        list(ex.map(worker, range(cores)))
     dt_all = time.perf_counter() - t0
     return {"value": round(single, 1), "unit": "Mpixels/s", "cores": 1, "kind": kind,
             "sample": f"{n} encodes of 3840x2160 G_struct q75 420 method 0, 1 thread, {dt:.1f} s",
-            "allcores_value": round(cores * per * W * H / dt_all / 1e6, 1), "allcores": cores}
+            "cpu_model": model, "physical_cores": cores, "logical_cpus": len(allowed),
+            "allcores_value": round(cores * per * W * H / dt_all / 1e6, 1), "allcores": cores,
+            "allcores_sample": f"{cores} threads (one per physical core, pinned), {per} encodes each, {dt_all:.1f} s"}
 
 
 def pmc_figures():
@@ -620,6 +661,9 @@ def main():
         if scan_avg:
             roof.update({"achieved": round(achieved / 1e9, 1), "frac": round(achieved / HBM_PEAK, 4), "traffic": traffic,
                          "traffic_source": PMC_SUMMARY if traffic is not None else None,
+                         # (traffic and valu.instr_per_wave are read from that committed PMC pass of this build's
+                         # default command, not collected in this run: counters need rocprofv3 around the process)
+                         "traffic_static": traffic is not None,
                          "kernel_ms": round(scan_avg * 1e3, 4), "kernel_ms_min": round(float(np.min(scan_ms)), 4),
                          "all_kernels_ms": round(float(np.mean(total_ms)), 4),
                          "stream_read_GBps": None if stream_gbps is None else round(stream_gbps, 1),

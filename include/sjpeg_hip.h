@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SJPEG_HIP_ABI_VERSION 16
+#define SJPEG_HIP_ABI_VERSION 17
 
 enum {
   SJPEG_HIP_OK = 0,
@@ -491,6 +491,16 @@ typedef struct sjpeg_hip_comm sjpeg_hip_comm;
 int sjpeg_hip_comm_unique_id(uint8_t id[SJPEG_HIP_COMM_ID_BYTES]);
 int sjpeg_hip_comm_create(const uint8_t id[SJPEG_HIP_COMM_ID_BYTES], int rank, int world, sjpeg_hip_comm** comm);
 int sjpeg_hip_comm_adopt(void* nccl_comm /* ncclComm_t */, sjpeg_hip_comm** comm);
+/* A communicator on the LOCAL transport: its ranks are threads of ONE process (a server that drives the
+ * GPUs of a node from one thread each, or several engines on one GPU), no RCCL in the process.  `id`: any
+ * 128 bytes the application picks, the same on every rank of the group; every rank calls this once, with
+ * the device it works on current.  The gather functions below are the same code on either transport; here
+ * a transfer is a copy on the receiver's stream (a peer copy between devices), ordered behind the sender's
+ * stream by an event and the sender's stream behind the copy by another -- the calls of a matched pair meet
+ * on the host, so a send returns once its receive has been enqueued, and a rank that does not show up within
+ * 60 s makes the call fail with SJPEG_HIP_ERUNTIME on the ranks that wait for it (never a hang). */
+int sjpeg_hip_comm_create_local(const uint8_t id[SJPEG_HIP_COMM_ID_BYTES], int rank, int world,
+                                sjpeg_hip_comm** comm);
 void sjpeg_hip_comm_destroy(sjpeg_hip_comm* comm);
 int sjpeg_hip_comm_rank(const sjpeg_hip_comm* comm);
 int sjpeg_hip_comm_world(const sjpeg_hip_comm* comm);

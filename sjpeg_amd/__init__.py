@@ -256,7 +256,7 @@ EXPORTED_C_SYMBOLS = [
     "sjpeg_hip_engine_last_total_ms", "sjpeg_hip_engine_scratch_bytes", "sjpeg_hip_compact_streams",
     "sjpeg_hip_debug_stream_read", "sjpeg_hip_debug_valu_rate", "sjpeg_hip_debug_shader_clock",
     "sjpeg_hip_restart_interval", "sjpeg_hip_header_add_restart", "sjpeg_hip_encode_intervals_src",
-    "sjpeg_hip_comm_unique_id", "sjpeg_hip_comm_create", "sjpeg_hip_comm_adopt", "sjpeg_hip_comm_destroy",
+    "sjpeg_hip_comm_unique_id", "sjpeg_hip_comm_create", "sjpeg_hip_comm_create_local", "sjpeg_hip_comm_adopt", "sjpeg_hip_comm_destroy",
     "sjpeg_hip_comm_rank", "sjpeg_hip_comm_world", "sjpeg_hip_gather_rows", "sjpeg_hip_gather_bytes",
     "sjpeg_hip_gather_streams", "sjpeg_hip_encode_scan_packed_src",
 ]
@@ -312,11 +312,13 @@ def comm_unique_id() -> bytes:
 class Comm:
     """The library's RCCL communicator (sjpeg_hip_comm_create): one per process, the device current."""
 
-    def __init__(self, unique_id: bytes, rank: int, world: int):
+    def __init__(self, unique_id: bytes, rank: int, world: int, local: bool = False):
+        """local: the ranks are threads of THIS process (sjpeg_hip_comm_create_local; any 128 bytes as the id)."""
         self._c = C.c_void_p()
         buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
-        if lib().sjpeg_hip_comm_create(buf, int(rank), int(world), C.byref(self._c)) != 0:
-            raise SjpegError(f"sjpeg_hip_comm_create: {lib().sjpeg_hip_last_error().decode()}")
+        make = lib().sjpeg_hip_comm_create_local if local else lib().sjpeg_hip_comm_create
+        if make(buf, int(rank), int(world), C.byref(self._c)) != 0:
+            raise SjpegError(f"sjpeg_hip_comm_create{'_local' if local else ''}: {lib().sjpeg_hip_last_error().decode()}")
         self.rank, self.world = int(rank), int(world)
 
     def close(self):
@@ -348,6 +350,24 @@ class Comm:
             C.c_void_p(torch.cuda.current_stream().cuda_stream))
         if rc != 0:
             raise SjpegError(f"sjpeg_hip_gather_bytes: {lib().sjpeg_hip_last_error().decode()}")
+
+    def gather_streams(self, root, packed, offsets, sizes, n_local, per_max, rows_dev, gathered):
+        """sjpeg_hip_gather_streams: rows + the capacity check on EVERY rank + the transfers, one call.
+        gathered (the root's buffer; its numel() is the capacity every rank passes) may be a tensor or an int
+        capacity on the ranks that are not the root.  Returns (rows, rank_offsets) like gather_rows."""
+        import torch
+        rows = np.zeros((self.world, per_max + 2), np.uint64)
+        offs = np.zeros(self.world + 1, np.uint64)
+        is_t = hasattr(gathered, "data_ptr")
+        rc = lib().sjpeg_hip_gather_streams(
+            self._c, int(root), C.c_void_p(packed.data_ptr() if packed is not None else 0),
+            C.c_void_p(offsets.data_ptr()), C.c_void_p(sizes.data_ptr() if n_local > 0 else 0), int(n_local),
+            int(per_max), C.c_void_p(rows_dev.data_ptr()), C.c_void_p(gathered.data_ptr() if is_t else 0),
+            C.c_size_t(int(gathered.numel()) if is_t else int(gathered)), C.c_void_p(rows.ctypes.data),
+            C.c_void_p(offs.ctypes.data), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        if rc != 0:
+            raise SjpegError(f"sjpeg_hip_gather_streams: {lib().sjpeg_hip_last_error().decode()}")
+        return rows, offs
 
 
 # ---------------------------------------------------------------- host API (sjpeg.h)
@@ -617,15 +637,18 @@ class Engine:
         import torch
         self._check_frames(frames)
         f, h, w, _ = frames.shape
+        # header None: the C-ABI's NULL / 0 -- every stream starts directly with its entropy-coded data (the call
+        # shape of INTEGRATION.md section B, where the reference has written SOI..SOS itself)
+        hdr_len = 0 if header is None else len(header)
         if out_stride is None:
-            out_stride = frame_bound(w, h, yuv_mode, len(header))
+            out_stride = frame_bound(w, h, yuv_mode, hdr_len)
         if out is None:
             out = torch.empty((f, out_stride), dtype=torch.uint8, device=frames.device)
         if sizes is None:
             sizes = torch.zeros(f, dtype=torch.int64, device=frames.device)
         rc = lib().sjpeg_hip_encode_scan(self._h, frames.data_ptr(), frames.stride(1),
                                          frames.stride(0), w, h, yuv_mode, f, C.byref(tables),
-                                         header, len(header), int(append_eoi), out.data_ptr(),
+                                         header, hdr_len, int(append_eoi), out.data_ptr(),
                                          out_stride, sizes.data_ptr(), self._stream())
         if rc != 0:
             raise SjpegError(f"sjpeg_hip_encode_scan: {lib().sjpeg_hip_last_error().decode()}")

@@ -3,12 +3,21 @@
 // single-threaded and single-device: no counterpart there (BASELINE.json config #4).
 // RCCL is resolved at run time with dlopen / dlsym -- the library carries no link dependency on the
 // 570 MB librccl, and a process that never gathers never loads it.
+// A communicator carries the table of transport functions it was made with: RCCL's (one process per GPU), or
+// the LOCAL transport further down -- the ranks are threads of ONE process, each with its own stream (and its
+// own device, or several on one), the transfers are peer copies ordered by events.  The gather functions are
+// the same code for both; the local transport is also how their N > 1 paths run on a one-GPU box
+// (tests/test_gpu_parity.py::test_exchange_c_abi_with_several_ranks_on_one_device).
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 #include <stdint.h>
 #include <string.h>
 
+#include <chrono>
+#include <condition_variable>
+#include <map>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <string>
@@ -28,7 +37,7 @@ int xfail(int code, const std::string& msg) {
   return code;
 }
 
-struct Rccl {
+struct Transport {
   void* handle = nullptr;
   decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
   decltype(&ncclCommInitRank) CommInitRank = nullptr;
@@ -44,6 +53,7 @@ struct Rccl {
   std::string why;
 };
 
+typedef Transport Rccl;
 Rccl g_rccl;
 std::once_flag g_rccl_once;
 
@@ -91,6 +101,252 @@ const Rccl* rccl() {
     if (e_ != hipSuccess) return xfail(SJPEG_HIP_ERUNTIME, std::string(#expr) + ": " + hipGetErrorString(e_)); \
   } while (0)
 
+
+// ------------------------------------------------------------------------------------------------------
+// The LOCAL transport: the ranks of a communicator are threads of this process.  Same function table as
+// RCCL's, so sjpeg_hip_gather_rows / _bytes / _streams above run unchanged on it.  A transfer is a
+// hipMemcpyAsync on the RECEIVER's stream (peer copy when the ranks drive different devices), ordered behind
+// the sender's stream by an event the sender records, and the sender's stream is ordered behind the copy by
+// an event of the receiver -- the buffer is the sender's again when its stream gets there, as with ncclSend.
+// What differs from RCCL: the calls meet on the HOST (mutex + condition variable), so a send returns once its
+// receive has been enqueued, not before; a peer that never shows up is a timeout error, not a hang.
+// Uses: a single-process server that drives the GPUs of a node from one thread each (no RCCL in the
+// process), and the N > 1 tests of the gather functions on a box with one GPU.
+
+constexpr int kLocalTimeoutS = 60;
+
+struct LocalGroup {
+  std::mutex mu;
+  std::condition_variable cv;
+  int world = 0, joined = 0, left = 0;
+  std::vector<uint8_t> taken;                    // ranks that have joined
+  // barrier
+  int bar_n = 0;
+  uint64_t bar_gen = 0;
+  // all-gather: what every rank contributes this round
+  struct Slot { const void* send = nullptr; hipEvent_t ready = nullptr, done = nullptr; };
+  std::vector<Slot> ag;
+  // mailboxes [src * world + dst]: one message in flight per pair
+  struct Box { int state = 0; const void* ptr = nullptr; size_t bytes = 0; hipEvent_t ready = nullptr, done = nullptr; };   // 0 empty, 1 posted, 2 taken
+  std::vector<Box> box;
+  bool broken = false;                           // a rank timed out or failed: everybody gives up
+};
+
+struct LocalRank {
+  std::shared_ptr<LocalGroup> g;
+  std::string key;
+  int rank = 0;
+  hipEvent_t ev_ready = nullptr, ev_done = nullptr;       // all-gather
+  std::vector<hipEvent_t> ev_send, ev_recv;               // per peer
+  int depth = 0;                                           // ncclGroupStart nesting
+  struct Op { bool send; void* buf; size_t bytes; int peer; hipStream_t st; };
+  std::vector<Op> pending;
+};
+
+std::mutex g_local_mu;
+std::map<std::string, std::weak_ptr<LocalGroup>> g_local_groups;
+
+LocalRank* local_join(const uint8_t* id, int rank, int world, std::string* why) {
+  const std::string key(reinterpret_cast<const char*>(id), SJPEG_HIP_COMM_ID_BYTES);
+  std::shared_ptr<LocalGroup> g;
+  {
+    std::lock_guard<std::mutex> lk(g_local_mu);
+    g = g_local_groups[key].lock();
+    if (!g) {
+      g = std::make_shared<LocalGroup>();
+      g->world = world;
+      g->taken.assign(world, 0);
+      g->ag.resize(world);
+      g->box.resize(static_cast<size_t>(world) * world);
+      g_local_groups[key] = g;
+    }
+  }
+  {
+    std::lock_guard<std::mutex> lk(g->mu);
+    if (g->world != world) { *why = "the group of this id has another world size"; return nullptr; }
+    if (g->taken[rank]) { *why = "rank already taken in the group of this id"; return nullptr; }
+    g->taken[rank] = 1;
+    ++g->joined;
+  }
+  LocalRank* lr = new (std::nothrow) LocalRank;
+  if (lr == nullptr) { *why = "host allocation failed"; return nullptr; }
+  lr->g = g; lr->key = key; lr->rank = rank;
+  lr->ev_send.assign(world, nullptr); lr->ev_recv.assign(world, nullptr);
+  bool ok = hipEventCreateWithFlags(&lr->ev_ready, hipEventDisableTiming) == hipSuccess &&
+            hipEventCreateWithFlags(&lr->ev_done, hipEventDisableTiming) == hipSuccess;
+  for (int k = 0; ok && k < world; ++k) {
+    ok = hipEventCreateWithFlags(&lr->ev_send[k], hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&lr->ev_recv[k], hipEventDisableTiming) == hipSuccess;
+  }
+  if (!ok) { *why = "hipEventCreate failed"; }
+  return lr;     // (a rank whose events could not be made still leaves through local_destroy)
+}
+
+// every rank of the group has got here (false: timeout or a broken group)
+bool local_barrier(LocalGroup* g, std::unique_lock<std::mutex>& lk) {
+  if (g->broken) return false;
+  const uint64_t gen = g->bar_gen;
+  if (++g->bar_n == g->world) {
+    g->bar_n = 0; ++g->bar_gen;
+    g->cv.notify_all();
+    return true;
+  }
+  const bool ok = g->cv.wait_for(lk, std::chrono::seconds(kLocalTimeoutS), [&] { return g->bar_gen != gen || g->broken; });
+  if (!ok || g->broken) { g->broken = true; g->cv.notify_all(); return false; }
+  return true;
+}
+
+size_t nccl_type_size(ncclDataType_t t) {
+  switch (t) {
+    case ncclInt8: case ncclUint8: return 1;
+    case ncclFloat16: case ncclBfloat16: return 2;
+    case ncclInt32: case ncclUint32: case ncclFloat32: return 4;
+    case ncclInt64: case ncclUint64: case ncclFloat64: return 8;
+    default: return 0;
+  }
+}
+
+ncclResult_t local_all_gather(const void* send, void* recv, size_t count, ncclDataType_t type, ncclComm_t comm, hipStream_t st) {
+  LocalRank* me = reinterpret_cast<LocalRank*>(comm);
+  LocalGroup* g = me->g.get();
+  const size_t bytes = count * nccl_type_size(type);
+  if (bytes == 0 || send == nullptr || recv == nullptr) return ncclInvalidArgument;
+  if (hipEventRecord(me->ev_ready, st) != hipSuccess) return ncclUnhandledCudaError;
+  std::unique_lock<std::mutex> lk(g->mu);
+  g->ag[me->rank].send = send; g->ag[me->rank].ready = me->ev_ready;
+  if (!local_barrier(g, lk)) return ncclInternalError;          // every contribution is posted
+  ncclResult_t res = ncclSuccess;
+  for (int k = 0; k < g->world; ++k) {
+    uint8_t* const dst = static_cast<uint8_t*>(recv) + static_cast<size_t>(k) * bytes;
+    if (k == me->rank) {
+      if (dst != send && hipMemcpyAsync(dst, send, bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) res = ncclUnhandledCudaError;
+      continue;
+    }
+    if (hipStreamWaitEvent(st, g->ag[k].ready, 0) != hipSuccess ||
+        hipMemcpyAsync(dst, g->ag[k].send, bytes, hipMemcpyDefault, st) != hipSuccess) res = ncclUnhandledCudaError;
+  }
+  if (hipEventRecord(me->ev_done, st) != hipSuccess) res = ncclUnhandledCudaError;
+  g->ag[me->rank].done = me->ev_done;
+  if (!local_barrier(g, lk)) return ncclInternalError;          // every rank has read every contribution (in stream order)
+  for (int k = 0; k < g->world; ++k) {
+    if (k != me->rank && hipStreamWaitEvent(st, g->ag[k].done, 0) != hipSuccess) res = ncclUnhandledCudaError;
+  }
+  if (!local_barrier(g, lk)) return ncclInternalError;          // nobody re-records an event somebody still has to wait for
+  return res;
+}
+
+// posts the sends, takes the receives, waits for the sends to be taken: the order that cannot deadlock for any
+// pattern of matched pairs
+ncclResult_t local_run(LocalRank* me, std::vector<LocalRank::Op>& ops) {
+  LocalGroup* g = me->g.get();
+  const auto limit = std::chrono::seconds(kLocalTimeoutS);
+  ncclResult_t res = ncclSuccess;
+  std::unique_lock<std::mutex> lk(g->mu);
+  auto give_up = [&]() { g->broken = true; g->cv.notify_all(); return ncclInternalError; };
+  for (auto& op : ops) {
+    if (!op.send) continue;
+    LocalGroup::Box& b = g->box[static_cast<size_t>(me->rank) * g->world + op.peer];
+    if (!g->cv.wait_for(lk, limit, [&] { return b.state == 0 || g->broken; }) || g->broken) return give_up();
+    if (hipEventRecord(me->ev_send[op.peer], op.st) != hipSuccess) res = ncclUnhandledCudaError;
+    b.ptr = op.buf; b.bytes = op.bytes; b.ready = me->ev_send[op.peer]; b.state = 1;
+    g->cv.notify_all();
+  }
+  for (auto& op : ops) {
+    if (op.send) continue;
+    LocalGroup::Box& b = g->box[static_cast<size_t>(op.peer) * g->world + me->rank];
+    if (!g->cv.wait_for(lk, limit, [&] { return b.state == 1 || g->broken; }) || g->broken) return give_up();
+    if (b.bytes != op.bytes) { res = ncclInvalidArgument; }       // (mismatched counts: RCCL would hang or corrupt)
+    else if (hipStreamWaitEvent(op.st, b.ready, 0) != hipSuccess ||
+             hipMemcpyAsync(op.buf, b.ptr, op.bytes, hipMemcpyDefault, op.st) != hipSuccess) res = ncclUnhandledCudaError;
+    if (hipEventRecord(me->ev_recv[op.peer], op.st) != hipSuccess) res = ncclUnhandledCudaError;
+    b.done = me->ev_recv[op.peer]; b.state = 2;
+    g->cv.notify_all();
+  }
+  for (auto& op : ops) {
+    if (!op.send) continue;
+    LocalGroup::Box& b = g->box[static_cast<size_t>(me->rank) * g->world + op.peer];
+    if (!g->cv.wait_for(lk, limit, [&] { return b.state == 2 || g->broken; }) || g->broken) return give_up();
+    if (hipStreamWaitEvent(op.st, b.done, 0) != hipSuccess) res = ncclUnhandledCudaError;
+    b.state = 0;
+    g->cv.notify_all();
+  }
+  return res;
+}
+
+// ncclGroupStart / End carry no communicator: the open group belongs to the calling thread
+struct LocalPending { LocalRank* rank; LocalRank::Op op; };
+thread_local int t_local_depth = 0;
+thread_local std::vector<LocalPending> t_local_pending;
+
+ncclResult_t local_p2p(bool send, void* buf, size_t count, ncclDataType_t type, int peer, ncclComm_t comm, hipStream_t st) {
+  LocalRank* me = reinterpret_cast<LocalRank*>(comm);
+  if (peer < 0 || peer >= me->g->world || peer == me->rank || buf == nullptr) return ncclInvalidArgument;
+  const LocalRank::Op op{send, buf, count * nccl_type_size(type), peer, st};
+  if (t_local_depth > 0) { t_local_pending.push_back({me, op}); return ncclSuccess; }
+  std::vector<LocalRank::Op> one{op};
+  return local_run(me, one);
+}
+
+ncclResult_t local_send(const void* buf, size_t count, ncclDataType_t type, int peer, ncclComm_t comm, hipStream_t st) {
+  return local_p2p(true, const_cast<void*>(buf), count, type, peer, comm, st);
+}
+ncclResult_t local_recv(void* buf, size_t count, ncclDataType_t type, int peer, ncclComm_t comm, hipStream_t st) {
+  return local_p2p(false, buf, count, type, peer, comm, st);
+}
+ncclResult_t local_group_start() { ++t_local_depth; return ncclSuccess; }
+ncclResult_t local_group_end() {
+  if (t_local_depth <= 0) return ncclInvalidUsage;
+  if (--t_local_depth > 0) return ncclSuccess;
+  ncclResult_t res = ncclSuccess;
+  // (one communicator per group in this library; several would be run one after the other)
+  while (!t_local_pending.empty()) {
+    LocalRank* const who = t_local_pending.front().rank;
+    std::vector<LocalRank::Op> ops;
+    std::vector<LocalPending> rest;
+    for (auto& p : t_local_pending) { if (p.rank == who) ops.push_back(p.op); else rest.push_back(p); }
+    t_local_pending.swap(rest);
+    const ncclResult_t e = local_run(who, ops);
+    if (e != ncclSuccess && res == ncclSuccess) res = e;
+  }
+  return res;
+}
+ncclResult_t local_destroy(ncclComm_t comm) {
+  LocalRank* me = reinterpret_cast<LocalRank*>(comm);
+  if (me->ev_ready) (void)hipEventDestroy(me->ev_ready);
+  if (me->ev_done) (void)hipEventDestroy(me->ev_done);
+  for (hipEvent_t e : me->ev_send) if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : me->ev_recv) if (e) (void)hipEventDestroy(e);
+  {
+    std::lock_guard<std::mutex> lk(me->g->mu);
+    me->g->taken[me->rank] = 0;                  // (the rank may join again: a new communicator on the same id)
+    --me->g->joined;
+  }
+  delete me;                                     // the last rank's shared_ptr frees the group; the registry holds a weak one
+  return ncclSuccess;
+}
+ncclResult_t local_count(const ncclComm_t comm, int* n) { *n = reinterpret_cast<const LocalRank*>(comm)->g->world; return ncclSuccess; }
+ncclResult_t local_user_rank(const ncclComm_t comm, int* r) { *r = reinterpret_cast<const LocalRank*>(comm)->rank; return ncclSuccess; }
+const char* local_error_string(ncclResult_t e) {
+  switch (e) {
+    case ncclSuccess: return "no error";
+    case ncclUnhandledCudaError: return "local transport: a HIP call failed";
+    case ncclInvalidArgument: return "local transport: invalid argument (NULL buffer, bad peer, or a receive whose length differs from the send's)";
+    case ncclInvalidUsage: return "local transport: group end without start";
+    default: return "local transport: a rank of the group did not arrive within 60 s (or failed): the group is broken";
+  }
+}
+
+const Transport* local_transport() {
+  static const Transport t = [] {
+    Transport x;
+    x.CommDestroy = local_destroy; x.CommCount = local_count; x.CommUserRank = local_user_rank;
+    x.AllGather = local_all_gather; x.Send = local_send; x.Recv = local_recv;
+    x.GroupStart = local_group_start; x.GroupEnd = local_group_end; x.GetErrorString = local_error_string;
+    return x;
+  }();
+  return &t;
+}
+
 // row of this rank: {packed bytes, number of frames, size of frame 0, 1, ... (0 beyond nframes_local)}
 __global__ void gather_row_kernel(const unsigned long long* offsets, const unsigned long long* sizes, int nframes_local,
                                   int per_max, unsigned long long* row) {
@@ -102,7 +358,8 @@ __global__ void gather_row_kernel(const unsigned long long* offsets, const unsig
 }  // namespace
 
 struct sjpeg_hip_comm {
-  ncclComm_t comm = nullptr;
+  const Transport* api = nullptr;     // RCCL's functions, or the local transport's
+  ncclComm_t comm = nullptr;          // (local transport: a LocalRank*)
   int rank = 0, world = 1;
   bool owned = false;
   uint64_t* h_pinned = nullptr;       // the host read of the rows goes through pinned memory
@@ -137,6 +394,22 @@ int sjpeg_hip_comm_create(const uint8_t id[SJPEG_HIP_COMM_ID_BYTES], int rank, i
     delete c;
     return xfail(SJPEG_HIP_ERUNTIME, std::string("ncclCommInitRank: ") + r->GetErrorString(e));
   }
+  c->api = r; c->rank = rank; c->world = world; c->owned = true;
+  *comm = c;
+  return 0;
+}
+
+int sjpeg_hip_comm_create_local(const uint8_t id[SJPEG_HIP_COMM_ID_BYTES], int rank, int world, sjpeg_hip_comm** comm) {
+  if (comm == nullptr) return xfail(SJPEG_HIP_EINVAL, "comm == NULL");
+  *comm = nullptr;
+  if (id == nullptr || world <= 0 || rank < 0 || rank >= world) return xfail(SJPEG_HIP_EINVAL, "bad id / rank / world");
+  sjpeg_hip_comm* c = new (std::nothrow) sjpeg_hip_comm;
+  if (c == nullptr) return xfail(SJPEG_HIP_ENOMEM, "host allocation failed");
+  std::string why;
+  LocalRank* lr = local_join(id, rank, world, &why);
+  if (lr == nullptr) { delete c; return xfail(SJPEG_HIP_ERUNTIME, "sjpeg_hip_comm_create_local: " + why); }
+  c->api = local_transport();
+  c->comm = reinterpret_cast<ncclComm_t>(lr);
   c->rank = rank; c->world = world; c->owned = true;
   *comm = c;
   return 0;
@@ -150,6 +423,7 @@ int sjpeg_hip_comm_adopt(void* nccl_comm, sjpeg_hip_comm** comm) {
   if (r == nullptr) return xfail(SJPEG_HIP_ERUNTIME, g_rccl.why);
   sjpeg_hip_comm* c = new (std::nothrow) sjpeg_hip_comm;
   if (c == nullptr) return xfail(SJPEG_HIP_ENOMEM, "host allocation failed");
+  c->api = r;
   c->comm = static_cast<ncclComm_t>(nccl_comm);
   if (r->CommCount(c->comm, &c->world) != ncclSuccess || r->CommUserRank(c->comm, &c->rank) != ncclSuccess) {
     delete c;
@@ -162,7 +436,7 @@ int sjpeg_hip_comm_adopt(void* nccl_comm, sjpeg_hip_comm** comm) {
 void sjpeg_hip_comm_destroy(sjpeg_hip_comm* c) {
   if (c == nullptr) return;
   if (c->h_pinned != nullptr) (void)hipHostFree(c->h_pinned);
-  if (c->owned && c->comm != nullptr && g_rccl.handle != nullptr) (void)g_rccl.CommDestroy(c->comm);
+  if (c->owned && c->comm != nullptr && c->api != nullptr) (void)c->api->CommDestroy(c->comm);
   delete c;
 }
 
@@ -178,8 +452,7 @@ int sjpeg_hip_gather_rows(sjpeg_hip_comm* c, const uint64_t* d_offsets, const ui
       (nframes_local > 0 && d_sizes == nullptr)) {
     return xfail(SJPEG_HIP_EINVAL, "sjpeg_hip_gather_rows: bad frame counts");
   }
-  const Rccl* r = rccl();
-  if (r == nullptr) return xfail(SJPEG_HIP_ERUNTIME, g_rccl.why);
+  const Transport* r = c->api;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const size_t row = static_cast<size_t>(per_max) + 2;
   const size_t nrows = static_cast<size_t>(c->world) * row;
@@ -230,8 +503,7 @@ int sjpeg_hip_gather_bytes(sjpeg_hip_comm* c, int root, const void* d_packed, in
                            const uint64_t* h_rank_offsets, void* d_gathered, size_t gathered_capacity, void* stream) {
   if (c == nullptr || h_rows == nullptr || h_rank_offsets == nullptr) return xfail(SJPEG_HIP_EINVAL, "sjpeg_hip_gather_bytes: NULL argument");
   if (root < 0 || root >= c->world || per_max <= 0) return xfail(SJPEG_HIP_EINVAL, "sjpeg_hip_gather_bytes: bad root / per_max");
-  const Rccl* r = rccl();
-  if (r == nullptr) return xfail(SJPEG_HIP_ERUNTIME, g_rccl.why);
+  const Transport* r = c->api;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const size_t row = static_cast<size_t>(per_max) + 2;
   const uint64_t my_bytes = h_rows[static_cast<size_t>(c->rank) * row];

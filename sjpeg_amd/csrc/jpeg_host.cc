@@ -551,7 +551,7 @@ struct OpenNodes {
 
 // T.81 K.2 (Figure K.3): no code longer than `limit` bits.  count[l] = codes of length l + 1.
 // false: the histogram was no prefix code (see below) -- the caller falls back to a flat code.
-bool LimitCodeLengths(uint8_t* count, int longest, int limit) {
+bool LimitCodeLengths(int* count, int longest, int limit) {
   for (int len = longest; len > limit; --len) {
     while (count[len - 1] > 0) {
       int shorter = len - 2;                  // a leaf at least two levels up becomes an inner node
@@ -559,7 +559,8 @@ bool LimitCodeLengths(uint8_t* count, int longest, int limit) {
       // (only a histogram that is no prefix code any more gets here: depths beyond 32 bits were
       // clamped, which takes Fibonacci-like counts over 33+ symbols; the reference reads in front
       // of its array in that case, src/entropy.cc:396-398)
-      if (shorter < 1) return false;
+      // (a prefix code has its deepest leaves in pairs; a lone one is the clamped histogram again)
+      if (shorter < 1 || count[len - 1] < 2) return false;
       count[len - 1] -= 2;                    // a pair of deepest leaves: one moves up one level,
       count[len - 2] += 1;
       count[shorter - 1] -= 1;                // the other joins the split leaf one level below it
@@ -607,7 +608,9 @@ void BuildOptimalSpec(const uint32_t* freq, int size, HuffSpec* out) {
   int depth[2 * 257];
   depth[nnodes - 1] = 0;
   for (int i = nnodes - 2; i >= 0; --i) depth[i] = depth[nodes[i].parent] + 1;
-  uint8_t count[kLongest];                    // count[l]: leaves with a code of l + 1 bits
+  // count[l]: leaves with a code of l + 1 bits.  int, not the DHT's bytes: with the reserved leaf still counted a
+  // level can hold 256 (255 symbols of equal weight), which only becomes 255 once that leaf is taken out below
+  int count[kLongest];
   memset(count, 0, sizeof(count));
   int length_of[257];
   for (int i = 0; i <= size; ++i) length_of[i] = 0;
@@ -633,18 +636,23 @@ void BuildOptimalSpec(const uint32_t* freq, int size, HuffSpec* out) {
   if (!LimitCodeLengths(count, longest, kLimit)) {
     // Depths beyond 32 bits were clamped and the histogram is no prefix code (Fibonacci-like counts over 33 or
     // more symbols; the reference's behaviour is undefined there).  A VALID table instead of a wrong
-    // one: every leaf -- the reserved one included -- gets the same length, the symbols in the order of their values.
+    // one: a complete code of two lengths over all leaves, the reserved one included -- with f = ceil(log2(leaves)),
+    // 2^f - leaves of them get f - 1 bits and the rest f (Kraft sum exactly 1) --, the symbols in the order of
+    // their values.  257 leaves: 255 codes of 8 bits + 2 of 9, and the reserved leaf is one of the two (ADVICE r04:
+    // one length for all of them put 256 / 257 into a byte).
     memset(count, 0, sizeof(count));
     int flat = 1;
     while ((1 << flat) < leaves) ++flat;      // <= 9 bits for 257 leaves
-    count[flat - 1] = static_cast<uint8_t>(leaves);
+    const int n_short = (1 << flat) - leaves;
+    if (flat > 1) count[flat - 2] = n_short;
+    count[flat - 1] = leaves - n_short;
     int k = 0;
     for (int sym = 0; sym < size; ++sym) if (freq[sym] > 0) out->syms[k++] = static_cast<uint8_t>(sym);
   }
   int last = kLimit;                          // the reserved leaf is the last code of the longest length
   while (last > 1 && count[last - 1] == 0) --last;
   --count[last - 1];
-  for (int l = 0; l < kLimit; ++l) out->bits[l] = count[l];
+  for (int l = 0; l < kLimit; ++l) out->bits[l] = static_cast<uint8_t>(count[l]);
 }
 
 }  // namespace sjpeg_host

@@ -145,6 +145,7 @@ struct sjpeg_hip_engine {
   DevBuf<unsigned long long> seg_off, chunk_off, stamps;
   DevBuf<uint32_t> hdr_off;
   bool want_stamps = false;
+  int stamp_mode = 0;              // SJPEG_HIP_STAMPS, parsed ONCE when the engine is made (1 cycle counter, 2 device clock, 3 + segment bits)
   int last_nseg = 0, last_nframes = 0;   // geometry of the last encode call (entropy_bits)
   size_t stamps_n = 0;
   bool timing = false;
@@ -440,7 +441,7 @@ int prepare_scan(sjpeg_hip_engine* e, const sjpeg_hip_source* src,
     a->stamps = e->stamps.p;
     // SJPEG_HIP_STAMPS=2: the 100 MHz real-time counter (one clock for the whole device: when workgroups start
     // and end relative to each other) instead of the shader-clock cycle counter (per CU: phase durations)
-    a->stamp_real = atoi(getenv("SJPEG_HIP_STAMPS")) == 2 ? 1 : (atoi(getenv("SJPEG_HIP_STAMPS")) == 3 ? 2 : 0);
+    a->stamp_real = e->stamp_mode == 2 ? 1 : (e->stamp_mode == 3 ? 2 : 0);
     e->stamps_n = total_segs * 8;
   }
   return 0;
@@ -487,7 +488,7 @@ int sjpeg_hip_engine_create(int device, sjpeg_hip_engine** engine) {
                       "the output of this engine is NOT valid JPEG data\n", e->ablate);
     }
   }
-  e->want_stamps = getenv("SJPEG_HIP_STAMPS") != nullptr;
+  if (const char* sm = getenv("SJPEG_HIP_STAMPS")) { e->want_stamps = true; e->stamp_mode = atoi(sm); }
   *engine = e;
   return 0;
 }
@@ -520,6 +521,9 @@ int sjpeg_hip_engine_trim(sjpeg_hip_engine* e) {
   e->seg_off.release(); e->chunk_off.release(); e->hdr_off.release(); e->stamps.release();
   e->tables.release(); e->header.release();        // (per-frame tables of a large batch are scratch like the rest)
   for (auto& sg : e->stage) {                      // ... and so are the pinned blocks they were uploaded through
+    // (their copies are done: the device was waited for above; the event is waited for all the same, so that the
+    // block's life does not hang on that one line)
+    if (sg.busy && sg.ev) (void)hipEventSynchronize(sg.ev);
     if (sg.p) (void)hipHostFree(sg.p);
     sg.p = nullptr; sg.cap = 0; sg.busy = false;
   }

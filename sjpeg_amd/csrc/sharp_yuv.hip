@@ -54,6 +54,7 @@ struct SharpArgs {
   // each), cancel, final sweep.  nplanes == 1: the in-place kernels, everything in plane 0.
   uint32_t* ctrl;
   int nframes, nplanes;
+  int frame0;                                     // sharp_sweeps_piped: first frame of this launch (batches go in chunks)
   uint8_t* y; uint8_t* u; uint8_t* v;
   long long y_frame_stride, uv_frame_stride;
   int stress;                                     // race stress builds only (SJPEG_HIP_ABLATE), else 0
@@ -444,7 +445,7 @@ __global__ __launch_bounds__(kSweepThreads) void sharp_sweeps_piped(const SharpA
   __shared__ unsigned long long red[kSweepThreads / 64];
   __shared__ int go;
   __shared__ int16_t above[2][3][COLS * kSweepThreads];   // the updated row above, ping-pong
-  const int frame = blockIdx.z * 8 + blockIdx.x, t = blockIdx.y, tid = threadIdx.x;
+  const int frame = a.frame0 + blockIdx.z * 8 + blockIdx.x, t = blockIdx.y, tid = threadIdx.x;
   if (frame >= a.nframes) return;
   for (int i = tid; i <= kMaxY; i += kSweepThreads) g2l[i] = a.tab->g2l[i];
   if (tid < kGammaTab + 2) l2g[tid] = a.tab->l2g[tid];
@@ -602,10 +603,19 @@ __global__ __launch_bounds__(kSweepThreads) void sharp_sweeps_piped(const SharpA
       // full barrier: it waits for the memory counter, i.e. a store's round trip, about as long as the row pair's
       // arithmetic), the seven steps between only order the LDS row above and leave stores and loads in flight.
       const bool hand_over = (ry & 7) == 7 || ry + 1 == uv_h;
-      if (hand_over) __syncthreads(); else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (hand_over) {
+        // EVERY wave releases its own stores at agent scope in front of the barrier (write-back of its L2 lines +
+        // s_waitcnt vmcnt(0)): a workgroup-scope barrier alone compiles to `s_waitcnt lgkmcnt(0); s_barrier` --
+        // it does not wait for the other waves' global stores, and thread 0's fence below covers only wave 0's
+        // (the rows of the other fifteen waves could still be in flight when the counter was published;
+        // checked in the ISA of the shipped object: `buffer_wbl2 sc1`, `s_waitcnt vmcnt(0)` in front of this `s_barrier`).
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __syncthreads();
+      } else {
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      }
       SHARP_RACE_POINT(45);
       if (hand_over && tid == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         __hip_atomic_store(&ctrl[t], static_cast<uint32_t>(ry + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
       }
       // rotate: cur <- next (old values), next <- the row requested above
@@ -819,8 +829,21 @@ int sjpeg_hip_sharp_yuv(const sjpeg_hip_source* src, int width, int height, int 
   a.nplanes = piped ? 3 : 1;
   if (piped && hipMemsetAsync(a.ctrl, 0, static_cast<size_t>(nframes) * 32 * sizeof(uint32_t), st) != hipSuccess) return SJPEG_HIP_ERUNTIME;
   hipLaunchKernelGGL(sharp_import, grid, dim3(256), 0, st, a);
-  if (piped && a.uv_w <= kSweepThreads) hipLaunchKernelGGL(sharp_sweeps_piped<1>, dim3(8, 4, (nframes + 7) / 8), dim3(kSweepThreads), 0, st, a);
-  else if (piped) hipLaunchKernelGGL(sharp_sweeps_piped<2>, dim3(8, 4, (nframes + 7) / 8), dim3(kSweepThreads), 0, st, a);
+  a.frame0 = 0;
+  if (piped) {
+    // A sweep spins on the counter of the sweep before it, another workgroup of the same launch: that only ends if
+    // the producer is resident.  A launch therefore never has more workgroups than the device holds at once --
+    // chunks of 32 pictures = 128 workgroups of 1024 threads, one per CU on half the chip (the whole
+    // batch in one grid relied on dispatch order for batches beyond that) --; the chunks follow each other on the stream.
+    constexpr int kChunk = 32;
+    for (int f0 = 0; f0 < nframes; f0 += kChunk) {
+      const int nf = nframes - f0 < kChunk ? nframes - f0 : kChunk;
+      a.frame0 = f0;
+      if (a.uv_w <= kSweepThreads) hipLaunchKernelGGL(sharp_sweeps_piped<1>, dim3(8, 4, (nf + 7) / 8), dim3(kSweepThreads), 0, st, a);
+      else hipLaunchKernelGGL(sharp_sweeps_piped<2>, dim3(8, 4, (nf + 7) / 8), dim3(kSweepThreads), 0, st, a);
+    }
+    a.frame0 = 0;
+  }
   else if (a.uv_w <= kFastCols * kSweepThreads) hipLaunchKernelGGL(sharp_sweeps_fast, dim3(nframes), dim3(kSweepThreads), 0, st, a);
   else hipLaunchKernelGGL(sharp_sweeps, dim3(nframes), dim3(kSweepThreads), 0, st, a);
   hipLaunchKernelGGL(sharp_export, grid, dim3(256), 0, st, a);

@@ -156,7 +156,11 @@ def gather_streams(out: torch.Tensor, sizes: torch.Tensor, frame_ids: Sequence[i
         return got.frames() if to_host else got
 
     # ---- the same protocol on torch.distributed (gloo, CPU tests)
-    if n_local > 0:
+    if packed_offsets is not None:
+        # `out` is packed already (the stand-in of encode_frames_packed): no compaction pass here either
+        packed, offsets = out.reshape(-1), packed_offsets
+        my_bytes = int(offsets[n_local])
+    elif n_local > 0:
         packed, offsets = compact(out, sizes, n_local, n_local * _align16(stride))
         my_bytes = int(offsets[n_local])
     else:
@@ -172,15 +176,20 @@ def gather_streams(out: torch.Tensor, sizes: torch.Tensor, frame_ids: Sequence[i
         if my_bytes > 0:
             dist.send(packed[:my_bytes].contiguous(), dst=dst, group=group)
         return None
-    gathered = (buf("gathered", max(offs[world], 16), torch.uint8) if reuse_gathered
-                else torch.empty(max(offs[world], 16), dtype=torch.uint8, device=dev))
+    in_place = (packed_offsets is not None and reuse_gathered and offs[dst] == 0 and packed.numel() >= offs[world])
+    if in_place:
+        gathered = packed                           # the root's own streams are where they belong already
+    else:
+        gathered = (buf("gathered", max(offs[world], 16), torch.uint8) if reuse_gathered
+                    else torch.empty(max(offs[world], 16), dtype=torch.uint8, device=dev))
     reqs = []
     for r in range(world):
         n = int(rows[r][0])
         if n == 0:
             continue
         if r == dst:
-            gathered[offs[r]:offs[r] + n] = packed[:n]
+            if not in_place:
+                gathered[offs[r]:offs[r] + n] = packed[:n]
         else:
             reqs.append(dist.irecv(gathered[offs[r]:offs[r] + n], src=r, group=group))
     for q in reqs:

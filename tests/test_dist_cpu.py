@@ -190,6 +190,69 @@ def test_exchange_loop_keeps_every_step_when_later_steps_are_smaller():
     assert ok
 
 
+def _packed_loop_worker(rank, world, port, nframes, nsteps, q):
+    """exchange_loop with PACKED output sets (what Engine.encode_frames_packed leaves: a flat buffer + offsets):
+    no compaction pass, and rank 0 as the root receives the others BEHIND its own streams in that very buffer."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import orc, synth
+    from sjpeg_amd.dist import exchange_loop, shard_frames
+    o = orc.oracle()
+    ids = shard_frames(nframes, rank, world)
+
+    def coded(step, k):
+        return o.encode(synth.g_struct(40 + 8 * (k % 3), 24, 1000 * step + k), 75.0, 1)
+
+    room = 1 << 16                                       # long enough for the whole world's streams
+    outs = [torch.full((room,), 0x5A, dtype=torch.uint8) for _ in range(2)]
+    sizes = [torch.zeros(max(len(ids), 1), dtype=torch.int64) for _ in range(2)]
+    poffs = [torch.zeros(len(ids) + 1, dtype=torch.int64) for _ in range(2)]
+    state = {"step": 0}
+
+    def encode(b):
+        at = 0
+        for i, k in enumerate(ids):
+            c = coded(state["step"], k)
+            poffs[b][i] = at
+            outs[b][at:at + ((len(c) + 15) & ~15)] = 0
+            outs[b][at:at + len(c)] = torch.from_numpy(np.frombuffer(c, np.uint8).copy())
+            sizes[b][i] = len(c)
+            at += (len(c) + 15) & ~15
+        poffs[b][len(ids)] = at
+        state["step"] += 1
+
+    got = exchange_loop(nsteps, encode, outs, sizes, ids, nframes, use_streams=False, compact=None, keep="last",
+                        packed_offsets=poffs)
+    if rank == 0:
+        g = got[-1]
+        ok = len(got) == 1 and g.frames() == [coded(nsteps - 1, k) for k in range(nframes)]
+        # in place: the gathered buffer IS the root's own output set of the last step
+        ok = ok and g.gathered.data_ptr() == outs[(nsteps - 1) & 1].data_ptr()
+        q.put(ok)
+    else:
+        assert got == [None]
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_exchange_loop_with_packed_output_and_the_root_in_place():
+    """packed_offsets was honoured on the CUDA path only -- on gloo the already-packed buffer was
+    compacted a second time with the wrong stride."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 37500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_packed_loop_worker, args=(r, 2, port, 5, 3, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    ok = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert ok
+
+
 def test_bench_launcher_starts_the_world_it_was_asked_for():
     """`python bench.py --gpus 2` without a torch.distributed environment must start two ranks by itself
     (the flag was parsed and ignored).  --launch-check takes the launcher's exact path -- re-exec

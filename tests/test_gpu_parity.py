@@ -1518,3 +1518,219 @@ def test_exchange_of_packed_output_and_the_overflow_flag(engine, oracle):
             comm.gather_rows(offs_s, sizes_s, nf, nf, rows_dev)
     finally:
         comm.close()
+
+
+def _sos_end(jpeg: bytes) -> int:
+    """Offset of the first entropy-coded byte: behind the SOS segment (marker walk from the SOI)."""
+    assert jpeg[:2] == b"\xff\xd8"
+    at = 2
+    while True:
+        assert jpeg[at] == 0xFF, at
+        marker = jpeg[at + 1]
+        seg = (jpeg[at + 2] << 8) | jpeg[at + 3]
+        at += 2 + seg
+        if marker == 0xDA:
+            return at
+
+
+def test_headerless_segment_is_the_binding_of_integration_md(engine, golden_small, digests):
+    """the reference keeps WriteSOS / WriteEOI (src/headers.cc:242-268) and replaces
+    SinglePassScan() (src/enc.cc:437-443) by sjpeg_hip_encode_scan(header = NULL, 0, append_eoi = 0).  What that
+    call returns must be exactly the reference file's bytes between the end of the SOS segment and the EOI marker
+    -- stuffed, padded with 1-bits --, and the reference-written header + that segment + FF D9 the reference file.
+    Reference bytes: tests/golden/small.npz (every geometry incl. the clipped ones, three colour modes)."""
+    n = 0
+    for key, want in golden_small.items():
+        img, mode, q, method = golden_input(key)
+        if method != 0:
+            continue
+        h, w = img.shape[:2]
+        t, quant = sj.make_tables(quality=q)
+        cut = _sos_end(want)
+        assert want[-2:] == b"\xff\xd9"
+        out, sizes = engine.encode_frames(dev(img), t, None, mode, append_eoi=False)
+        torch.cuda.synchronize()
+        seg = bytes(out[0, :int(sizes[0])].cpu().numpy())
+        assert seg == want[cut:-2], key
+        assert want[:cut] + seg + b"\xff\xd9" == want
+        # the two halves one at a time: header without EOI, EOI without header
+        out, sizes = engine.encode_frames(dev(img), t, want[:cut], mode, append_eoi=False)
+        torch.cuda.synchronize()
+        assert bytes(out[0, :int(sizes[0])].cpu().numpy()) == want[:-2], key
+        out, sizes = engine.encode_frames(dev(img), t, None, mode, append_eoi=True)
+        torch.cuda.synchronize()
+        assert bytes(out[0, :int(sizes[0])].cpu().numpy()) == want[cut:], key
+        n += 1
+    assert n >= 180
+    # a batch at full size, 1080p: clipped last MCU row (SURVEY section 0 fact 9), frames 0 and 1 of config #4
+    frames = np.stack([synth.g_struct(1920, 1080, 7654321 + k) for k in range(2)])
+    t, quant = sj.make_tables(quality=75.0)
+    header = sj.make_header(1920, 1080, 1, quant)
+    out, sizes = engine.encode_frames(torch.from_numpy(frames).cuda(), t, None, 1, append_eoi=False)
+    torch.cuda.synchronize()
+    for k in range(2):
+        seg = bytes(out[k, :int(sizes[k])].cpu().numpy())
+        whole = header + seg + b"\xff\xd9"
+        assert hashlib.md5(whole).hexdigest() == digests[f"struct1080p_k{k}|420|q75|m0"]["md5"]
+
+
+def _local_world(world, body):
+    """Runs body(rank, comm) on `world` threads, every one with its own stream and a communicator of the LOCAL
+    transport (sjpeg_hip_comm_create_local: the ranks are threads of this process, on this one device).
+    Returns the per-rank results; an exception of any rank is re-raised here."""
+    ident = os.urandom(128)
+    results, errors = [None] * world, [None] * world
+
+    def run(r):
+        try:
+            torch.cuda.set_device(0)
+            with torch.cuda.stream(torch.cuda.Stream()):
+                comm = sj.Comm(ident, r, world, local=True)
+                try:
+                    results[r] = body(r, comm)
+                    torch.cuda.current_stream().synchronize()
+                finally:
+                    comm.close()
+        except BaseException as e:          # noqa: BLE001 -- handed to the main thread
+            errors[r] = e
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+        assert not t.is_alive(), "a rank of the local world hangs"
+    return results, errors
+
+
+@pytest.mark.parametrize("world,nframes,root", [(2, 7, 0), (3, 7, 0), (3, 8, 2), (2, 5, 1), (3, 2, 1), (3, 1, 0)])
+def test_exchange_c_abi_with_several_ranks_on_one_device(oracle, world, nframes, root):
+    """sjpeg_hip_gather_rows / _bytes / _streams with MORE THAN ONE rank (VERDICT r04 missing #1): their N > 1
+    code -- per-rank receive offsets, grouped receives of exact lengths, the root that codes in place, a root that
+    is not rank 0, ragged ranks, a rank with no frame at all -- on the local transport, the ranks being threads
+    with a stream and an engine each.  Frame k is coded by rank k % world (sjpeg_amd.dist.shard_frames); the
+    gathered buffer must be, byte for byte, what the gloo twin of the protocol (sjpeg_amd/dist.py, checked by
+    tests/test_dist_cpu.py) holds: every rank's packed block -- its frames at multiples of 16, zero padding --
+    in rank order, without gaps.  Reference: none (no communication backend)."""
+    from sjpeg_amd.dist import shard_frames
+    from test_dist_cpu import _compact_torch
+    w, h, q = 200, 120, 75.0
+    imgs = [synth.g_struct(w + 0, h, 4000 + k) if k % 3 else synth.g_noise(w, h, 4000 + k) for k in range(nframes)]
+    want_frames = [oracle.encode(im, q, 1) for im in imgs]
+    per_max = (nframes + world - 1) // world
+    tables, quant = sj.make_tables(quality=q)
+    header = sj.make_header(w, h, sj.YUV_420, quant)
+    stride = sj.frame_bound(w, h, sj.YUV_420, len(header))
+    # the twin's buffer, from the oracle's bytes
+    blocks = []
+    for r in range(world):
+        ids = shard_frames(nframes, r, world)
+        if not ids:
+            blocks.append(b"")
+            continue
+        out = torch.zeros((len(ids), stride), dtype=torch.uint8)
+        sz = torch.tensor([len(want_frames[k]) for k in ids], dtype=torch.int64)
+        for i, k in enumerate(ids):
+            out[i, :len(want_frames[k])] = torch.from_numpy(np.frombuffer(want_frames[k], np.uint8).copy())
+        need = int(((sz + 15) & ~15).sum())
+        blocks.append(_compact_torch(out, sz, len(ids), need)[0].numpy().tobytes())
+    want = b"".join(blocks)
+
+    def body(rank, comm, in_place, one_call):
+        ids = shard_frames(nframes, rank, world)
+        n_local = len(ids)
+        eng = sj.Engine(0)
+        # the root that is rank 0 may code straight into the buffer the others are received behind
+        cap = len(want) + 64
+        room = max(n_local, 1) * stride + (cap if (in_place and rank == root) else 0)
+        flat = torch.full((room,), 0x5A, dtype=torch.uint8, device="cuda")
+        sizes = torch.zeros(max(n_local, 1), dtype=torch.int64, device="cuda")
+        offs = torch.zeros(per_max + 1, dtype=torch.int64, device="cuda")
+        if n_local:
+            frames = torch.from_numpy(np.stack([imgs[k] for k in ids])).cuda()
+            eng.encode_frames_packed(frames, tables, header, sj.YUV_420, flat, sizes, offs[:n_local + 1], stride)
+        rows_dev = torch.zeros((world + 1) * (per_max + 2), dtype=torch.int64, device="cuda")
+        if one_call:
+            gathered = torch.full((cap,), 0xC3, dtype=torch.uint8, device="cuda") if rank == root else cap
+            rows, ro = comm.gather_streams(root, flat, offs, sizes, n_local, per_max, rows_dev, gathered)
+        else:
+            rows, ro = comm.gather_rows(offs, sizes, n_local, per_max, rows_dev)
+            assert int(ro[world]) == len(want)
+            gathered = None
+            if rank == root:
+                gathered = flat if in_place else torch.full((int(ro[world]),), 0xC3, dtype=torch.uint8, device="cuda")
+            comm.gather_bytes(root, flat, per_max, rows, ro, gathered)
+        torch.cuda.current_stream().synchronize()
+        # every rank has the same rows: sizes of every frame of every rank
+        for r in range(world):
+            rids = shard_frames(nframes, r, world)
+            assert int(rows[r][1]) == len(rids) and [int(v) for v in rows[r][2:2 + len(rids)]] == [len(want_frames[k]) for k in rids]
+            assert int(ro[r]) == sum(len(b) for b in blocks[:r])
+        if rank != root:
+            return None
+        return gathered[:len(want)].cpu().numpy().tobytes()
+
+    for in_place, one_call in ((False, False), (True, False), (False, True)):
+        if in_place and root != 0:
+            continue                                  # (only a root whose block comes first can code in place)
+        results, errors = _local_world(world, lambda r, c: body(r, c, in_place, one_call))
+        assert errors == [None] * world, errors
+        assert results[root] == want, (in_place, one_call)
+        assert all(results[r] is None for r in range(world) if r != root)
+    # the frames, out of the gathered buffer, against the oracle (what a consumer does with rows + offsets)
+    o = 0
+    for r in range(world):
+        for k in shard_frames(nframes, r, world):
+            assert want[o:o + len(want_frames[k])] == want_frames[k]
+            o += (len(want_frames[k]) + 15) & ~15
+
+
+def test_exchange_refusals_reach_every_rank_of_a_local_world(oracle):
+    """Three ranks: (a) one frame of rank 1 does not fit its output slot (size 0) -- sjpeg_hip_gather_rows returns
+    SJPEG_HIP_ECAPACITY on EVERY rank, nothing is sent, nobody waits; (b) the root's capacity is too small for the
+    total -- sjpeg_hip_gather_streams refuses on every rank before anybody sends; (c) the same communicators then
+    do a good exchange: a refusal leaves no message behind."""
+    from sjpeg_amd.dist import shard_frames
+    world, nframes, root = 3, 6, 0
+    w, h, q = 200, 120, 75.0
+    imgs = [synth.g_struct(w, h, 5000 + k) for k in range(nframes)]
+    imgs[4] = synth.g_noise(w, h, 5004)                                     # rank 1's second frame: three times the bytes
+    want_frames = [oracle.encode(im, q, 1) for im in imgs]
+    tables, quant = sj.make_tables(quality=q)
+    header = sj.make_header(w, h, sj.YUV_420, quant)
+    per_max = 2
+    tight = (max(len(want_frames[k]) for k in range(nframes) if k != 4) + 64 + 15) & ~15
+    assert tight < len(want_frames[4])
+    full = sj.frame_bound(w, h, sj.YUV_420, len(header))
+    total = sum((len(f) + 15) & ~15 for f in want_frames)
+
+    def body(rank, comm):
+        ids = shard_frames(nframes, rank, world)
+        eng = sj.Engine(0)
+        frames = torch.from_numpy(np.stack([imgs[k] for k in ids])).cuda()
+        log = []
+        for stride, cap in ((tight, total), (full, total - 16), (full, total)):
+            flat = torch.zeros(len(ids) * stride, dtype=torch.uint8, device="cuda")
+            sizes = torch.zeros(len(ids), dtype=torch.int64, device="cuda")
+            offs = torch.zeros(per_max + 1, dtype=torch.int64, device="cuda")
+            eng.encode_frames_packed(frames, tables, header, sj.YUV_420, flat, sizes, offs, stride)
+            rows_dev = torch.zeros((world + 1) * (per_max + 2), dtype=torch.int64, device="cuda")
+            gathered = torch.zeros(cap, dtype=torch.uint8, device="cuda") if rank == root else cap
+            try:
+                comm.gather_streams(root, flat, offs, sizes, len(ids), per_max, rows_dev, gathered)
+                torch.cuda.current_stream().synchronize()
+                log.append(gathered.cpu().numpy().tobytes() if rank == root else "sent")
+            except sj.SjpegError as e:
+                log.append("refused: " + ("size 0" if "size 0" in str(e) else "capacity" if "capacity" in str(e) else str(e)))
+        return log
+
+    results, errors = _local_world(world, body)
+    assert errors == [None] * world, errors
+    for r in range(world):
+        assert results[r][0] == "refused: size 0" and results[r][1] == "refused: capacity", results[r][:2]
+    got, o = results[root][2], 0
+    for r in range(world):
+        for k in shard_frames(nframes, r, world):
+            assert got[o:o + len(want_frames[k])] == want_frames[k], k
+            o += (len(want_frames[k]) + 15) & ~15
+    assert o == total and results[1][2] == "sent" and results[2][2] == "sent"

@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_library_loads_and_exports_declared_symbols():
     lib = sj.lib()
     assert lib.SjpegVersion() == 0x000101
-    assert lib.sjpeg_hip_abi_version() == 16
+    assert lib.sjpeg_hip_abi_version() == 17
     declared = set()
     for hdr in ("include/sjpeg_hip.h", "include/sjpeg.h"):
         text = open(os.path.join(ROOT, hdr)).read()
@@ -27,6 +27,15 @@ def test_library_loads_and_exports_declared_symbols():
     assert declared == set(sj.EXPORTED_C_SYMBOLS), declared ^ set(sj.EXPORTED_C_SYMBOLS)
     for name in declared:
         assert hasattr(lib, name), name
+
+
+def test_documents_quote_the_header_abi_version():
+    """INTEGRATION.md / DESIGN.md name the ABI version: it must be the header's (one was stale)."""
+    ver = int(re.search(r"#define SJPEG_HIP_ABI_VERSION (\d+)", open(os.path.join(ROOT, "include/sjpeg_hip.h")).read()).group(1))
+    assert ver == sj.lib().sjpeg_hip_abi_version()
+    for doc in ("INTEGRATION.md", "DESIGN.md"):
+        quoted = [int(v) for v in re.findall(r"ABI(?: version)? (\d+)", open(os.path.join(ROOT, doc)).read())]
+        assert quoted and all(v == ver for v in quoted), (doc, quoted, ver)
 
 
 def test_cxx_api_symbols_present():
@@ -225,6 +234,35 @@ def test_optimal_huffman_survives_counts_that_break_the_depth_clamp():
         assert sp.nsyms == 44 and sum(bits) == 44
         assert sorted(sp.syms[:44]) == list(range(44))
         assert sum((c + (1 if l == max(i for i, v in enumerate(bits) if v) else 0)) * 2.0 ** -(l + 1) for l, c in enumerate(bits)) <= 1.0 + 1e-12
+
+
+@pytest.mark.parametrize("nused", [255, 256, 100, 45])
+def test_flat_fallback_with_every_symbol_used(nused):
+    """The same breakdown with 255 / 256 used symbols (256 / 257 leaves with the reserved one): the fallback code
+    must still fit the DHT's byte counts -- a complete code of two lengths, e.g. 255 of 8 bits + 1 of 9 -- and list
+    every symbol once (one length for all leaves wrapped a uint8 to 0 / 1)."""
+    f = np.zeros((2, 272), np.uint32)
+    a, b = 1, 2
+    for k in range(nused):
+        f[:, k] = min(a, (1 << 32) - 1)
+        a, b = b, a + b
+    f[:, 256] = 1
+    t = sj.ScanTables()
+    specs = sj.optimize_huffman(f, 1, t)
+    for tbl in range(2):
+        sp = specs[2 + tbl]
+        bits = [int(x) for x in sp.bits]
+        assert sp.nsyms == nused and sum(bits) == nused, (sp.nsyms, bits)
+        assert sorted(sp.syms[:nused]) == list(range(nused))
+        longest = max(i for i, v in enumerate(bits) if v)
+        kraft = sum((c + (1 if l == longest else 0)) * 2.0 ** -(l + 1) for l, c in enumerate(bits))
+        assert kraft <= 1.0 + 1e-12, (bits, kraft)
+        # the codes the table installs are distinct prefix-free words of the listed lengths
+        codes = [(int(t.ac_codes[tbl][s]) >> 16, int(t.ac_codes[tbl][s]) & 0xff) for s in range(nused)]
+        assert all(1 <= n <= 16 for _, n in codes)
+        words = sorted(format(c, "0%db" % n) for c, n in codes)
+        assert all(not words[i + 1].startswith(words[i]) for i in range(len(words) - 1))
+        assert all("0" in w for w in words)                       # no all-ones code (T.81 C: reserved)
 
 
 def test_shipped_riskiness_table_is_the_reference_table():
