@@ -5,6 +5,14 @@
 // ------------------------------------------------------------------------------------
 // K1: colour + fDCT + quantize + entropy-code one segment
 
+// experiment switches of the entropy phase (tools/build_variant.sh); the defaults are the shipped kernel
+#ifndef SJPEG_WALK_PIPE
+#define SJPEG_WALK_PIPE 2
+#endif
+#ifndef SJPEG_NO_MERGE
+#define SJPEG_NO_MERGE 0
+#endif
+
 enum { kKindEncode = 0, kKindTap = 1, kKindHisto = 2, kKindStats = 3, kKindError = 4,
        kKindEncodeTrellis = 5, kKindStatsTrellis = 6,     // the same two with trellis quantization
        kKindEncodeReplay = 7,     // entropy-code the coefficients a statistics pass left behind
@@ -748,9 +756,27 @@ __global__ __launch_bounds__(kScanThreads, ((KINDX == kKindHisto && SRC == kSrcR
   // The counting sort of the parts (below) starts here: the bins were cleared when the tables were
   // staged, and the atomics that rank this block's parts are in flight across the DC barrier.
   uint32_t pc[4] = {0, 0, 0, 0}, rank[4] = {0, 0, 0, 0};
+  // Two quarters of one half of the scan (0 + 1, 2 + 3) are coded as ONE part when the lean walk can take them in
+  // one go: both hold symbols, no more than 16 between them (the sort's bins, the balance of a wave's trip counts),
+  // and the run between the last symbol of the first and the first of the second is below 16 -- so that, as in a
+  // quarter, only the part's FIRST symbol can need ZRL codes.  The ordinary block of a picture makes one or two
+  // parts this way instead of two or three, and a part's start-up, wind-down and placement are what a round costs.
+  uint32_t mg01 = 0, mg23 = 0;
   if (KIND == kKindEncode || KIND == kKindStats) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) pc[q] = static_cast<uint32_t>(__popc(nzq[q]));
+    if (KIND == kKindEncode) {
+      // the block takes the checked walk (some AC level has more bits than the lean walk is proven for): no merging
+      unsafe = (any_ac & ldc[24 + tbl]) != 0u ? 1u : 0u;
+      const uint32_t end0 = 32u - static_cast<uint32_t>(__clz(nzq[0] | 1u));      // position after the last non-zero of quarter 0 (1 = none)
+      const uint32_t end2 = 32u - static_cast<uint32_t>(__clz(nzq[2]));           // the same of quarter 2, local (0 = none)
+      // (run between the two < 16  <=>  first position of the upper quarter, local, < end of the lower one, local)
+      mg01 = (unsafe == 0u && nzq[1] != 0u && static_cast<uint32_t>(__builtin_ctz(nzq[1] | 0x10000u)) < end0 && pc[0] + pc[1] <= 16u) ? 1u : 0u;
+      mg23 = (unsafe == 0u && nzq[3] != 0u && static_cast<uint32_t>(__builtin_ctz(nzq[3] | 0x10000u)) < end2 && pc[2] + pc[3] <= 16u) ? 1u : 0u;
+      if (SJPEG_NO_MERGE) { mg01 = 0u; mg23 = 0u; }
+      if (mg01) { pc[0] += pc[1]; pc[1] = 0u; }
+      if (mg23) { pc[2] += pc[3]; pc[3] = 0u; }
+    }
     if (emits) {
       uint32_t* const hist0 = reinterpret_cast<uint32_t*>(smem + L::kOffHist);
       rank[0] = atomicAdd(&hist0[pc[0]], 1u);      // quarter 0 always makes a part (DC, EOB)
@@ -782,8 +808,6 @@ __global__ __launch_bounds__(kScanThreads, ((KINDX == kKindHisto && SRC == kSrcR
     const uint32_t code = ldc[tbl * 12 + n];
     dc_word = (((code & 0xffu) + n) << 24) | ((code >> 16) << n) | suffix;
   }
-  // the block takes the checked walk (some AC level has more bits than the lean walk is proven for)
-  unsafe = (any_ac & ldc[24 + tbl]) != 0u ? 1u : 0u;
   // What a part's walk needs to know of its block, one word per quarter q in the slot's tail: the quarter's
   // non-zero mask (bits 0..15), the run in front of its first symbol, ZRLs included (bits 16..21; the walk splits
   // it into ZRL count and run), bit 22 = "this part carries the EOB" (nothing non-zero above the quarter, and
@@ -804,8 +828,14 @@ __global__ __launch_bounds__(kScanThreads, ((KINDX == kKindHisto && SRC == kSrcR
     const uint32_t e2 = nzq[3] == 0u ? 0x40u : 0u, e3 = (nzq[3] >> 15) == 0u ? 0x40u : 0u;
     const uint32_t fl = (unsafe << 24) | (static_cast<uint32_t>(tbl) << 25);
     if (has_slot) {
-      *reinterpret_cast<uint4*>(tail) = make_uint4(nzq[0] | (((r0 & 63u) | e0) << 16) | fl, nzq[1] | (((r1 & 63u) | e1) << 16) | fl,
-                                                   nzq[2] | (((r2 & 63u) | e2) << 16) | fl, nzq[3] | (((r3 & 63u) | e3) << 16) | fl);
+      // (a merged part: bit 23 in the word of its first quarter, which takes the EOB flag of the second; the second
+      // quarter's word keeps only its mask, in the UPPER half -- read as a length it is zero, like a quarter without
+      // a part)
+      const uint32_t w0 = nzq[0] | (((r0 & 63u) | (mg01 ? e1 | 0x80u : e0)) << 16) | fl;
+      const uint32_t w1 = mg01 ? nzq[1] << 16 : nzq[1] | (((r1 & 63u) | e1) << 16) | fl;
+      const uint32_t w2 = nzq[2] | (((r2 & 63u) | (mg23 ? e3 | 0x80u : e2)) << 16) | fl;
+      const uint32_t w3 = mg23 ? nzq[3] << 16 : nzq[3] | (((r3 & 63u) | e3) << 16) | fl;
+      *reinterpret_cast<uint4*>(tail) = make_uint4(w0, w1, w2, w3);
       dcw[tid] = dc_word;
     }
   } else {
@@ -1013,12 +1043,17 @@ __global__ __launch_bounds__(kScanThreads, ((KINDX == kKindHisto && SRC == kSrcR
   // and run, so a symbol costs two LDS reads and about thirty simple instructions.
   const uint32_t acm_base = static_cast<uint32_t>(L::kOffAcm) - 22u * 4u;    // word [run][clz - 22]: 40 bytes per run
   typedef uint16_t __attribute__((may_alias)) u16_alias2;
-  auto walk_lean = [&](uint32_t unit, uint32_t pw, uint32_t dcword, uint32_t& rec_out, uint32_t& tail_out) {
+  auto walk_lean = [&](uint32_t unit, uint32_t pw, uint32_t pw2, uint32_t dcword, uint32_t& rec_out, uint32_t& tail_out) {
     const uint32_t blk = unit & 255u, q = unit >> 8;
     const uint32_t slot_off = blk * kSlotBytes;
     const uint32_t b_tbl = (pw >> 25) & 1u;
     const uint32_t tb = acm_base + b_tbl * 640u;
-    uint32_t m = pw & 0xffffu;                     // the part's own 16 positions
+    // the part's own 16 positions -- 32 for a merged part (bit 23), whose second quarter's mask is the upper half
+    // of the word behind.  Everything below holds for 32 positions as it does for 16: T(i) <= 16 (i + 1) + 15 for
+    // i = 0 .. 31 (no run inside the part reaches 16: that is what made it one part), with the EOB T <= 543, so
+    // at most 16 words are stored where the 32 entries were, the last, partial word stays in a register.
+    const bool merged = ((pw >> 23) & 1u) != 0u;
+    const uint32_t m = (pw & 0xffffu) | (merged ? pw2 & 0xffff0000u : 0u);
     // the block's thread has read the masks for this quarter already (P3 start)
     const uint32_t inf = (pw >> 16) & 0x7fu;
     uint32_t acc = 0, fill = 0;                    // bits of the word in the making, left-aligned; their number
@@ -1031,11 +1066,16 @@ __global__ __launch_bounds__(kScanThreads, ((KINDX == kKindHisto && SRC == kSrcR
     // positions are local to the quarter from here on; the ZRLs of the first run are taken out of it
     // (only the first symbol of a part can have a run of 16 or more, and never in quarter 0)
     const uint32_t nzrl = (inf >> 4) & 3u;
-    // bit 16 set for good: a guard behind the part's 16 positions, so that "the next non-zero" is a bare v_ffbl
-    uint32_t ms = m | 0x10000u;
+    // bit 16 set for good: a guard behind the part's 16 positions, so that "the next non-zero" is a bare v_ffbl; a
+    // merged part has no room for one: its mask runs out at zero, of which v_ffbl makes -1 -- the fetch behind the
+    // last symbol then goes to the two bytes in front of the part (in the slot of a coded block, never the first
+    // of LDS), and is not used either
+    const uint32_t guard = merged ? 0u : 0x10000u;
+    uint32_t ms = m | guard;
+    auto first_bit = [](uint32_t x) { int r; asm("v_ffbl_b32 %0, %1" : "=v"(r) : "v"(x)); return r; };
     // local position OF the previous non-zero (may be negative); a symbol's row of merged code words is picked by
     // pos - prevp = run + 1, with the table base one row down: one subtraction instead of a three-operand form
-    int prevp = __builtin_ctz(ms) - static_cast<int>(inf & 15u) - 1;
+    int prevp = first_bit(ms) - static_cast<int>(inf & 15u) - 1;
     const uint32_t tbm = tb - 40u;
     // (the two code words the end of the part may need: fetched here, under the symbols' round trips)
     const uint2 ez = *reinterpret_cast<const uint2*>(ldc + 26 + 2 * b_tbl);
@@ -1075,18 +1115,19 @@ __global__ __launch_bounds__(kScanThreads, ((KINDX == kKindHisto && SRC == kSrcR
       asm("v_mad_u32_u24 %0, %1, 40, %2" : "=v"(row) : "v"(run1), "v"(tbm));
       cw_at = row + nl * 4u;
     };
+#if SJPEG_WALK_PIPE == 2
     if (m) {
-      int i = __builtin_ctz(ms);
+      int i = first_bit(ms);
       uint32_t e = entry_at(i);
       ms &= ms - 1u;
-      int i_next = __builtin_ctz(ms);
+      int i_next = first_bit(ms);
       uint32_t e_next = entry_at(i_next);
       uint32_t lv, cw_at;
       stage(i, e, lv, cw_at);
       uint32_t cw = *reinterpret_cast<const uint32_t*>(smem + cw_at);
-      while (ms != 0x10000u) {                     // (i_next, e_next) is a symbol
+      while (ms != guard) {                        // (i_next, e_next) is a symbol
         ms &= ms - 1u;
-        const int i_after = __builtin_ctz(ms);
+        const int i_after = first_bit(ms);
         const uint32_t e_after = entry_at(i_after);
         uint32_t lv_next, cw_at_next;
         stage(i_next, e_next, lv_next, cw_at_next);
@@ -1097,6 +1138,63 @@ __global__ __launch_bounds__(kScanThreads, ((KINDX == kKindHisto && SRC == kSrcR
       }
       append((cw & 0x07ffffffu) | lv, cw >> 27);
     }
+#elif SJPEG_WALK_PIPE == 0
+    // no read ahead at all: the other waves of the SIMD cover the two round trips of a symbol
+    while (ms != guard) {
+      const int i = first_bit(ms);
+      ms &= ms - 1u;
+      const uint32_t e = entry_at(i);
+      uint32_t lv, cw_at;
+      stage(i, e, lv, cw_at);
+      const uint32_t cw = *reinterpret_cast<const uint32_t*>(smem + cw_at);
+      append((cw & 0x07ffffffu) | lv, cw >> 27);
+    }
+#elif SJPEG_WALK_PIPE == 1
+    // the next symbol's entry is fetched one symbol ahead; its code word inside the iteration
+    if (m) {
+      int i = first_bit(ms);
+      uint32_t e = entry_at(i);
+      do {
+        ms &= ms - 1u;
+        const int i_next = first_bit(ms);
+        const uint32_t e_next = entry_at(i_next);
+        uint32_t lv, cw_at;
+        stage(i, e, lv, cw_at);
+        const uint32_t cw = *reinterpret_cast<const uint32_t*>(smem + cw_at);
+        append((cw & 0x07ffffffu) | lv, cw >> 27);
+        i = i_next; e = e_next;
+      } while (ms != guard);
+    }
+#elif SJPEG_WALK_PIPE == 3
+    // the depth of variant 2 (entries two symbols ahead, code words one), two symbols per trip of the loop: the
+    // registers change roles by name, not by moves
+    if (m) {
+      int i0 = first_bit(ms);
+      uint32_t e0 = entry_at(i0);
+      ms &= ms - 1u;
+      int i1 = first_bit(ms);
+      uint32_t e1 = entry_at(i1);
+      uint32_t lv0, at0, lv1, at1;
+      stage(i0, e0, lv0, at0);
+      uint32_t cw0 = *reinterpret_cast<const uint32_t*>(smem + at0), cw1;
+      for (;;) {
+        if (ms == guard) { append((cw0 & 0x07ffffffu) | lv0, cw0 >> 27); break; }
+        ms &= ms - 1u;
+        i0 = first_bit(ms);
+        e0 = entry_at(i0);
+        stage(i1, e1, lv1, at1);
+        cw1 = *reinterpret_cast<const uint32_t*>(smem + at1);
+        append((cw0 & 0x07ffffffu) | lv0, cw0 >> 27);
+        if (ms == guard) { append((cw1 & 0x07ffffffu) | lv1, cw1 >> 27); break; }
+        ms &= ms - 1u;
+        i1 = first_bit(ms);
+        e1 = entry_at(i1);
+        stage(i0, e0, lv0, at0);
+        cw0 = *reinterpret_cast<const uint32_t*>(smem + at0);
+        append((cw1 & 0x07ffffffu) | lv1, cw1 >> 27);
+      }
+    }
+#endif
     if (inf & 0x40u) append(eob >> 16, eob & 0xffu);
     const uint32_t len = ((wp - wp0) << 3) + fill;
     const uint32_t zl = zrl & 0xffu;
@@ -1119,7 +1217,7 @@ __global__ __launch_bounds__(kScanThreads, ((KINDX == kKindHisto && SRC == kSrcR
   // instead of one dependent chain of LDS round trips in front of every walk.
   // (rounds: 256 parts each; the ordinary segment has two -- the rounds behind the last are skipped by everybody)
   const int nrounds = static_cast<int>((n_units + 255u) >> 8);           // uniform
-  uint32_t un[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu}, pws[4] = {0, 0, 0, 0}, dws[4] = {0, 0, 0, 0};
+  uint32_t un[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu}, pws[4] = {0, 0, 0, 0}, pw2s[4] = {0, 0, 0, 0}, dws[4] = {0, 0, 0, 0};
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     if (r < nrounds) {
@@ -1134,6 +1232,8 @@ __global__ __launch_bounds__(kScanThreads, ((KINDX == kKindHisto && SRC == kSrcR
       // (no part: some word inside the kernel's LDS is read and not used)
       const uint32_t blk = un[r] & 255u, q = (un[r] >> 8) & 3u;
       pws[r] = *reinterpret_cast<const u32_alias*>(smem + blk * kSlotBytes + 128u + 4u * q);
+      // (the word behind: the second quarter's mask of a merged part; something in LDS otherwise)
+      pw2s[r] = *reinterpret_cast<const u32_alias*>(smem + blk * kSlotBytes + 132u + 4u * q);
       dws[r] = dcw[blk];
     }
   }
@@ -1145,7 +1245,7 @@ __global__ __launch_bounds__(kScanThreads, ((KINDX == kKindHisto && SRC == kSrcR
       if ((pws[r] >> 24) & 1u) {
         walk_checked(un[r], pws[r], dws[r], rec, tw);      // (tw: the part's pool row)
       } else {
-        walk_lean(un[r], pws[r], dws[r], rec, tw);
+        walk_lean(un[r], pws[r], pw2s[r], dws[r], rec, tw);
       }
       if (r == 0) { ur0 = rec; tw0 = tw; } else if (r == 1) { ur1 = rec; tw1 = tw; }
       else if (r == 2) { ur2 = rec; tw2 = tw; } else { ur3 = rec; tw3 = tw; }
