@@ -238,7 +238,7 @@ def run_config(sj, torch, eng, frames_np, tile, q, mode, want_md5, reps=10):
             "bit_exact": bool(ok)}
 
 
-def run_batch_config(sj, torch, eng, frames_np, tile, mode, method, want, quality=75.0, quant=None, reps=25):
+def run_batch_config(sj, torch, eng, frames_np, tile, mode, method, want, quality=75.0, quant=None, reps=25, latency_calls=15):
     """A configuration that goes through the per-picture analysis of the reference (adaptive quantization,
     optimised Huffman tables: sjpeg_hip_encode_batch_src, device passes + host analysis in between), or
     through caller-supplied matrices (C5): `tile` copies resident in HBM, whole call timed, frame 0
@@ -258,22 +258,27 @@ def run_batch_config(sj, torch, eng, frames_np, tile, mode, method, want, qualit
     out = torch.empty((F, stride), dtype=torch.uint8, device="cuda")
     sizes = torch.zeros(F, dtype=torch.int64, device="cuda")
     step = lambda: eng.encode_batch(src, F, w, h, mode, qm, method, min_quant=quant, out_stride=stride, out=out, sizes=sizes)
-    for _ in range(5):                            # (the first calls of a geometry allocate: 10 and 7 ms)
+    first = []
+    for _ in range(5):                            # (the first call of a geometry allocates the scratch: ~10 ms)
+        t0 = time.perf_counter()
         step()
-    torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        first.append(round((time.perf_counter() - t0) * 1e3, 3))
     # Timed like every other configuration: calls back to back, one synchronise behind a group of them (a call returns
     # when its last pass is launched; the next call's first pass queues behind it).  Beside it the call taken alone
     # -- synchronised after each, nothing of the next one under its tail --, median: the latency of one batch.
     groups = []
-    for _ in range(5):                            # (median of five groups: one call of a process, some tens of calls in,
-        t0 = time.perf_counter()                  # takes 6-8 ms in the runtime -- DESIGN.md section 4 --, and a mean would carry it)
+    for _ in range(5):                            # (median of five groups)
+        t0 = time.perf_counter()
         for _ in range(max(reps // 5, 1)):
             step()
         torch.cuda.synchronize()
         groups.append((time.perf_counter() - t0) / max(reps // 5, 1))
     dt = float(np.median(groups))
+    # (`latency_calls` of them: p50 / p99 / max say whether a call of the process stands out -- round 4 had one of
+    # 6-8 ms some tens of calls in, the pinned upload blocks growing one by one)
     per_call = []
-    for _ in range(15):
+    for _ in range(latency_calls):
         t0 = time.perf_counter()
         step()
         torch.cuda.synchronize()
@@ -286,6 +291,8 @@ def run_batch_config(sj, torch, eng, frames_np, tile, mode, method, want, qualit
         ok = ok and hashlib.md5(bytes(out[k, :int(sz[k])].cpu().numpy())).hexdigest() == want["md5"]
     return {"frames": F, "width": w, "height": h, "method": method, "mpix_s": round(F * w * h / dt / 1e6, 1),
             "ms_per_step": round(dt * 1e3, 4), "ms_per_call_alone": round(dt_alone * 1e3, 4),
+            "call_ms": {"calls": latency_calls, "p50": round(dt_alone * 1e3, 4), "p99": round(float(np.percentile(per_call, 99)) * 1e3, 4),
+                        "max": round(float(np.max(per_call)) * 1e3, 4), "first_calls": first},
             "bytes_per_frame": int(sz[0]), "bit_exact": bool(ok)}
 
 
@@ -832,7 +839,7 @@ def main():
                     sj.YUV_420, digests["struct4k|420|q75|m0"]["md5"], reps=50)
                 g4k = [host[0]] if args.input == "struct" else [synth.g_struct(W, H, 7654321)]
                 oc["C2 4K G_struct q75 420 default parameters (method 4) x32"] = run_batch_config(
-                    sj, torch, eng, g4k, 32, sj.YUV_420, 4, digests["struct4k|420|q75|m4"])
+                    sj, torch, eng, g4k, 32, sj.YUV_420, 4, digests["struct4k|420|q75|m4"], latency_calls=500)
                 c5q = np.array(digests["recompress|r90|m0"]["source_quant"], np.uint8).reshape(2, 64)
                 c5q = np.clip((c5q.astype(np.float64) * 100.0 / 90.0 + 0.5).astype(np.int64), 1, 255).astype(np.uint8)
                 oc["C5 4K recompress r=90 method 0 x32"] = run_batch_config(
@@ -860,6 +867,18 @@ def main():
             except Exception as exc:
                 oc["error"] = repr(exc)
             res["other_configs"] = oc
+            # SURVEY section 8d "report separately": host buffer in, host buffer out through the drop-in API (SjpegEncode of
+            # include/sjpeg.h, PCIe both ways) -- one 4K frame at a time from pageable and from pinned memory, and a
+            # stream of frames from several threads (every thread has its own device context and stream)
+            try:
+                sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+                import host_to_host
+                hh = host_to_host.measure(budget=0.6, threads=(1, 4))
+                hh["what"] = ("SjpegEncode(rgb, 3840, 2160, ...) q75 4:2:0 method 0, pixels and JPEG in host memory; Gpixels/s; "
+                              "PCIe bound of the upload alone at ~54 GB/s: 18 Gpixels/s")
+                res["host_to_host"] = hh
+            except Exception as exc:
+                res["host_to_host"] = {"error": repr(exc)}
             if any(isinstance(v, dict) and v.get("bit_exact") is False for v in oc.values()):
                 parity = False
         if not args.no_cpu_baseline and world == 1 and not args.timed_only:

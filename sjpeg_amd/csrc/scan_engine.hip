@@ -91,6 +91,18 @@ bool frame_geo(int W, int H, int mode, FrameGeo* g) {
   return true;
 }
 
+// measurement aid (SJPEG_HIP_BATCH_DEBUG=1): microseconds since this thread's previous mark, on stderr -- which runtime
+// call of a launch sequence the host spent its time in (tools/slow_call_timeline.py)
+inline void dbg_mark(const char* what) {
+  static const bool on = getenv("SJPEG_HIP_BATCH_DEBUG") != nullptr && atoi(getenv("SJPEG_HIP_BATCH_DEBUG")) >= 2;
+  if (!on) return;
+  static thread_local std::chrono::steady_clock::time_point last = std::chrono::steady_clock::now();
+  const auto now = std::chrono::steady_clock::now();
+  const double us = std::chrono::duration<double, std::micro>(now - last).count();
+  if (us > 200.0) fprintf(stderr, "    step %-28s %9.1f us\n", what, us);
+  last = now;
+}
+
 template <typename T>
 struct DevBuf {
   T* p = nullptr;
@@ -123,7 +135,7 @@ struct sjpeg_hip_engine {
   // engine owns: hipMemcpyAsync from pageable memory pins the caller's pages for the length of the copy -- tens of
   // microseconds of host time per upload and, now and then, several milliseconds (seen as one call in twenty of a
   // 32-frame default-parameter batch taking 8 ms instead of 1.6).
-  struct Stage { void* p = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; bool busy = false; } stage[4];
+  struct Stage { void* p = nullptr; void* dp = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; bool busy = false; } stage[4];
   int stage_next = 0;
   std::vector<uint8_t> header_held;
   const void* tables_held_at = nullptr; const void* header_held_at = nullptr;
@@ -279,28 +291,76 @@ int order_on_stream(sjpeg_hip_engine* e, hipStream_t st) {
   return 0;
 }
 
+// The copy of a staged upload: a kernel reads the engine's pinned block over the bus and writes device memory.  Not
+// hipMemcpyAsync: that call took 6-9 ms ONCE per process -- the first copy it is asked for while kernels of the same
+// stream are still running (the second default-parameter batch call of a process; now and then a later one) --, the
+// "6-8 ms call some tens of calls in" of round 4, named in round 5 by the marks of SJPEG_HIP_BATCH_DEBUG=2
+// (profiles/r05/slow_call.txt: `upload: hipMemcpyAsync 6920 us`).  A kernel stays on the stream's own queue: no copy
+// engine, no hand-over between queues, and a launch costs the host less than the copy call did.
+__global__ __launch_bounds__(256) void stage_copy_kernel(uint8_t* dst, const uint8_t* src, size_t bytes) {
+  const size_t n16 = bytes >> 4;
+  const uint4* const s4 = reinterpret_cast<const uint4*>(src);
+  uint4* const d4 = reinterpret_cast<uint4*>(dst);
+  for (size_t i = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x; i < n16; i += static_cast<size_t>(gridDim.x) * 256) d4[i] = s4[i];
+  if (blockIdx.x == 0 && threadIdx.x < (bytes & 15u)) dst[(n16 << 4) + threadIdx.x] = src[(n16 << 4) + threadIdx.x];
+}
+
+// bytes between two places the DEVICE can address (device memory, mapped pinned host memory), by that kernel; the
+// runtime's copy where the addresses do not allow 16-byte accesses
+int copy_by_kernel(void* dst, const void* src, size_t bytes, hipStream_t st, hipMemcpyKind fallback_kind, const void* fallback_src, void* fallback_dst) {
+  if (bytes == 0) return 0;
+  if (((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 15u) != 0 || dst == nullptr || src == nullptr) {
+    HIP_TRY(hipMemcpyAsync(fallback_dst, fallback_src, bytes, fallback_kind, st));
+    return 0;
+  }
+  const size_t n16 = bytes >> 4;
+  const unsigned blocks = static_cast<unsigned>(n16 >= 256 * 64 ? 64 : (n16 + 255) / 256 + (n16 == 0 ? 1 : 0));
+  hipLaunchKernelGGL(stage_copy_kernel, dim3(blocks), dim3(256), 0, st, static_cast<uint8_t*>(dst), static_cast<const uint8_t*>(src), bytes);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
 // dst <- src on the stream, through one of the engine's pinned blocks when the copy is not tiny (see sjpeg_hip_engine::stage)
 int upload(sjpeg_hip_engine* e, void* dst, const void* src, size_t bytes, hipStream_t st) {
-  // (tiny copies are staged by the runtime itself; for a very large one -- the per-frame tables of a batch of tens of
-  // thousands of frames -- the pinning is small beside the copy, and four pinned blocks of that size would not be)
-  if (bytes < 4096 || bytes > (static_cast<size_t>(8) << 20)) {
+  // (for a very large one -- the per-frame tables of a batch of tens of thousands of frames -- the runtime's pinning is
+  // small beside the copy, and four pinned blocks of that size would not be)
+  if (bytes == 0) return 0;
+  if (bytes > (static_cast<size_t>(8) << 20)) {
     HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st));
     return 0;
   }
   sjpeg_hip_engine::Stage& s = e->stage[e->stage_next];
   e->stage_next = (e->stage_next + 1) & 3;
+  dbg_mark("upload: begin");
   if (s.busy) { HIP_TRY(hipEventSynchronize(s.ev)); s.busy = false; }       // (four uploads ago: long done)
+  dbg_mark("upload: block free");
   if (s.cap < bytes) {
-    if (s.p) (void)hipHostFree(s.p);
-    s.p = nullptr; s.cap = 0;
-    const size_t want = (bytes + 65535) & ~static_cast<size_t>(65535);
-    if (hipHostMalloc(&s.p, want, hipHostMallocDefault) != hipSuccess) { s.p = nullptr; return fail(SJPEG_HIP_ENOMEM, "hipHostMalloc(upload block) failed"); }
-    s.cap = want;
+    // ALL four blocks grow together, to a power of two: hipHostFree + hipHostMalloc of one block takes milliseconds,
+    // and blocks that grew one by one -- whenever the ring brought a small block to a large upload -- were the
+    // "6-8 ms call some tens of calls in" of the default-parameter batch path (round 4; named in round 5 by the
+    // library's own host timeline: the second call's statistics launch, profiles/r05/slow_call.txt).  Now the first
+    // upload of a size class pays for the four, once.
+    size_t want = static_cast<size_t>(256) << 10;
+    while (want < bytes) want <<= 1;
+    for (auto& g : e->stage) {
+      if (g.cap >= want) continue;
+      if (g.busy) { HIP_TRY(hipEventSynchronize(g.ev)); g.busy = false; }
+      if (g.p) (void)hipHostFree(g.p);
+      g.p = nullptr; g.dp = nullptr; g.cap = 0;
+      if (hipHostMalloc(&g.p, want, hipHostMallocMapped) != hipSuccess) { g.p = nullptr; return fail(SJPEG_HIP_ENOMEM, "hipHostMalloc(upload block) failed"); }
+      g.cap = want;
+      // (the address the device reads the block at; without one the copy falls back to the runtime's)
+      if (hipHostGetDevicePointer(&g.dp, g.p, 0) != hipSuccess) { (void)hipGetLastError(); g.dp = nullptr; }
+    }
   }
   if (s.ev == nullptr && hipEventCreateWithFlags(&s.ev, hipEventDisableTiming) != hipSuccess) { s.ev = nullptr; return fail(SJPEG_HIP_ERUNTIME, "hipEventCreate failed"); }
+  dbg_mark("upload: block sized");
   memcpy(s.p, src, bytes);
-  HIP_TRY(hipMemcpyAsync(dst, s.p, bytes, hipMemcpyHostToDevice, st));
+  dbg_mark("upload: memcpy");
+  if (int rc = copy_by_kernel(dst, s.dp, bytes, st, hipMemcpyHostToDevice, s.p, dst)) return rc;
+  dbg_mark("upload: copy launched");
   HIP_TRY(hipEventRecord(s.ev, st));
+  dbg_mark("upload: hipEventRecord");
   s.busy = true;
   return 0;
 }
@@ -383,8 +443,10 @@ int prepare_scan(sjpeg_hip_engine* e, const sjpeg_hip_source* src,
     a->plane[2] = a->plane[1]; a->row_stride[2] = a->row_stride[1]; a->frame_stride[2] = a->frame_stride[1];
   }
   if (nframes > 65535) return fail(SJPEG_HIP_EINVAL, "nframes > 65535");
+  dbg_mark("prepare: begin");
   HIP_TRY(hipSetDevice(e->device));
   if (int rc0 = order_on_stream(e, st)) return rc0;
+  dbg_mark("prepare: ordered");
   // anything but a pipelined encode shares buffers with the stitch still running on the engine's stream
   if (e->side_pending && !piped_encode) {
     HIP_TRY(hipStreamWaitEvent(st, e->side_done, 0));
@@ -403,6 +465,7 @@ int prepare_scan(sjpeg_hip_engine* e, const sjpeg_hip_source* src,
     if ((rc = e->seg_xbase.ensure(total_segs))) return rc;
   }
   if (plan_out != nullptr) *plan_out = plan;
+  dbg_mark("prepare: buffers");
   {
     // (pageable source: the copy has left the host buffer when the call returns)
     std::vector<DevTables> host_tables(ntab);
@@ -410,9 +473,11 @@ int prepare_scan(sjpeg_hip_engine* e, const sjpeg_hip_source* src,
     const bool held = e->tables_held_at == e->tables.p && e->tables_stream == st &&
                       e->tables_held.size() == static_cast<size_t>(ntab) &&
                       memcmp(e->tables_held.data(), host_tables.data(), sizeof(DevTables) * ntab) == 0;
+    dbg_mark("prepare: tables digested");
     if (!held) {
       e->tables_held_at = nullptr;
       if (int rcu = upload(e, e->tables.p, host_tables.data(), sizeof(DevTables) * ntab, st)) return rcu;
+      dbg_mark("prepare: tables uploaded");
       if (ntab <= 16) {                            // (a big batch of per-frame tables is not worth holding)
         e->tables_held.swap(host_tables);
         e->tables_held_at = e->tables.p; e->tables_stream = st;
@@ -525,7 +590,7 @@ int sjpeg_hip_engine_trim(sjpeg_hip_engine* e) {
     // block's life does not hang on that one line)
     if (sg.busy && sg.ev) (void)hipEventSynchronize(sg.ev);
     if (sg.p) (void)hipHostFree(sg.p);
-    sg.p = nullptr; sg.cap = 0; sg.busy = false;
+    sg.p = nullptr; sg.dp = nullptr; sg.cap = 0; sg.busy = false;
   }
   e->tables_held_at = nullptr; e->header_held_at = nullptr;
   e->replay_w = e->replay_h = e->replay_mode = e->replay_nframes = 0;
@@ -681,11 +746,13 @@ static int scan_statistics(sjpeg_hip_engine* e, const sjpeg_hip_source* src, int
     a.replay = e->replay.p + static_cast<size_t>(first) * per_frame;
     e->replay_w = width; e->replay_h = height; e->replay_mode = yuv_mode; e->replay_nframes = total;
   }
+  dbg_mark("statistics: buffers");
   if (histogram) rc = launch_scan<kKindHisto>(yuv_mode, cls, dim3(g.nseg, nframes), st, a);
   else if (tables != nullptr && (tables->flags & SJPEG_HIP_QUANT_TRELLIS)) rc = launch_scan<kKindStatsTrellis>(yuv_mode, cls, dim3(g.nseg, nframes), st, a);
   else if (coefs_in) rc = launch_scan_src<kKindStatsCoef, kSrcRgb24>(yuv_mode, dim3(g.nseg, nframes), st, a);   // (reads no pixel)
   else rc = launch_scan<kKindStats>(yuv_mode, cls, dim3(g.nseg, nframes), st, a);
   if (rc) return rc;
+  dbg_mark("statistics: pass launched");
   // Slices of the segments meet in the output with device-scope atomics, and those are what the summing
   // kernel waits for: as FEW slices as still fill the device.  The histogram (4096 words x 4 counters per
   // frame) wants about a thousand workgroups -- 16 frames: 63 us with 16 slices, 40 with 4, 38 with 2; a
@@ -704,8 +771,10 @@ static int scan_statistics(sjpeg_hip_engine* e, const sjpeg_hip_source* src, int
     rs = e->reduce_stream;
     HIP_TRY(hipEventRecord(e->reduce_ev, st));
     HIP_TRY(hipStreamWaitEvent(rs, e->reduce_ev, 0));
+    dbg_mark("statistics: side stream waits");
   }
   HIP_TRY(hipMemsetAsync(d_out, 0, static_cast<size_t>(nframes) * words * (histogram ? 4 : 1) * sizeof(uint32_t), rs));
+  dbg_mark("statistics: memset");
   if (histogram) {
     hipLaunchKernelGGL(reduce_partials<true>, grid, dim3(kThreads), 0, rs, partial, g.nseg, words, d_out);
   } else {
@@ -1119,7 +1188,7 @@ int sjpeg_hip_stitch_bands(sjpeg_hip_engine* e, int nbands, const uint32_t* d_wo
   if ((rc = e->chunk_off.ensure(max_chunks))) return rc;
   if ((rc = e->header.ensure(header_size > 0 ? header_size : 1))) return rc;
   e->header_held_at = nullptr;                     // (this path does not track what it uploads)
-  if (header_size > 0) HIP_TRY(hipMemcpyAsync(e->header.p, header, header_size, hipMemcpyHostToDevice, st));
+  if (header_size > 0) { if (int rcu = upload(e, e->header.p, header, header_size, st)) return rcu; }
   StitchArgs s;
   memset(&s, 0, sizeof(s));
   s.nseg = nbands; s.nframes = 1;
@@ -1177,6 +1246,7 @@ struct BatchScratch {                 // per host thread: device scratch of sjpe
   void* d_sums = nullptr; size_t sums_cap = 0;
   void* d_freq = nullptr; size_t freq_cap = 0;
   void* h_pinned = nullptr; size_t pinned_cap = 0;   // where the device's sums / counts land on the host
+  void* d_pinned = nullptr;                          // ... as the device addresses it
   int device = -1;
   void Drop() {
     if (d_hist) (void)hipFree(d_hist);
@@ -1187,7 +1257,7 @@ struct BatchScratch {                 // per host thread: device scratch of sjpe
     if (pass_done) (void)hipEventDestroy(pass_done);
     if (side) { (void)hipStreamSynchronize(side); (void)hipStreamDestroy(side); }
     pass_done = nullptr; side = nullptr;
-    d_hist = d_sums = d_freq = h_pinned = nullptr; hist_cap = sums_cap = freq_cap = pinned_cap = 0;
+    d_hist = d_sums = d_freq = h_pinned = d_pinned = nullptr; hist_cap = sums_cap = freq_cap = pinned_cap = 0;
   }
   hipEvent_t ev[8] = {};                         // behind the read-backs of a part: sums [0..3], counts [4..7]
   hipStream_t side = nullptr;                    // the sums of a part (and their read-back) under the next part's pass
@@ -1203,9 +1273,11 @@ struct BatchScratch {                 // per host thread: device scratch of sjpe
   bool EnsurePinned(size_t need) {
     if (need <= pinned_cap) return true;
     if (h_pinned) (void)hipHostFree(h_pinned);
-    h_pinned = nullptr; pinned_cap = 0;
-    if (hipHostMalloc(&h_pinned, need, hipHostMallocDefault) != hipSuccess) return false;
+    h_pinned = nullptr; d_pinned = nullptr; pinned_cap = 0;
+    if (hipHostMalloc(&h_pinned, need, hipHostMallocMapped) != hipSuccess) return false;
     pinned_cap = need;
+    // (the address the device writes the block at: the read-backs are kernels too, see stage_copy_kernel)
+    if (hipHostGetDevicePointer(&d_pinned, h_pinned, 0) != hipSuccess) { (void)hipGetLastError(); d_pinned = nullptr; }
     return true;
   }
   ~BatchScratch() { if (device >= 0) { (void)hipSetDevice(device); Drop(); } }
@@ -1296,6 +1368,11 @@ int sjpeg_hip_encode_batch_src(sjpeg_hip_engine* engine, const sjpeg_hip_source*
       engine->replay_total = nframes;
       rs = sc.side;
     }
+    // device -> the pinned block, on the side stream: a kernel writes it over the bus (no runtime copy: stage_copy_kernel)
+    auto read_back = [&](void* h_dst, const void* d_src, size_t bytes) -> int {
+      void* const dv = sc.d_pinned == nullptr ? nullptr : static_cast<uint8_t*>(sc.d_pinned) + (static_cast<uint8_t*>(h_dst) - static_cast<uint8_t*>(sc.h_pinned));
+      return copy_by_kernel(dv, d_src, bytes, rs, hipMemcpyDeviceToHost, d_src, h_dst);
+    };
     static const bool no_coefs = getenv("SJPEG_HIP_NO_COEF_KEEP") != nullptr;       // (A/B: every pass from the pixels)
     engine->coefs_keep = adaptive && optimize && !no_coefs;
     if (adaptive) {
@@ -1312,8 +1389,8 @@ int sjpeg_hip_encode_batch_src(sjpeg_hip_engine* engine, const sjpeg_hip_source*
                                     d_sums + f0 * (kSums / sizeof(int64_t)), d_tot + f0 * (kTot / sizeof(int32_t)), rs);
         }
         if (rc != 0) return rc;
-        HIP_TRY(hipMemcpyAsync(h_sums + f0 * kSums, d_sums + f0 * (kSums / sizeof(int64_t)), nf * kSums, hipMemcpyDeviceToHost, rs));
-        HIP_TRY(hipMemcpyAsync(h_sums + n * kSums + f0 * kTot, d_tot + f0 * (kTot / sizeof(int32_t)), nf * kTot, hipMemcpyDeviceToHost, rs));
+        if (int rcc = read_back(h_sums + f0 * kSums, d_sums + f0 * (kSums / sizeof(int64_t)), nf * kSums)) return rcc;
+        if (int rcc = read_back(h_sums + n * kSums + f0 * kTot, d_tot + f0 * (kTot / sizeof(int32_t)), nf * kTot)) return rcc;
         HIP_TRY(hipEventRecord(sc.ev[p], rs));
       }
     }
@@ -1352,8 +1429,10 @@ int sjpeg_hip_encode_batch_src(sjpeg_hip_engine* engine, const sjpeg_hip_source*
         uint32_t* const d_freq = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(sc.d_freq) + f0 * kFreq);
         const int rc = sjpeg_hip_scan_symbol_stats_multi(engine, &ps, width, height, yuv_mode, static_cast<int>(nf), &tables[f0], d_freq, stream);
         if (rc != 0) return rc;
-        HIP_TRY(hipMemcpyAsync(h_freq + f0 * kFreq, d_freq, nf * kFreq, hipMemcpyDeviceToHost, rs));
+        if (int rcc = read_back(h_freq + f0 * kFreq, d_freq, nf * kFreq)) return rcc;
+        dbg_mark("batch: counts read back");
         HIP_TRY(hipEventRecord(sc.ev[kMaxParts + p], rs));
+        dbg_mark("batch: event recorded");
         mark("stats launched", p);
       }
     }

@@ -12,6 +12,11 @@
 #ifndef SJPEG_NO_MERGE
 #define SJPEG_NO_MERGE 0
 #endif
+// wave priorities by phase (s_setprio): one 2-bit field per phase -- P1 (bits 0-1), P2 (2-3), P3 (4-5), P4 (6-7)
+#ifndef SJPEG_PHASE_PRIO
+#define SJPEG_PHASE_PRIO 0
+#endif
+#define PHASE_PRIO(k) do { if (SJPEG_PHASE_PRIO) __builtin_amdgcn_s_setprio((SJPEG_PHASE_PRIO >> (2 * (k))) & 3); } while (0)
 
 enum { kKindEncode = 0, kKindTap = 1, kKindHisto = 2, kKindStats = 3, kKindError = 4,
        kKindEncodeTrellis = 5, kKindStatsTrellis = 6,     // the same two with trellis quantization
@@ -82,6 +87,7 @@ __global__ __launch_bounds__(kScanThreads, ((KINDX == kKindHisto && SRC == kSrcR
     }
   };
   stamp(0);
+  PHASE_PRIO(0);
   RACE_POINT(0);
   const int m_first = (seg + a.seg_first) * G::kSegMcus;       // first coded MCU of the segment
   const int n_coded = min(G::kSegMcus, a.n_mcus - m_first);
@@ -315,6 +321,7 @@ __global__ __launch_bounds__(kScanThreads, ((KINDX == kKindHisto && SRC == kSrcR
   }
   __syncthreads();
   stamp(1);
+  PHASE_PRIO(1);
   RACE_POINT(1);
   if (a.ablate == 1) return;
 
@@ -742,6 +749,7 @@ __global__ __launch_bounds__(kScanThreads, ((KINDX == kKindHisto && SRC == kSrcR
   if (a.ablate == 2) { if (nz_lo + nz_hi + dc_val == 0x7fffffff) a.seg_nbits[0] = 1; return; }
 
   stamp(2);
+  PHASE_PRIO(2);
 #ifdef SJPEG_HIP_PRIO_STRESS
   prio_stress<SJPEG_HIP_PRIO_STRESS>(1);
 #endif
@@ -1253,6 +1261,7 @@ __global__ __launch_bounds__(kScanThreads, ((KINDX == kKindHisto && SRC == kSrcR
   }
   __syncthreads();
   stamp(4);
+  PHASE_PRIO(3);
   RACE_POINT(7);
   // offsets are a prefix sum in STREAM order (thread tid owns block tid here); the block's tail
   // (masks and DC word: consumed) becomes the bit offsets of its four parts
