@@ -12,9 +12,18 @@
 #ifndef SJPEG_NO_MERGE
 #define SJPEG_NO_MERGE 0
 #endif
-// wave priorities by phase (s_setprio): one 2-bit field per phase -- P1 (bits 0-1), P2 (2-3), P3 (4-5), P4 (6-7)
+// wave priorities by phase (s_setprio): one 2-bit field per phase -- P1 (bits 0-1), P2 (2-3), P3 (4-5), P4 (6-7).
+// Shipped: the entropy phase and the stitch run at priority 2, colour conversion and DCT at 0 -- the waves that
+// wait for LDS round trips issue the moment their data is back, the dense arithmetic of the other workgroups of the
+// CU fills the rest.  A/B on one box, six alternating runs each (profiles/r05/phase_prio_ab.txt): K1 0.8549 ->
+// 0.8445 ms, step 0.8964 -> 0.8899; P1 at 3 (0x03) and P2 at 3 (0x0c): nothing.  (The race-stress builds skew the
+// priorities themselves.)
 #ifndef SJPEG_PHASE_PRIO
+#ifdef SJPEG_HIP_PRIO_STRESS
 #define SJPEG_PHASE_PRIO 0
+#else
+#define SJPEG_PHASE_PRIO 0xa0
+#endif
 #endif
 #define PHASE_PRIO(k) do { if (SJPEG_PHASE_PRIO) __builtin_amdgcn_s_setprio((SJPEG_PHASE_PRIO >> (2 * (k))) & 3); } while (0)
 
