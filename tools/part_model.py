@@ -62,13 +62,18 @@ def parts_of(rule):
         p = [pp[:, i] for i in range(4)]; valid = [vv[:, i] for i in range(4)]
     return np.stack(p, 1), np.stack(valid, 1)
 
-def model(rule, per_part=50, per_sym=26):
+def model(rule, per_part=110, per_sym=27, coarse=False):
     pcs, valid = parts_of(rule)
     nseg = (nb + seg_blocks - 1) // seg_blocks
     tot_units = tot_rounds = tot_iter = tot_roundslots = 0
     for s in range(nseg):
         sl = slice(s * seg_blocks, min(nb, (s + 1) * seg_blocks))
-        u = np.sort(pcs[sl][valid[sl]])[::-1]
+        u = pcs[sl][valid[sl]]
+        if coarse:      # bins of the sort: one per count up to 16, then 17-20, 21-24, 25-32 (stream order inside a bin)
+            key = np.where(u <= 16, u, 17 + np.minimum((u - 17) >> 2, 2))
+            u = u[np.argsort(-key, kind="stable")]
+        else:
+            u = np.sort(u)[::-1]
         n = len(u); tot_units += n
         rounds = (n + 255) // 256; tot_rounds += rounds
         for g in range((n + 63) // 64):
@@ -79,5 +84,7 @@ def model(rule, per_part=50, per_sym=26):
         rule, tot_units / nb, tot_rounds / nseg, tot_roundslots / nseg, tot_iter / nseg, syms / nseg / 64,
         (tot_iter * per_sym + tot_roundslots * per_part) / nseg / 4))
 
-for r in ("quarters", "halves16", "greedy16p", "greedy20p", "greedy16", "greedy20", "greedy24"):
+for r in ("quarters", "halves16", "halves24", "halves32"):
     model(r)
+for r in ("halves20", "halves24", "halves32"):
+    print("coarse bins:", end=" "); model(r, coarse=True)
