@@ -788,7 +788,12 @@ __global__ __launch_bounds__(kScanThreads, ((KINDX == kKindHisto && SRC == kSrcR
       const uint32_t end0 = 32u - static_cast<uint32_t>(__clz(nzq[0] | 1u));      // position after the last non-zero of quarter 0 (1 = none)
       const uint32_t end2 = 32u - static_cast<uint32_t>(__clz(nzq[2]));           // the same of quarter 2, local (0 = none)
       // (run between the two < 16  <=>  first position of the upper quarter, local, < end of the lower one, local)
-      mg01 = (unsafe == 0u && nzq[1] != 0u && static_cast<uint32_t>(__builtin_ctz(nzq[1] | 0x10000u)) < end0 && pc[0] + pc[1] <= 16u) ? 1u : 0u;
+#ifdef SJPEG_MUTATE_MERGE                          // (a WRONG rule, to see the directed test fail: tools/build_variant.sh)
+      const uint32_t end0m = end0 + 1u;
+#else
+      const uint32_t end0m = end0;
+#endif
+      mg01 = (unsafe == 0u && nzq[1] != 0u && static_cast<uint32_t>(__builtin_ctz(nzq[1] | 0x10000u)) < end0m && pc[0] + pc[1] <= 16u) ? 1u : 0u;
       mg23 = (unsafe == 0u && nzq[3] != 0u && static_cast<uint32_t>(__builtin_ctz(nzq[3] | 0x10000u)) < end2 && pc[2] + pc[3] <= 16u) ? 1u : 0u;
       if (SJPEG_NO_MERGE) { mg01 = 0u; mg23 = 0u; }
       if (mg01) { pc[0] += pc[1]; pc[1] = 0u; }

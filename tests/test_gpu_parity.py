@@ -443,6 +443,103 @@ def test_kept_blocks_narrow_and_wide(engine, oracle):
                 assert got[k] == oracle.encode_method(imgs[k], q, mode, method), (w, h, k, mode, q, method)
 
 
+def _pictures_of_sparse_blocks(rng, bw, bh, q):
+    """Gray pictures whose 8x8 blocks are inverse DCTs of chosen sparse coefficient patterns (levels +-1..3 times
+    the quantizer step q: they survive the rounding to 8 bits, everything else stays zero), built to sit ON the rules
+    by which K1 codes two quarters of the zig-zag scan as one part (scan_segments.h, `mg01` / `mg23`): a run of exactly
+    15 / 16 zeros across the quarter boundary, 16 / 17 symbols in the two quarters, an empty first quarter, position 63."""
+    from scipy.fft import idctn
+    zig = [0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21,
+           28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63]
+    img = np.zeros((bh * 8, bw * 8), np.uint8)
+    for by in range(bh):
+        for bx in range(bw):
+            pos = set()
+            kind = rng.randint(0, 9)
+            half = 32 * rng.randint(0, 2)                         # the rule applies to quarters 0 + 1 and to 2 + 3 alike
+            if kind == 0:                                         # run of 15 / 16 across the quarter boundary
+                last = rng.randint(1, 16)
+                pos = {half + last, half + last + 16 + rng.randint(0, 2)} - {half + 0}
+            elif kind == 1:                                       # 16 / 17 symbols in the two quarters
+                n = 16 + rng.randint(0, 2)
+                pos = set(half + p for p in rng.choice(np.arange(1, 32), n, replace=False))
+                pos |= {half + 15, half + 16}                     # (no long run between the quarters)
+            elif kind == 2:                                       # first quarter empty: run 15 / 16 from the DC (or from quarter 1)
+                pos = {half + 16 + rng.randint(0, 2)} | set(half + p for p in rng.choice(np.arange(18, 32), rng.randint(0, 5), replace=False))
+            elif kind == 3:                                       # both halves merged, and position 63 (no EOB)
+                pos = {1, 14, 17, 30, 33, 47, 49, 63} if rng.randint(0, 2) else {3, 15, 16, 40, 47, 48}
+            elif kind == 4:                                       # dense block: nothing merges
+                pos = set(rng.choice(np.arange(1, 64), rng.randint(34, 63), replace=False))
+            elif kind == 5:                                       # DC only / empty
+                pos = set()
+            else:                                                 # ordinary sparse blocks
+                pos = set(rng.choice(np.arange(1, 64), rng.randint(1, 14), replace=False) % (rng.choice([16, 32, 48, 64])))
+            pos = {p for p in pos if 1 <= p <= 63}
+            F = np.zeros(64)
+            for p in pos:
+                F[zig[p]] = q * rng.choice([-3, -2, -1, 1, 2, 3], p=[0.05, 0.1, 0.35, 0.35, 0.1, 0.05])
+            F[0] = q * rng.randint(-6, 7)
+            blk = idctn(F.reshape(8, 8), norm="ortho") + 128.0
+            img[by * 8:by * 8 + 8, bx * 8:bx * 8 + 8] = np.clip(np.rint(blk), 0, 255)
+    return img
+
+
+def test_two_quarters_as_one_part(engine, oracle):
+    """K1 codes two quarters of a block's zig-zag scan as ONE part when the lean walk can take them in one go: both hold
+    symbols, at most 16 between them, and fewer than 16 zeros between the last symbol of the first and the first of the
+    second (so that only the part's first symbol can need ZRL codes).  Pictures made of blocks that sit on those three
+    rules -- checked on the oracle's own coefficients, so that the test cannot go blind --, as gray, and as R = G = B
+    through the colour kinds (chroma blocks: a DC and nothing else), one frame and a batch, standard and optimised
+    tables (replay kind)."""
+    rng = np.random.RandomState(20260929)
+    q = 16
+    quant = np.full((2, 64), q, np.uint8)
+    pics = [_pictures_of_sparse_blocks(rng, 41, 13, q) for _ in range(3)] + [_pictures_of_sparse_blocks(rng, 12, 7, q)]
+    # coverage, on the reference's coefficients: every rule is met from both sides in these pictures
+    seen = {"run15": 0, "run16": 0, "sum16": 0, "sum17": 0, "empty_first": 0, "pos63": 0, "both_halves": 0}
+    for img in pics:
+        h, w = img.shape
+        zz = oracle.scan_coeffs(np.repeat(img[..., None], 3, 2), quant, yuv_mode=4)
+        nz = zz != 0
+        nz[:, 0] = False
+        for b in nz:
+            merged = 0
+            for half in (0, 32):
+                a, c = b[half:half + 16], b[half + 16:half + 32]
+                if not c.any():
+                    continue
+                end_a = (np.nonzero(a)[0].max() + 1) if a.any() else (1 if half == 0 else 0)
+                run = 16 + np.nonzero(c)[0].min() - end_a if (a.any() or half == 0) else None
+                if run == 15: seen["run15"] += 1
+                if run == 16: seen["run16"] += 1
+                if run is not None and run < 16:
+                    n = int(a.sum() + c.sum())
+                    if n == 16: seen["sum16"] += 1
+                    if n == 17: seen["sum17"] += 1
+                    if not a.any() and half == 0: seen["empty_first"] += 1
+                    if n <= 16: merged += 1
+            if b[63]: seen["pos63"] += 1
+            if merged == 2: seen["both_halves"] += 1
+    assert all(v >= 3 for v in seen.values()), seen
+    for img in pics:
+        h, w = img.shape
+        gray = torch.from_numpy(img).cuda().unsqueeze(0)
+        want = oracle.encode_src(sj.SRC_GRAY, [img], w, h, quant, yuv_mode=4)
+        assert sj.encode_source_method(sj.SRC_GRAY, [gray], w, h, 75.0, 4, 0, engine=engine, quant=quant) == want
+        for method in (1, 4):                                 # optimised tables: statistics + replay kinds
+            assert (sj.encode_source_method(sj.SRC_GRAY, [gray], w, h, 75.0, 4, method, engine=engine, quant=quant) ==
+                    oracle.encode_src(sj.SRC_GRAY, [img], w, h, quant, yuv_mode=4, method=method)), method
+        rgb = np.repeat(img[..., None], 3, 2).copy()
+        for mode in (1, 3):
+            got = sj.encode_device(torch.from_numpy(rgb).cuda().unsqueeze(0), 75.0, mode, engine=engine, quant=quant)[0]
+            assert got == oracle.encode_matrices(rgb, quant, yuv_mode=mode), mode
+    # a batch (one launch, parts of several frames in flight), default parameters
+    frames = torch.from_numpy(np.stack([np.repeat(p[..., None], 3, 2) for p in pics[:3]])).cuda()
+    got = sj.encode_device_method(frames, 75.0, 1, 4, engine=engine, quant=quant)
+    for k in range(3):
+        assert got[k] == oracle.encode_full(np.repeat(pics[k][..., None], 3, 2), quant, yuv_mode=1, method=4), k
+
+
 def test_saturated_primaries_chroma_plus_128(engine, oracle):
     """Pure blue makes Cb = +128 and pure red Cr = +128 (one past the int8 range the other samples stay in):
     four such columns in a block put the row pass' even sum at 32768, one past int16 -- solid red and blue
