@@ -443,6 +443,25 @@ def test_kept_blocks_narrow_and_wide(engine, oracle):
                 assert got[k] == oracle.encode_method(imgs[k], q, mode, method), (w, h, k, mode, q, method)
 
 
+def test_batches_over_the_scratch_limit_go_in_several_launches(oracle, monkeypatch):
+    """A batch whose segment scratch would pass the engine's limit (SJPEG_HIP_SCRATCH_LIMIT_BYTES, read when the engine
+    is made; 16 GiB by default) is coded as several launches of as many frames as fit: same bytes, one frame per launch
+    (limit 1) or a few, ordered and pipelined, one header for all and a header per frame (default parameters)."""
+    imgs = [synth.g_struct(176, 96, 300 + k) for k in range(7)]
+    frames = torch.from_numpy(np.stack(imgs)).cuda()
+    want = [oracle.encode(im, 80.0, 1) for im in imgs]
+    want4 = [oracle.encode_method(im, 80.0, 1, 4) for im in imgs]
+    for limit in ("1", "150000", "400000"):
+        monkeypatch.setenv("SJPEG_HIP_SCRATCH_LIMIT_BYTES", limit)
+        eng = sj.Engine(0)
+        for piped in (False, True):
+            eng.set_pipelined(piped)
+            assert sj.encode_device(frames, 80.0, 1, engine=eng) == want, (limit, piped)
+            assert sj.encode_device(frames, 80.0, 1, engine=eng) == want, (limit, piped)
+        eng.set_pipelined(False)
+        assert sj.encode_device_method(frames, 80.0, 1, 4, engine=eng) == want4, limit
+
+
 def _pictures_of_sparse_blocks(rng, bw, bh, q):
     """Gray pictures whose 8x8 blocks are inverse DCTs of chosen sparse coefficient patterns (levels +-1..3 times
     the quantizer step q: they survive the rounding to 8 bits, everything else stays zero), built to sit ON the rules
