@@ -141,6 +141,7 @@ struct sjpeg_hip_engine {
   const void* tables_held_at = nullptr; const void* header_held_at = nullptr;
   hipStream_t tables_stream = nullptr, header_stream = nullptr;
   DevBuf<uint32_t> seg_words, seg_nbits, pool, pool_ctr, seg_xbase, ubuf, chunk_ff, partial, replay;
+  DevBuf<uint32_t> frame_flags;        // K2's copy of every frame's "overran its pool" flag (stitch_kernels.h)
   int replay_w = 0, replay_h = 0, replay_mode = 0, replay_nframes = 0;   // what `replay` holds (0 = nothing)
   // A batch coded in parts (sjpeg_hip_encode_batch_src): the statistics / replay calls of a part address the
   // kept blocks of frames [replay_first, replay_first + nframes) of a buffer for replay_total frames.
@@ -565,6 +566,7 @@ void sjpeg_hip_engine_destroy(sjpeg_hip_engine* e) {
   (void)hipSetDevice(e->device);
   e->tables.release(); e->header.release(); e->seg_words.release(); e->seg_nbits.release(); e->pool.release(); e->pool_ctr.release(); e->seg_xbase.release(); e->replay.release();
   e->ubuf.release(); e->chunk_ff.release(); e->partial.release(); e->seg_off.release(); e->chunk_off.release(); e->hdr_off.release(); e->stamps.release();
+  e->frame_flags.release();
   for (auto& ev : e->ev) if (ev) (void)hipEventDestroy(ev);
   for (auto& sg : e->stage) {
     if (sg.busy) (void)hipEventSynchronize(sg.ev);
@@ -586,6 +588,7 @@ int sjpeg_hip_engine_trim(sjpeg_hip_engine* e) {
   e->seg_words2.release(); e->seg_nbits2.release(); e->pool2.release(); e->pool_ctr2.release(); e->seg_xbase2.release();
   e->ubuf.release(); e->chunk_ff.release(); e->partial.release(); e->replay.release();
   e->seg_off.release(); e->chunk_off.release(); e->hdr_off.release(); e->stamps.release();
+  e->frame_flags.release();
   e->tables.release(); e->header.release();        // (per-frame tables of a large batch are scratch like the rest)
   for (auto& sg : e->stage) {                      // ... and so are the pinned blocks they were uploaded through
     // (their copies are done: the device was waited for above; the event is waited for all the same, so that the
@@ -918,6 +921,7 @@ static int encode_scan_one(sjpeg_hip_engine* e, const sjpeg_hip_source* src, int
   if ((rc = e->ubuf.ensure(static_cast<size_t>(nframes) * ubuf_words))) return rc;
   if ((rc = e->chunk_ff.ensure(static_cast<size_t>(nframes) * max_chunks))) return rc;
   if ((rc = e->chunk_off.ensure(static_cast<size_t>(nframes) * max_chunks))) return rc;
+  if ((rc = e->frame_flags.ensure(static_cast<size_t>(nframes)))) return rc;
   if ((rc = e->header.ensure(header_size > 0 ? header_size : 1))) return rc;
   if (header_size > 0) {
     const uint8_t* const hb = static_cast<const uint8_t*>(header);
@@ -973,6 +977,12 @@ static int encode_scan_one(sjpeg_hip_engine* e, const sjpeg_hip_source* src, int
   }
   s.hdr_off = multi ? e->hdr_off.p : nullptr;
   s.seg_first = a.seg_first; s.rst_tail = rst_tail;
+  s.frame_flags = e->frame_flags.p;
+  // few, small frames (the launches whose time is launch latency): K4 inside K5 -- one dependent launch less.  (Not
+  // in pipelined mode, whose hand-over hangs on K4; not with packed output or restart markers, which read what K4 writes.)
+  static const bool no_fuse_k4 = getenv("SJPEG_HIP_NO_FUSED_K4") != nullptr;        // (A/B)
+  s.fused_k4 = (!no_fuse_k4 && !piped && s.pack_off == nullptr && !a.rst && max_chunks <= kFusedChunks &&
+                static_cast<size_t>(nframes) * g.nseg <= 8192) ? 1 : 0;
 
   if (e->timing) HIP_TRY(hipEventRecord(e->ev[0], st));
   if (tables->flags & SJPEG_HIP_QUANT_REPLAY) {
@@ -1005,8 +1015,10 @@ static int encode_scan_one(sjpeg_hip_engine* e, const sjpeg_hip_source* src, int
   if (gx > max_chunks) gx = max_chunks;
   hipLaunchKernelGGL(place_segments, dim3((g.nseg * s.subs + 3) / 4, nframes), dim3(kThreads), 0, hs, s);
   HIP_TRY(hipGetLastError());
-  hipLaunchKernelGGL(scan_chunk_offsets, dim3(nframes), dim3(kThreads), 0, hs, s);
-  HIP_TRY(hipGetLastError());
+  if (!s.fused_k4) {
+    hipLaunchKernelGGL(scan_chunk_offsets, dim3(nframes), dim3(kThreads), 0, hs, s);
+    HIP_TRY(hipGetLastError());
+  }
   e->ctr_clean_at[set] = a.pool_ctr; e->ctr_clean_n[set] = static_cast<size_t>(nframes);
   if (piped) {                                     // (K4 is the last reader of this set: it looks at the pool's overrun flag)
     HIP_TRY(hipEventRecord(e->k3_done[set], hs));
@@ -1019,7 +1031,8 @@ static int encode_scan_one(sjpeg_hip_engine* e, const sjpeg_hip_source* src, int
     hipLaunchKernelGGL(pack_frame_edges, dim3(nframes), dim3(kThreads), 0, hs, s);
     HIP_TRY(hipGetLastError());
   }
-  hipLaunchKernelGGL(stuff_chunks, dim3(gx, nframes), dim3(kThreads), 0, hs, s);
+  if (s.fused_k4) hipLaunchKernelGGL(stuff_chunks<true>, dim3(gx, nframes), dim3(kThreads), 0, hs, s);
+  else hipLaunchKernelGGL(stuff_chunks<false>, dim3(gx, nframes), dim3(kThreads), 0, hs, s);
   HIP_TRY(hipGetLastError());
   if (a.rst && g.nseg - 1 + rst_tail > 0) {
     hipLaunchKernelGGL(patch_restart_markers, dim3((g.nseg - 1 + rst_tail + 3) / 4, nframes), dim3(kThreads), 0, hs, s);
@@ -1258,7 +1271,7 @@ int sjpeg_hip_stitch_bands(sjpeg_hip_engine* e, int nbands, const uint32_t* d_wo
   HIP_TRY(hipGetLastError());
   uint32_t gx = 4096u;
   if (gx > max_chunks) gx = max_chunks;
-  hipLaunchKernelGGL(stuff_chunks, dim3(gx, 1), dim3(kThreads), 0, st, s);
+  hipLaunchKernelGGL(stuff_chunks<false>, dim3(gx, 1), dim3(kThreads), 0, st, s);
   HIP_TRY(hipGetLastError());
   return 0;
 }

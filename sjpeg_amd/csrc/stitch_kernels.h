@@ -35,7 +35,16 @@ struct StitchArgs {
   uint32_t wide_subs;                      // K3: an ordinary call whose (few) segments are cut into sub-ranges of 768 words
   int seg_first;                           // restart mode, band of a frame: frame-level index of segment 0 ...
   int rst_tail;                            // ... and whether the band's last interval gets its marker too (it is not the frame's last)
+  // [nframes]: K2 takes the frame's "overran its pool" flag here and leaves the pool's counters at zero for the next
+  // call; K3 .. K5 read the copy.  (NULL -- bands, which have no K4 --: K3 reads the counter itself.)
+  uint32_t* frame_flags;
+  // small launches: K5 works the chunk offsets out itself (every workgroup scans the frame's 0xFF counts, at most
+  // 2048 of them) and its first workgroup does what else K4 does -- size, header, EOI: no K4 launch
+  int fused_k4;
 };
+__device__ __forceinline__ bool frame_overran(const StitchArgs& a, int frame) {
+  return a.frame_flags != nullptr ? a.frame_flags[frame] != 0u : (a.pool_ctr != nullptr && a.pool_ctr[2 * frame + 1] != 0u);
+}
 
 __global__ __launch_bounds__(kThreads) void scan_seg_offsets(const StitchArgs a) {
   __shared__ uint32_t scratch[16];
@@ -94,6 +103,11 @@ __global__ __launch_bounds__(kThreads) void scan_seg_offsets(const StitchArgs a)
   const uint32_t nchunks = static_cast<uint32_t>(nch64);
   uint32_t* ff = a.chunk_ff + static_cast<size_t>(frame) * a.max_chunks;
   for (uint32_t i = threadIdx.x; i < nchunks; i += kThreads) ff[i] = 0;
+  if (a.frame_flags != nullptr && a.pool_ctr != nullptr && threadIdx.x == 0) {
+    a.frame_flags[frame] = a.pool_ctr[2 * frame + 1];
+    const_cast<uint32_t*>(a.pool_ctr)[2 * frame] = 0u;
+    const_cast<uint32_t*>(a.pool_ctr)[2 * frame + 1] = 0u;
+  }
 }
 
 // ------------------------------------------------------------------------------------
@@ -176,7 +190,7 @@ __global__ __launch_bounds__(kThreads) void place_segments(const StitchArgs a) {
   const unsigned long long U = (T + 7) >> 3;                // bytes incl. 1-bit padding
   // a frame whose stream is longer than the scratch sized from out_stride cannot fit its output slot
   // either; one that overran its pool has words missing: K4 reports size 0 for both, nothing to place
-  if (((U + 3) >> 2) + 1 > a.ubuf_words || (a.pool_ctr != nullptr && a.pool_ctr[2 * frame + 1] != 0u)) return;
+  if (((U + 3) >> 2) + 1 > a.ubuf_words || frame_overran(a, frame)) return;
   // word i of segment sc: in its slot, or (the rare long segment) in the frame's pool
   const uint32_t* const pool_f = a.pool == nullptr ? nullptr : a.pool + static_cast<size_t>(frame) * a.pool_words;
   const uint32_t* const xbase_f = a.seg_xbase == nullptr ? nullptr : a.seg_xbase + static_cast<size_t>(frame) * a.nseg;
@@ -404,11 +418,10 @@ __global__ __launch_bounds__(kThreads) void scan_chunk_offsets(const StitchArgs 
   const uint32_t hoff = a.hdr_off ? a.hdr_off[frame] : 0u;
   const uint32_t hsize = a.hdr_off ? a.hdr_off[frame + 1] - hoff : a.header_size;
   const unsigned long long size = hsize + body + (a.append_eoi ? 2 : 0);
-  const bool fits = size <= a.out_stride && ((U + 3) >> 2) + 1 <= a.ubuf_words &&
-                    (a.pool_ctr == nullptr || a.pool_ctr[2 * frame + 1] == 0u);
-  // last reader of the frame's pool counters: leave them at zero for the next call (scan_engine.hip)
+  const bool fits = size <= a.out_stride && ((U + 3) >> 2) + 1 <= a.ubuf_words && !frame_overran(a, frame);
+  // (without K2's copy of the flag this is the last reader of the frame's pool counters: it leaves them at zero)
   __syncthreads();
-  if (a.pool_ctr != nullptr && threadIdx.x == 0) {
+  if (a.frame_flags == nullptr && a.pool_ctr != nullptr && threadIdx.x == 0) {
     const_cast<uint32_t*>(a.pool_ctr)[2 * frame] = 0u;
     const_cast<uint32_t*>(a.pool_ctr)[2 * frame + 1] = 0u;
   }
@@ -468,17 +481,53 @@ __global__ __launch_bounds__(kThreads) void pack_frame_edges(const StitchArgs a)
 // it has loaded itself (a fifth source word), so no two threads ever exchange anything.  94 % of the
 // threads hold no 0xFF byte (1 byte in 256 of an entropy-coded stream): four byte-aligns and two
 // ds_write2_b32 instead of the sixteen byte stores of the general path, which the others keep.
+constexpr uint32_t kFusedChunks = 2048;                     // K4 inside K5: frames of up to 8 MiB of un-stuffed stream
+template <bool FUSED>
 __global__ __launch_bounds__(kThreads) void stuff_chunks(const StitchArgs a) {
   __shared__ uint32_t scratch[16];
   __shared__ __attribute__((aligned(16))) uint8_t stage[2 * kChunkBytes + 64];
+  __shared__ uint32_t fused_off[FUSED ? kFusedChunks : 1];   // FUSED: 0xFF bytes in front of every chunk of the frame
   const int frame = blockIdx.y;
   const unsigned long long T = a.seg_off[static_cast<size_t>(frame) * (a.nseg + 1) + a.nseg];
   const unsigned long long U = (T + 7) >> 3;
   const uint32_t nchunks = static_cast<uint32_t>((U + kChunkBytes - 1) / kChunkBytes);
   const uint32_t* ub = a.ubuf + static_cast<size_t>(frame) * a.ubuf_words;
   const unsigned long long* co = a.chunk_off + static_cast<size_t>(frame) * a.max_chunks;
-  const uint32_t hsize = a.hdr_off ? a.hdr_off[frame + 1] - a.hdr_off[frame] : a.header_size;
-  if (a.sizes[frame] == 0) return;                          // did not fit (see K4)
+  const uint32_t hoff = a.hdr_off ? a.hdr_off[frame] : 0u;
+  const uint32_t hsize = a.hdr_off ? a.hdr_off[frame + 1] - hoff : a.header_size;
+  if (FUSED) {
+    // K4's scan, by every workgroup for itself (the counts of at most 2048 chunks: eight per thread, one scan): no
+    // launch between K3 and this kernel.  Workgroup 0 also reports the size and writes header and EOI.
+    const uint32_t* ff = a.chunk_ff + static_cast<size_t>(frame) * a.max_chunks;
+    const uint32_t nch = nchunks < a.max_chunks ? nchunks : a.max_chunks;     // (more: the frame does not fit, below)
+    constexpr uint32_t kRun = kFusedChunks / kThreads;
+    const uint32_t i0 = threadIdx.x * kRun;
+    uint32_t v[kRun], mine = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < kRun; ++j) {
+      v[j] = (i0 + j < nch) ? ff[i0 + j] : 0u;
+      mine += v[j];
+    }
+    uint32_t total;
+    uint32_t at = wg_exclusive_scan<kThreads>(mine, scratch, &total);
+#pragma unroll
+    for (uint32_t j = 0; j < kRun; ++j) { fused_off[i0 + j] = at; at += v[j]; }
+    const unsigned long long body = U + total;
+    const unsigned long long size = hsize + body + (a.append_eoi ? 2 : 0);
+    const bool fits = nchunks <= kFusedChunks && size <= a.out_stride && ((U + 3) >> 2) + 1 <= a.ubuf_words && !frame_overran(a, frame);
+    if (blockIdx.x == 0) {
+      if (threadIdx.x == 0) a.sizes[frame] = fits ? size : 0ull;
+      if (fits) {
+        uint8_t* const dst = a.out + static_cast<size_t>(frame) * a.out_stride;
+        if (threadIdx.x == 0 && a.append_eoi) { dst[hsize + body] = 0xff; dst[hsize + body + 1] = 0xd9; }
+        for (uint32_t i = threadIdx.x; i < hsize; i += kThreads) dst[i] = a.header[hoff + i];
+      }
+    }
+    if (!fits) return;                                      // (uniform over the frame's workgroups)
+    __syncthreads();                                        // fused_off is complete
+  } else {
+    if (a.sizes[frame] == 0) return;                        // did not fit (see K4)
+  }
   uint8_t* const dst0 = frame_out(a, frame) + hsize;
   // the 16 bytes of this thread in the NEXT chunk of the workgroup (and the word behind them) are
   // requested while the current ones are stuffed
@@ -490,7 +539,7 @@ __global__ __launch_bounds__(kThreads) void stuff_chunks(const StitchArgs a) {
     if (chunk >= nchunks) return;
     const unsigned long long w0 = static_cast<unsigned long long>(chunk) * kChunkWords + threadIdx.x * 4;
     const unsigned long long byte0 = w0 * 4;
-    *off = co[chunk];
+    *off = FUSED ? static_cast<unsigned long long>(fused_off[chunk]) : co[chunk];
     if (byte0 < U) {
       *q = *reinterpret_cast<const uint4*>(ub + w0);
       *valid = (U - byte0 >= 16) ? 16 : static_cast<int>(U - byte0);
