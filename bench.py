@@ -69,7 +69,7 @@ W, H, QUALITY = 3840, 2160, 75.0
 HBM_PEAK = 8.0e12          # B/s, MI355X HBM3E spec (MI355X_MICROARCH.md)
 N_SIMD, CLOCK_HZ = 256 * 4, 2.4e9
 # the PMC pass of this build the static figures (HBM traffic, VALU instructions per wave) come from
-PMC_SUMMARY = os.path.join("profiles", "r04", "final_pmc_summary.txt")
+PMC_SUMMARY = os.path.join("profiles", "r05", "final_pmc_summary.txt")
 
 
 def host_cpus():
