@@ -125,7 +125,11 @@ typedef struct sjpeg_hip_huffman_spec {
  * first waits (on the device) for that one's work -- use one engine per stream to overlap.
  * A stream handed to a call must stay alive until the engine's NEXT call has been issued (that call
  * orders itself behind it with an event); if it was destroyed earlier the engine falls back to a
- * device-wide synchronisation instead of failing. */
+ * device-wide synchronisation instead of failing.
+ * The scratch of an encode is sized from the bytes the caller gives every frame (out_stride), per frame of the
+ * batch; a batch that would take more than SJPEG_HIP_SCRATCH_LIMIT_BYTES of it (environment, read when the engine
+ * is created; default 16 GiB) is coded as several launches of as many frames as fit, in order, on the same
+ * stream -- the caller sees one call. */
 typedef struct sjpeg_hip_engine sjpeg_hip_engine;
 
 int sjpeg_hip_abi_version(void);
