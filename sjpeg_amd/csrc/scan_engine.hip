@@ -94,12 +94,12 @@ bool frame_geo(int W, int H, int mode, FrameGeo* g) {
 // measurement aid (SJPEG_HIP_BATCH_DEBUG=1): microseconds since this thread's previous mark, on stderr -- which runtime
 // call of a launch sequence the host spent its time in (tools/slow_call_timeline.py)
 inline void dbg_mark(const char* what) {
-  static const bool on = getenv("SJPEG_HIP_BATCH_DEBUG") != nullptr && atoi(getenv("SJPEG_HIP_BATCH_DEBUG")) >= 2;
-  if (!on) return;
+  static const int level = getenv("SJPEG_HIP_BATCH_DEBUG") != nullptr ? atoi(getenv("SJPEG_HIP_BATCH_DEBUG")) : 0;
+  if (level < 2) return;
   static thread_local std::chrono::steady_clock::time_point last = std::chrono::steady_clock::now();
   const auto now = std::chrono::steady_clock::now();
   const double us = std::chrono::duration<double, std::micro>(now - last).count();
-  if (us > 200.0) fprintf(stderr, "    step %-28s %9.1f us\n", what, us);
+  if (us > (level >= 3 ? 6.0 : 200.0)) fprintf(stderr, "    step %-28s %9.1f us\n", what, us);   // (3: every step over 6 us)
   last = now;
 }
 
@@ -184,6 +184,10 @@ struct sjpeg_hip_engine {
   int set = 0;                                   // buffer set of the NEXT call
   hipEvent_t k1_done = nullptr, side_done = nullptr, k3_done[2] = {nullptr, nullptr};
   bool k3_pending[2] = {false, false}, side_pending = false;
+  // side_done is recorded LAZILY, by whoever is about to wait on it (side_mark): an event record is a packet in the
+  // queue and about 5 us of host time, and a loop of pipelined calls needs none -- one frame per call was bound by the
+  // HOST at five event calls per call (36-46 us against 35 of device time, `tools/one_frame_piped.py`)
+  bool side_recorded = false;
 };
 
 namespace {
@@ -271,6 +275,15 @@ sjpeg_hip_source rgb_source(const void* d_rgb, int64_t row_stride, int64_t frame
   return s;
 }
 
+// the event behind everything the engine has put on its own (stitch) stream so far
+int side_mark(sjpeg_hip_engine* e) {
+  if (e->side_pending && !e->side_recorded) {
+    HIP_TRY(hipEventRecord(e->side_done, e->side));
+    e->side_recorded = true;
+  }
+  return 0;
+}
+
 // Orders this call after everything the engine was asked to do on another stream.
 int order_on_stream(sjpeg_hip_engine* e, hipStream_t st) {
   if (e->last_stream_valid && e->last_stream != st) {
@@ -280,7 +293,7 @@ int order_on_stream(sjpeg_hip_engine* e, hipStream_t st) {
     bool ordered = (e->cross_ev != nullptr) || hipEventCreateWithFlags(&e->cross_ev, hipEventDisableTiming) == hipSuccess;
     ordered = ordered && hipEventRecord(e->cross_ev, e->last_stream) == hipSuccess &&
               hipStreamWaitEvent(st, e->cross_ev, 0) == hipSuccess;
-    if (ordered && e->side_pending) ordered = hipStreamWaitEvent(st, e->side_done, 0) == hipSuccess;
+    if (ordered && e->side_pending) ordered = side_mark(e) == 0 && hipStreamWaitEvent(st, e->side_done, 0) == hipSuccess;
     if (!ordered) {
       (void)hipGetLastError();                     // clear the sticky error of the stale handle
       e->last_stream_valid = false;
@@ -451,6 +464,7 @@ int prepare_scan(sjpeg_hip_engine* e, const sjpeg_hip_source* src,
   dbg_mark("prepare: ordered");
   // anything but a pipelined encode shares buffers with the stitch still running on the engine's stream
   if (e->side_pending && !piped_encode) {
+    if (int rcm = side_mark(e)) return rcm;
     HIP_TRY(hipStreamWaitEvent(st, e->side_done, 0));
   }
   int rc;
@@ -603,7 +617,7 @@ int sjpeg_hip_engine_trim(sjpeg_hip_engine* e) {
   e->last_nseg = e->last_nframes = 0;
   e->ctr_clean_at[0] = e->ctr_clean_at[1] = nullptr;
   e->ctr_clean_n[0] = e->ctr_clean_n[1] = 0;
-  e->k3_pending[0] = e->k3_pending[1] = e->side_pending = false;
+  e->k3_pending[0] = e->k3_pending[1] = e->side_pending = e->side_recorded = false;
   e->last_stream_valid = false;
   e->ev_valid = false;
   return 0;
@@ -630,7 +644,7 @@ int sjpeg_hip_engine_set_pipelined(sjpeg_hip_engine* e, int on) {
   }
   if (!on && e->pipelined) {                       // drain: from here on the caller's stream orders everything again
     HIP_TRY(hipStreamSynchronize(e->side));
-    e->k3_pending[0] = e->k3_pending[1] = e->side_pending = false;
+    e->k3_pending[0] = e->k3_pending[1] = e->side_pending = e->side_recorded = false;
   }
   e->pipelined = on != 0;
   e->header_held_at = nullptr;                    // the header buffer changes streams
@@ -641,6 +655,7 @@ int sjpeg_hip_engine_wait(sjpeg_hip_engine* e, void* stream) {
   if (e == nullptr) return fail(SJPEG_HIP_EINVAL, "engine == NULL");
   if (e->side_pending) {
     HIP_TRY(hipSetDevice(e->device));
+    if (int rcm = side_mark(e)) return rcm;
     HIP_TRY(hipStreamWaitEvent(static_cast<hipStream_t>(stream), e->side_done, 0));
   }
   return 0;
@@ -949,7 +964,11 @@ static int encode_scan_one(sjpeg_hip_engine* e, const sjpeg_hip_source* src, int
       a.pool = e->pool2.p; a.pool_ctr = e->pool_ctr2.p; a.seg_xbase = e->seg_xbase2.p;
     }
     // this set was last read by the K3 of the call before the previous one
-    if (e->k3_pending[set]) HIP_TRY(hipStreamWaitEvent(st, e->k3_done[set], 0));
+    // (two calls back: as a rule long done, and a query costs the host a tenth of what a wait in the queue does)
+    if (e->k3_pending[set]) {
+      if (hipEventQuery(e->k3_done[set]) == hipSuccess) e->k3_pending[set] = false;
+      else { (void)hipGetLastError(); HIP_TRY(hipStreamWaitEvent(st, e->k3_done[set], 0)); }
+    }
   }
   if (e->ctr_clean_at[set] != a.pool_ctr || e->ctr_clean_n[set] < static_cast<size_t>(nframes)) {
     HIP_TRY(hipMemsetAsync(a.pool_ctr, 0, static_cast<size_t>(nframes) * 2 * sizeof(uint32_t), st));
@@ -1001,14 +1020,18 @@ static int encode_scan_one(sjpeg_hip_engine* e, const sjpeg_hip_source* src, int
     rc = launch_scan<kKindEncode>(yuv_mode, cls, dim3(g.nseg, nframes), st, a);
   }
   if (rc) return rc;
+  dbg_mark("encode: K1 launched");
   if (e->timing) HIP_TRY(hipEventRecord(e->ev[1], st));
   if (piped) {
     HIP_TRY(hipEventRecord(e->k1_done, st));
+    dbg_mark("encode: k1_done recorded");
     HIP_TRY(hipStreamWaitEvent(hs, e->k1_done, 0));
+    dbg_mark("encode: side waits k1_done");
   }
 
   hipLaunchKernelGGL(scan_seg_offsets, dim3(nframes), dim3(kThreads), 0, hs, s);
   HIP_TRY(hipGetLastError());
+  dbg_mark("encode: K2 launched");
   // the chunk count is only known on the device: a fixed grid strides over the chunks
   uint32_t gx = 4096u / static_cast<uint32_t>(nframes);
   if (gx < 64) gx = 64;
@@ -1020,8 +1043,10 @@ static int encode_scan_one(sjpeg_hip_engine* e, const sjpeg_hip_source* src, int
     HIP_TRY(hipGetLastError());
   }
   e->ctr_clean_at[set] = a.pool_ctr; e->ctr_clean_n[set] = static_cast<size_t>(nframes);
+  dbg_mark("encode: K3 K4 launched");
   if (piped) {                                     // (K4 is the last reader of this set: it looks at the pool's overrun flag)
     HIP_TRY(hipEventRecord(e->k3_done[set], hs));
+    dbg_mark("encode: k3_done recorded");
     e->k3_pending[set] = true;
     e->set = set ^ 1;
   }
@@ -1034,13 +1059,14 @@ static int encode_scan_one(sjpeg_hip_engine* e, const sjpeg_hip_source* src, int
   if (s.fused_k4) hipLaunchKernelGGL(stuff_chunks<true>, dim3(gx, nframes), dim3(kThreads), 0, hs, s);
   else hipLaunchKernelGGL(stuff_chunks<false>, dim3(gx, nframes), dim3(kThreads), 0, hs, s);
   HIP_TRY(hipGetLastError());
+  dbg_mark("encode: K5 launched");
   if (a.rst && g.nseg - 1 + rst_tail > 0) {
     hipLaunchKernelGGL(patch_restart_markers, dim3((g.nseg - 1 + rst_tail + 3) / 4, nframes), dim3(kThreads), 0, hs, s);
     HIP_TRY(hipGetLastError());
   }
   if (piped) {
-    HIP_TRY(hipEventRecord(e->side_done, hs));
-    e->side_pending = true;
+    e->side_pending = true;                        // (side_done itself: side_mark(), when somebody waits for it)
+    e->side_recorded = false;
   }
   if (e->timing) {
     HIP_TRY(hipEventRecord(e->ev[2], hs));

@@ -21,7 +21,8 @@ for piped in (False, True, False, True):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(reps): step()
+    t1 = time.perf_counter()                     # every call has returned: what the HOST needs per call
     torch.cuda.synchronize()
-    res.append("%s %.2f us" % ("pipelined" if piped else "ordered", (time.perf_counter() - t0) / reps * 1e6))
+    res.append("%s %.2f us (host %.2f)" % ("pipelined" if piped else "ordered", (time.perf_counter() - t0) / reps * 1e6, (t1 - t0) / reps * 1e6))
 eng.set_pipelined(False)
 print("  ".join(res))
