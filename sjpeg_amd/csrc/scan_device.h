@@ -79,6 +79,10 @@ struct ScanArgs {
   unsigned long long* stamps;  // profiling (env SJPEG_HIP_STAMPS): 8 cycle stamps per workgroup
   int stamp_real;              // ... taken from the device-wide 100 MHz counter instead
   int ablate;              // profiling knob (env SJPEG_HIP_ABLATE): stop after phase 1/2/3; 0 = full
+  // small launches without a K2 (stitch_kernels.h, fused_k2): every workgroup zeroes its share of the frame's 0xFF
+  // counters for K3 -- clear_per of the frame's clear_n, from index seg * clear_per on (NULL: K2 does it)
+  uint32_t* clear_ff;
+  uint32_t clear_per, clear_n;
 };
 
 // LDS carve of K1 (bytes, all offsets multiples of 16): the block slots, then the region R behind them.

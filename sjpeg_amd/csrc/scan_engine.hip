@@ -1002,6 +1002,12 @@ static int encode_scan_one(sjpeg_hip_engine* e, const sjpeg_hip_source* src, int
   static const bool no_fuse_k4 = getenv("SJPEG_HIP_NO_FUSED_K4") != nullptr;        // (A/B)
   s.fused_k4 = (!no_fuse_k4 && !piped && s.pack_off == nullptr && !a.rst && max_chunks <= kFusedChunks &&
                 static_cast<size_t>(nframes) * g.nseg <= 8192) ? 1 : 0;
+  static const bool no_fuse_k2 = getenv("SJPEG_HIP_NO_FUSED_K2") != nullptr;        // (A/B)
+  s.fused_k2 = (s.fused_k4 && !no_fuse_k2 && g.nseg <= kFusedSegs && e->ablate == 0) ? 1 : 0;
+  if (s.fused_k2) {                                // K1 clears the 0xFF counters K2 would have
+    a.clear_ff = e->chunk_ff.p; a.clear_n = max_chunks;
+    a.clear_per = (max_chunks + static_cast<uint32_t>(g.nseg) - 1u) / static_cast<uint32_t>(g.nseg);
+  }
 
   if (e->timing) HIP_TRY(hipEventRecord(e->ev[0], st));
   if (tables->flags & SJPEG_HIP_QUANT_REPLAY) {
@@ -1029,14 +1035,17 @@ static int encode_scan_one(sjpeg_hip_engine* e, const sjpeg_hip_source* src, int
     dbg_mark("encode: side waits k1_done");
   }
 
-  hipLaunchKernelGGL(scan_seg_offsets, dim3(nframes), dim3(kThreads), 0, hs, s);
-  HIP_TRY(hipGetLastError());
+  if (!s.fused_k2) {
+    hipLaunchKernelGGL(scan_seg_offsets, dim3(nframes), dim3(kThreads), 0, hs, s);
+    HIP_TRY(hipGetLastError());
+  }
   dbg_mark("encode: K2 launched");
   // the chunk count is only known on the device: a fixed grid strides over the chunks
   uint32_t gx = 4096u / static_cast<uint32_t>(nframes);
   if (gx < 64) gx = 64;
   if (gx > max_chunks) gx = max_chunks;
-  hipLaunchKernelGGL(place_segments, dim3((g.nseg * s.subs + 3) / 4, nframes), dim3(kThreads), 0, hs, s);
+  if (s.fused_k2) hipLaunchKernelGGL(place_segments<true>, dim3((g.nseg * s.subs + 3) / 4, nframes), dim3(kThreads), 0, hs, s);
+  else hipLaunchKernelGGL(place_segments<false>, dim3((g.nseg * s.subs + 3) / 4, nframes), dim3(kThreads), 0, hs, s);
   HIP_TRY(hipGetLastError());
   if (!s.fused_k4) {
     hipLaunchKernelGGL(scan_chunk_offsets, dim3(nframes), dim3(kThreads), 0, hs, s);
@@ -1242,7 +1251,7 @@ int sjpeg_hip_encode_band_src(sjpeg_hip_engine* e, const sjpeg_hip_source* src, 
   if (rc) return rc;
   hipLaunchKernelGGL(scan_seg_offsets, dim3(1), dim3(kThreads), 0, st, s);
   HIP_TRY(hipGetLastError());
-  hipLaunchKernelGGL(place_segments, dim3((nloc + 3) / 4, 1), dim3(kThreads), 0, st, s);
+  hipLaunchKernelGGL(place_segments<false>, dim3((nloc + 3) / 4, 1), dim3(kThreads), 0, st, s);
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -1291,7 +1300,7 @@ int sjpeg_hip_stitch_bands(sjpeg_hip_engine* e, int nbands, const uint32_t* d_wo
   hipLaunchKernelGGL(scan_seg_offsets, dim3(1), dim3(kThreads), 0, st, s);
   HIP_TRY(hipGetLastError());
   const uint32_t units = static_cast<uint32_t>(nbands) * s.subs;
-  hipLaunchKernelGGL(place_segments, dim3((units + 3) / 4, 1), dim3(kThreads), 0, st, s);
+  hipLaunchKernelGGL(place_segments<false>, dim3((units + 3) / 4, 1), dim3(kThreads), 0, st, s);
   HIP_TRY(hipGetLastError());
   hipLaunchKernelGGL(scan_chunk_offsets, dim3(1), dim3(kThreads), 0, st, s);
   HIP_TRY(hipGetLastError());

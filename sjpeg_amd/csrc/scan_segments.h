@@ -98,6 +98,12 @@ __global__ __launch_bounds__(kScanThreads, ((KINDX == kKindHisto && SRC == kSrcR
   stamp(0);
   PHASE_PRIO(0);
   RACE_POINT(0);
+  if (KIND == kKindEncode && a.clear_ff != nullptr) {
+    for (uint32_t i = tid; i < a.clear_per; i += kScanThreads) {
+      const uint32_t idx = static_cast<uint32_t>(seg) * a.clear_per + i;
+      if (idx < a.clear_n) a.clear_ff[static_cast<size_t>(frame) * a.clear_n + idx] = 0u;
+    }
+  }
   const int m_first = (seg + a.seg_first) * G::kSegMcus;       // first coded MCU of the segment
   const int n_coded = min(G::kSegMcus, a.n_mcus - m_first);
   // (restart mode: every segment is a restart interval, its DC predictors start at zero)

@@ -41,6 +41,10 @@ struct StitchArgs {
   // small launches: K5 works the chunk offsets out itself (every workgroup scans the frame's 0xFF counts, at most
   // 2048 of them) and its first workgroup does what else K4 does -- size, header, EOI: no K4 launch
   int fused_k4;
+  // ... and K3 the segment offsets (every workgroup scans the frame's at most 2048 segment lengths into LDS; its first
+  // workgroup leaves the total and the overrun flag behind for K5, whose first workgroup then zeroes the pool's counters;
+  // K1 has cleared the frame's 0xFF counters): no K2 launch either -- K1, K3, K5
+  int fused_k2;
 };
 __device__ __forceinline__ bool frame_overran(const StitchArgs& a, int frame) {
   return a.frame_flags != nullptr ? a.frame_flags[frame] != 0u : (a.pool_ctr != nullptr && a.pool_ctr[2 * frame + 1] != 0u);
@@ -142,15 +146,44 @@ constexpr int kSpec = 12;                                   // speculative batch
 constexpr int kPlaceLanes = 64;                             // one WAVE per segment, four segments per workgroup
 constexpr int kWideSpec = 3;                                // wide form: speculative batches of 256 words
 struct __attribute__((packed, aligned(4))) Words4 { uint32_t w[4]; };   // 16 bytes at any word address
+constexpr int kFusedSegs = 2048;                            // K2 inside K3: frames of up to 2048 segments
+template <bool FUSED>
 __global__ __launch_bounds__(kThreads) void place_segments(const StitchArgs a) {
+  __shared__ unsigned long long off_lds[FUSED ? kFusedSegs + 1 : 1];
+  __shared__ uint32_t scratch_k2[16];
   const int frame = blockIdx.y;
+  if (FUSED) {
+    // K2's scan, by every workgroup for itself (eight lengths per thread, one scan; the sums stay below 2^32: such a
+    // frame has at most 8 MiB of stream); the loads go out with the speculative ones below
+    const uint32_t* const nb = a.seg_nbits + static_cast<size_t>(frame) * a.nseg;
+    constexpr int kRun = kFusedSegs / kThreads;
+    const int i0 = static_cast<int>(threadIdx.x) * kRun;
+    uint32_t v[kRun], mine = 0;
+#pragma unroll
+    for (int j = 0; j < kRun; ++j) {
+      v[j] = (i0 + j < a.nseg) ? nb[i0 + j] : 0u;
+      mine += v[j];
+    }
+    uint32_t total;
+    uint32_t at = wg_exclusive_scan<kThreads>(mine, scratch_k2, &total);
+#pragma unroll
+    for (int j = 0; j < kRun; ++j) { off_lds[i0 + j] = at; at += v[j]; }
+    if (threadIdx.x == 0) {
+      off_lds[a.nseg] = total;
+      if (blockIdx.x == 0) {
+        a.seg_off[static_cast<size_t>(frame) * (a.nseg + 1) + a.nseg] = total;      // (K5 reads the total here)
+        if (a.frame_flags != nullptr && a.pool_ctr != nullptr) a.frame_flags[frame] = a.pool_ctr[2 * frame + 1];
+      }
+    }
+    __syncthreads();
+  }
   // a wave takes words [sub * kSpec * 64, ...) of one segment; normal segments have one wave
   // (subs == 1, the loop below takes the rare longer rest), whole bands are cut into many
   const uint32_t unit = blockIdx.x * (kThreads / kPlaceLanes) + (threadIdx.x >> 6);
   const int sc0 = static_cast<int>(unit / a.subs);
   const uint32_t ibase = (unit % a.subs) * (a.wide_subs ? kWideSpec * 256u : kSpec * kPlaceLanes);
   if (sc0 >= a.nseg) return;
-  const unsigned long long* off = a.seg_off + static_cast<size_t>(frame) * (a.nseg + 1);
+  const unsigned long long* off = FUSED ? off_lds : a.seg_off + static_cast<size_t>(frame) * (a.nseg + 1);
   const uint32_t* segw = a.seg_words + static_cast<size_t>(frame) * a.nseg * a.slot_words;
   const uint32_t* src = segw + static_cast<size_t>(sc0) * a.slot_words;
   // Two forms of the same loads.  WIDE (every ordinary call): a lane takes 4 consecutive words per batch
@@ -190,7 +223,9 @@ __global__ __launch_bounds__(kThreads) void place_segments(const StitchArgs a) {
   const unsigned long long U = (T + 7) >> 3;                // bytes incl. 1-bit padding
   // a frame whose stream is longer than the scratch sized from out_stride cannot fit its output slot
   // either; one that overran its pool has words missing: K4 reports size 0 for both, nothing to place
-  if (((U + 3) >> 2) + 1 > a.ubuf_words || frame_overran(a, frame)) return;
+  // (FUSED: K2's copy of the flag does not exist yet -- this kernel's first workgroup makes it, for K5)
+  const bool overran = FUSED ? (a.pool_ctr != nullptr && a.pool_ctr[2 * frame + 1] != 0u) : frame_overran(a, frame);
+  if (((U + 3) >> 2) + 1 > a.ubuf_words || overran) return;
   // word i of segment sc: in its slot, or (the rare long segment) in the frame's pool
   const uint32_t* const pool_f = a.pool == nullptr ? nullptr : a.pool + static_cast<size_t>(frame) * a.pool_words;
   const uint32_t* const xbase_f = a.seg_xbase == nullptr ? nullptr : a.seg_xbase + static_cast<size_t>(frame) * a.nseg;
@@ -517,6 +552,10 @@ __global__ __launch_bounds__(kThreads) void stuff_chunks(const StitchArgs a) {
     const bool fits = nchunks <= kFusedChunks && size <= a.out_stride && ((U + 3) >> 2) + 1 <= a.ubuf_words && !frame_overran(a, frame);
     if (blockIdx.x == 0) {
       if (threadIdx.x == 0) a.sizes[frame] = fits ? size : 0ull;
+      if (a.fused_k2 && a.pool_ctr != nullptr && threadIdx.x == 0) {    // (K3, their last reader, is through)
+        const_cast<uint32_t*>(a.pool_ctr)[2 * frame] = 0u;
+        const_cast<uint32_t*>(a.pool_ctr)[2 * frame + 1] = 0u;
+      }
       if (fits) {
         uint8_t* const dst = a.out + static_cast<size_t>(frame) * a.out_stride;
         if (threadIdx.x == 0 && a.append_eoi) { dst[hsize + body] = 0xff; dst[hsize + body + 1] = 0xd9; }
