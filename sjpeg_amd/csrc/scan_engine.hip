@@ -126,6 +126,8 @@ struct DevBuf {
 
 struct sjpeg_hip_engine {
   int device = 0;
+  int cu_count = 256;                  // compute units of the device (the persistent histogram kind sizes its grid by it)
+  int histo_slots = 0;                 // SJPEG_HIP_HISTO_SLOTS, read when the engine is made: workgroups of a histogram launch (tests: many trips)
   DevBuf<DevTables> tables;
   DevBuf<uint8_t> header;
   // what the two buffers hold, and the stream that put it there: a call with the same tables /
@@ -562,6 +564,7 @@ int sjpeg_hip_engine_create(int device, sjpeg_hip_engine** engine) {
   sjpeg_hip_engine* e = new (std::nothrow) sjpeg_hip_engine;
   if (e == nullptr) return fail(SJPEG_HIP_ENOMEM, "host allocation failed");
   e->device = device;
+  if (prop.multiProcessorCount > 0) e->cu_count = prop.multiProcessorCount;
   if (const char* ab = getenv("SJPEG_HIP_ABLATE")) {                       // profiling / race-stress aid only
     e->ablate = atoi(ab);
     if (e->ablate != 0) {
@@ -569,6 +572,7 @@ int sjpeg_hip_engine_create(int device, sjpeg_hip_engine** engine) {
                       "the output of this engine is NOT valid JPEG data\n", e->ablate);
     }
   }
+  if (const char* hs = getenv("SJPEG_HIP_HISTO_SLOTS")) e->histo_slots = atoi(hs);
   if (const char* sm = getenv("SJPEG_HIP_STAMPS")) { e->want_stamps = true; e->stamp_mode = atoi(sm); }
   if (const char* sl = getenv("SJPEG_HIP_SCRATCH_LIMIT_BYTES")) { const long long v = atoll(sl); if (v > 0) e->scratch_limit = static_cast<size_t>(v); }
   *engine = e;
@@ -747,8 +751,28 @@ static int scan_statistics(sjpeg_hip_engine* e, const sjpeg_hip_source* src, int
   const int part_total = e->replay_total > 0 ? e->replay_total : nframes;
   const int part_first = e->replay_total > 0 ? e->replay_first : 0;
   if (part_first < 0 || part_first + nframes > part_total) return fail(SJPEG_HIP_EINVAL, "part outside the batch");
-  if ((rc = e->partial.ensure(static_cast<size_t>(part_total) * g.nseg * words))) return rc;
-  uint32_t* const partial = e->partial.p + static_cast<size_t>(part_first) * g.nseg * words;
+  // The histogram kind is persistent: `groups` workgroups per frame walk the frame's segments and leave one partial
+  // each (kHistoPartialWords).  As many as run at once, in whole trips -- 16 4K frames of 791 segments on 768 slots: 17
+  // trips, 47 groups a frame, 752 workgroups --; at least nseg / 256 (16-bit counters), at most what the partial
+  // buffer's frame stride has room for.
+  size_t frame_words = static_cast<size_t>(g.nseg) * words;
+  int groups = g.nseg;
+  if (histogram) {
+    // (THREE per CU although four would fit: the kernel runs no faster with four -- tools/histogram_ablate.py with
+    // SJPEG_HIP_HISTO_SLOTS --, and four persistent workgroups of 128 registers hold a SIMD's whole register file until the
+    // launch ends: the small kernels of the side stream -- the sums of the previous part, their read-back -- would wait)
+    const long long slots = e->histo_slots > 0 ? e->histo_slots : 3ll * e->cu_count;
+    const long long trips = std::max(1ll, (static_cast<long long>(g.nseg) * nframes + slots - 1) / slots);
+    groups = static_cast<int>((g.nseg + trips - 1) / trips);
+    const int min_groups = (g.nseg + kHistoMaxSegsPerGroup - 1) / kHistoMaxSegsPerGroup;
+    // (small batches: a partial per segment if need be -- twice the old stride; large ones keep the old stride)
+    if (static_cast<size_t>(part_total) * g.nseg * kHistoPartialWords * sizeof(uint32_t) <= (256u << 20)) frame_words = static_cast<size_t>(g.nseg) * kHistoPartialWords;
+    frame_words = std::max(frame_words, static_cast<size_t>(min_groups) * kHistoPartialWords);
+    groups = std::min(groups, static_cast<int>(frame_words / kHistoPartialWords));
+    groups = std::max(groups, min_groups);
+  }
+  if ((rc = e->partial.ensure(static_cast<size_t>(part_total) * frame_words))) return rc;
+  uint32_t* const partial = e->partial.p + static_cast<size_t>(part_first) * frame_words;
   a.partial = partial;
   const bool coefs_in = !histogram && e->coefs_use && (tables->flags & SJPEG_HIP_QUANT_KEEP) && !(tables->flags & SJPEG_HIP_QUANT_TRELLIS);
   if (coefs_in) {
@@ -757,7 +781,8 @@ static int scan_statistics(sjpeg_hip_engine* e, const sjpeg_hip_source* src, int
       return fail(SJPEG_HIP_EINVAL, "no histogram pass of these frames left its coefficients behind");
     }
   }
-  if ((!histogram && (tables->flags & SJPEG_HIP_QUANT_KEEP)) || (histogram && e->coefs_keep)) {
+  static const bool force_keep = getenv("SJPEG_HIP_FORCE_COEF_KEEP") != nullptr;   // (measurement aid: tools/histogram_ablate.py)
+  if ((!histogram && (tables->flags & SJPEG_HIP_QUANT_KEEP)) || (histogram && (e->coefs_keep || force_keep))) {
     const size_t per_frame = static_cast<size_t>(g.nseg) * kScanThreads * 36;
     const int total = e->replay_total > 0 ? e->replay_total : nframes;
     const int first = e->replay_total > 0 ? e->replay_first : 0;
@@ -767,24 +792,24 @@ static int scan_statistics(sjpeg_hip_engine* e, const sjpeg_hip_source* src, int
     e->replay_w = width; e->replay_h = height; e->replay_mode = yuv_mode; e->replay_nframes = total;
   }
   dbg_mark("statistics: buffers");
-  if (histogram) rc = launch_scan<kKindHisto>(yuv_mode, cls, dim3(g.nseg, nframes), st, a);
+  if (histogram) rc = launch_scan<kKindHisto>(yuv_mode, cls, dim3(groups, nframes), st, a);
   else if (tables != nullptr && (tables->flags & SJPEG_HIP_QUANT_TRELLIS)) rc = launch_scan<kKindStatsTrellis>(yuv_mode, cls, dim3(g.nseg, nframes), st, a);
   else if (coefs_in) rc = launch_scan_src<kKindStatsCoef, kSrcRgb24>(yuv_mode, dim3(g.nseg, nframes), st, a);   // (reads no pixel)
   else rc = launch_scan<kKindStats>(yuv_mode, cls, dim3(g.nseg, nframes), st, a);
   if (rc) return rc;
   dbg_mark("statistics: pass launched");
-  // Slices of the segments meet in the output with device-scope atomics, and those are what the summing
-  // kernel waits for: as FEW slices as still fill the device.  The histogram (4096 words x 4 counters per
-  // frame) wants about a thousand workgroups -- 16 frames: 63 us with 16 slices, 40 with 4, 38 with 2; a
-  // single frame needs its 32 --, the symbol counts (544 words) are small enough for the atomics not to
-  // matter and take the slices they can get (16 frames: 7 us with 32, 25 with 2).
-  const int xblocks = (words + kThreads - 1) / kThreads;
-  int slices = (histogram ? 1024 : 4096) / (xblocks * nframes);
+  // The symbol counts (544 words a frame): slices of the segments meet in the output with device-scope atomics -- small
+  // enough for the atomics not to matter, they take the slices they can get (16 frames: 7 us with 32, 25 with 2).
+  const int xblocks = histogram ? 32 : (words + kThreads - 1) / kThreads;
+  int slices = 4096 / (xblocks * nframes);
   if (slices > 32) slices = 32;
-  if (histogram && slices < 2) slices = 2;
+  // (the histogram's partials: a workgroup's four waves share the groups; slices -- and their atomics -- only where one
+  // wave would walk more than 64 partials: single large frames)
+  if (histogram) slices = std::min(slices, (groups + 255) / 256);
   static const int slices_env = getenv("SJPEG_HIP_REDUCE_SLICES") ? atoi(getenv("SJPEG_HIP_REDUCE_SLICES")) : 0;   // (experiments)
   if (slices_env > 0) slices = slices_env;
   if (slices < 1 || g.nseg < 64) slices = 1;
+  if (histogram && groups < slices) slices = groups;
   const dim3 grid(xblocks, nframes, slices);
   hipStream_t rs = st;
   if (e->reduce_stream != nullptr && e->reduce_ev != nullptr) {   // (a batch coded in parts: see sjpeg_hip_encode_batch_src)
@@ -793,12 +818,16 @@ static int scan_statistics(sjpeg_hip_engine* e, const sjpeg_hip_source* src, int
     HIP_TRY(hipStreamWaitEvent(rs, e->reduce_ev, 0));
     dbg_mark("statistics: side stream waits");
   }
-  HIP_TRY(hipMemsetAsync(d_out, 0, static_cast<size_t>(nframes) * words * (histogram ? 4 : 1) * sizeof(uint32_t), rs));
-  dbg_mark("statistics: memset");
+  if (!(histogram && slices == 1)) {               // (one slice stores, several add)
+    HIP_TRY(hipMemsetAsync(d_out, 0, static_cast<size_t>(nframes) * words * (histogram ? 4 : 1) * sizeof(uint32_t), rs));
+    dbg_mark("statistics: memset");
+  }
   if (histogram) {
-    hipLaunchKernelGGL(reduce_partials<true>, grid, dim3(kThreads), 0, rs, partial, g.nseg, words, d_out);
+    static_assert(kThreads == kScanThreads, "reduce_partials16: a thread per thread of the scan kernel");
+    // (the partials of a launch lie back to back: frame f of this launch at f * groups * kHistoPartialWords)
+    hipLaunchKernelGGL(reduce_partials16, grid, dim3(kThreads), 0, rs, reinterpret_cast<const uint4*>(partial), groups, d_out);
   } else {
-    hipLaunchKernelGGL(reduce_partials<false>, grid, dim3(kThreads), 0, rs, partial, g.nseg, words, d_out);
+    hipLaunchKernelGGL(reduce_partials, grid, dim3(kThreads), 0, rs, partial, g.nseg, words, d_out);
   }
   HIP_TRY(hipGetLastError());
   return 0;

@@ -3,37 +3,66 @@
 // Part of the single translation unit scan_engine.hip: included there inside its anonymous
 // namespace, after <hip/hip_runtime.h> and sjpeg_hip.h; not a stand-alone header.
 // ------------------------------------------------------------------------------------
-// Sums the per-workgroup partial statistics of one frame: out[frame][i] = sum over segments.
-// BYTES: partial words hold four 8-bit counters (histogram) -> four u32 outputs per word.
-template <bool BYTES>
-__global__ __launch_bounds__(kThreads) void reduce_partials(const uint32_t* part, int nseg, int words,
-                                                           uint32_t* out) {
+// Sums the per-workgroup partial symbol counts of one frame (statistics kinds): out[frame][i] = sum over segments.
+__global__ __launch_bounds__(kThreads) void reduce_partials(const uint32_t* part, int nseg, int words, uint32_t* out) {
   // blockIdx.z = slice of the segments: a thread adds up its slice (independent loads, unrolled)
-  // and the slices meet in the output with atomics (cleared by the caller).  One thread walking
-  // all ~800 partials of a 4K frame was a chain of loads: 0.15 ms of a 0.23 ms histogram pass.
+  // and the slices meet in the output with atomics (cleared by the caller).
   const int frame = blockIdx.y;
   const int w = blockIdx.x * kThreads + threadIdx.x;
   if (w >= words) return;
   const int per = (nseg + gridDim.z - 1) / gridDim.z;
   const int s0 = blockIdx.z * per, s1 = min(nseg, s0 + per);
   const uint32_t* src = part + static_cast<size_t>(frame) * nseg * words + w;
-  if (BYTES) {
-    uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+  uint32_t sum = 0;
 #pragma unroll 8
-    for (int s = s0; s < s1; ++s) {
-      const uint32_t v = src[static_cast<size_t>(s) * words];
-      c0 += v & 0xffu; c1 += (v >> 8) & 0xffu; c2 += (v >> 16) & 0xffu; c3 += v >> 24;
+  for (int s = s0; s < s1; ++s) sum += src[static_cast<size_t>(s) * words];
+  if (sum) atomicAdd(&out[static_cast<size_t>(frame) * words + w], sum);
+}
+
+// Sums the partials of the histogram kind (scan_segments.h: one per persistent workgroup, `groups` per frame; 16-bit
+// counters, [8][256] pieces of 16 bytes -- piece j of thread t holds the 8-bit counters of words 16 t + 2 j and
+// 16 t + 2 j + 1 of the kernel's [2][16][128] words as (byte 0 | byte 2 << 16), (byte 1 | byte 3 << 16) twice; word
+// (table, q, bin) counts that bin of the positions 2q, 2q + 1, 32 + 2q, 33 + 2q in its four bytes):
+// out[frame][table][position][bin].  A workgroup takes 64 threads' worth of one piece, its four waves a quarter of the
+// groups each (independent loads, sixteen in flight) and meet in LDS: no atomics, and `out` needs no clearing -- unless
+// the launch has slices (blockIdx.z: one big frame with a thousand partials), which meet with atomics in a cleared `out`.
+__global__ __launch_bounds__(kThreads) void reduce_partials16(const uint4* part, int groups, uint32_t* out) {
+  __shared__ uint32_t red[3][8][64];
+  const int frame = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = blockIdx.x >> 2, t = (blockIdx.x & 3) * 64 + lane;   // piece, thread of the scan kernel
+  const int per_slice = (groups + gridDim.z - 1) / gridDim.z;
+  const int s0 = blockIdx.z * per_slice, s1 = min(groups, s0 + per_slice);
+  const int per = (s1 - s0 + 3) >> 2;
+  const int g0 = s0 + wave * per, g1 = min(s1, g0 + per);
+  const uint4* src = part + (static_cast<size_t>(frame) * groups * 8 + j) * 256 + t;
+  uint32_t c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll 16
+  for (int g = g0; g < g1; ++g) {
+    const uint4 v = src[static_cast<size_t>(g) * (8 * 256)];
+    c[0] += v.x & 0xffffu; c[1] += v.y & 0xffffu; c[2] += v.x >> 16; c[3] += v.y >> 16;
+    c[4] += v.z & 0xffffu; c[5] += v.w & 0xffffu; c[6] += v.z >> 16; c[7] += v.w >> 16;
+  }
+  if (wave != 0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) red[wave - 1][i][lane] = c[i];
+  }
+  __syncthreads();
+  if (wave != 0) return;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) c[i] += red[0][i][lane] + red[1][i][lane] + red[2][i][lane];
+  // words 16 t + 2 j, + 1: table and q from t >> 3, bins 16 (t & 7) + 2 j, + 1
+  const int tq = t >> 3, bin = 16 * (t & 7) + 2 * j;
+  uint32_t* dst = out + static_cast<size_t>(frame) * (2 * 64 * 128) + ((tq >> 4) * 64 + 2 * (tq & 15)) * 128 + bin;
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {                      // byte b: position 2q + (b & 1) + 32 (b >> 1)
+    uint32_t* const d2 = dst + ((b & 1) + 32 * (b >> 1)) * 128;
+    if (gridDim.z == 1) {
+      *reinterpret_cast<uint2*>(d2) = make_uint2(c[b], c[4 + b]);
+    } else {
+      if (c[b]) atomicAdd(&d2[0], c[b]);
+      if (c[4 + b]) atomicAdd(&d2[1], c[4 + b]);
     }
-    uint32_t* dst = out + (static_cast<size_t>(frame) * words + w) * 4;
-    if (c0) atomicAdd(&dst[0], c0);
-    if (c1) atomicAdd(&dst[1], c1);
-    if (c2) atomicAdd(&dst[2], c2);
-    if (c3) atomicAdd(&dst[3], c3);
-  } else {
-    uint32_t sum = 0;
-#pragma unroll 8
-    for (int s = s0; s < s1; ++s) sum += src[static_cast<size_t>(s) * words];
-    if (sum) atomicAdd(&out[static_cast<size_t>(frame) * words + w], sum);
   }
 }
 

@@ -31,7 +31,21 @@ enum { kKindEncode = 0, kKindTap = 1, kKindHisto = 2, kKindStats = 3, kKindError
        kKindEncodeTrellis = 5, kKindStatsTrellis = 6,     // the same two with trellis quantization
        kKindEncodeReplay = 7,     // entropy-code the coefficients a statistics pass left behind
        kKindStatsCoef = 8 };      // statistics from the DCT coefficients a histogram pass left behind
-constexpr int kHistoWords = 2 * 64 * 32;          // per-workgroup partial: u8 counters [2][64][128]
+constexpr int kHistoWords = 2 * 64 * 32;          // words of u8 counters [2][64][128] a workgroup bins one segment into (LDS)
+// The histogram kind is PERSISTENT: a workgroup bins the segments seg, seg + gridDim.x, ... of its frame and leaves ONE
+// partial behind -- 16-bit counters, two words per word of 8-bit ones (scan_reduce.h reduce_partials16).
+constexpr int kHistoPartialWords = 2 * kHistoWords;
+constexpr int kHistoMaxSegsPerGroup = 256;        // 246 blocks a segment at most: 16 bits hold 266 of them
+// LDS of the histogram kind behind P1 (over the block slots): 256 staged half blocks of 64 + 16 bytes, then the 8-bit
+// counters.  A WORD of counters belongs to one bin of FOUR positions -- 2q, 2q + 1, 32 + 2q, 33 + 2q, q = 0..15: the
+// pair of coefficients lane q of the binning loop reads from the first half of a block and from the second --, so the
+// byte a coefficient bumps is known at compile time and its bin is nothing but the word's address.  129 words per
+// (table, q): bins 0..127 and one word that swallows everything above.
+constexpr int kHistoStageStride = 80;
+constexpr int kHistoOffBins = 256 * kHistoStageStride;
+constexpr int kHistoPosBytes = 129 * 4;           // one (table, q) group
+constexpr int kHistoTblBytes = 16 * kHistoPosBytes;
+constexpr int kHistoLdsBytes = kHistoOffBins + 2 * kHistoTblBytes;   // 37 376: four workgroups per CU
 constexpr int kStatsWords = 2 * 272;              // per-workgroup partial: u32 [2][256 AC + 16 DC]
 
 // Race stress build (make STRESS=1|2): RACE_POINT(n) holds ONE wave of every workgroup back at
@@ -55,11 +69,14 @@ __device__ __forceinline__ void race_point(int code, int n) {
 // only: ROCm 7.2's clang crashes in its register allocator on the 4-byte-pixel instantiation with the
 // smaller LDS block)
 // the compact LDS layout (scan_device.h): four workgroups per CU
+#ifndef SJPEG_HISTO_WGS
+#define SJPEG_HISTO_WGS 4          // workgroups per CU the histogram kind is compiled for (experiments: 3)
+#endif
 template <int MODE, int KINDX, int SRC>
 constexpr bool kCompactLds = (KINDX == kKindEncode || KINDX == kKindEncodeReplay || KINDX == kKindStats || KINDX == kKindStatsCoef);
 
 template <int MODE, int KINDX, int SRC>
-__global__ __launch_bounds__(kScanThreads, ((KINDX == kKindHisto && SRC == kSrcRgb24) || kCompactLds<MODE, KINDX, SRC>) ? 4 : 1) void scan_segments(const ScanArgs a) {
+__global__ __launch_bounds__(kScanThreads, ((KINDX == kKindHisto && SRC == kSrcRgb24) ? SJPEG_HISTO_WGS : (kCompactLds<MODE, KINDX, SRC> ? 4 : 1))) void scan_segments(const ScanArgs a) {
   constexpr bool TRELLIS = (KINDX == kKindEncodeTrellis || KINDX == kKindStatsTrellis);
   constexpr bool REPLAY = (KINDX == kKindEncodeReplay);
   // the block's unquantized coefficients come from the histogram pass of the same call (the adaptive methods run
@@ -77,7 +94,8 @@ __global__ __launch_bounds__(kScanThreads, ((KINDX == kKindHisto && SRC == kSrcR
   static_assert(2 * 4 * G::kSegMcus * BPM <= L::kListBytes, "the part list holds four parts of every coded block");
   // static, not `extern __shared__`: the address of a dynamic block is resolved after instruction
   // selection and leaves a `+ 0` in ~65 address computations of this kernel
-  __shared__ __attribute__((aligned(16))) unsigned char smem[(KIND == kKindStats && !COMPACT) ? kLdsBytesStats : (KIND == kKindHisto && SRC == kSrcRgb24) ? kSamplesBytes : L::kLdsBytes];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[(KIND == kKindStats && !COMPACT) ? kLdsBytesStats : (KIND == kKindHisto && SRC == kSrcRgb24) ? kHistoLdsBytes : L::kLdsBytes];
+  static_assert(kHistoLdsBytes >= kSamplesBytes && kHistoLdsBytes <= L::kLdsBytes && 4 * kHistoLdsBytes <= 160 * 1024, "histogram kind: slots, then staging + bins");
   uint32_t* const win = reinterpret_cast<uint32_t*>(smem + L::kOffWin);
   uint4* const lq = reinterpret_cast<uint4*>(smem + L::kOffQ);
   uint32_t* const ldc = reinterpret_cast<uint32_t*>(smem + L::kOffDc);
@@ -88,7 +106,17 @@ __global__ __launch_bounds__(kScanThreads, ((KINDX == kKindHisto && SRC == kSrcR
   typedef uint16_t __attribute__((may_alias)) u16_may_alias;
 
   const int tid = threadIdx.x;
-  const int seg = blockIdx.x, frame = blockIdx.y;
+  const int frame = blockIdx.y;
+  // the histogram kind's 16-bit counters, two to a register: the 8-bit counters of words 16 * tid .. 16 * tid + 15 of
+  // the LDS histogram (overflow words not counted), bytes 0 / 2 in the even and bytes 1 / 3 in the odd register (no
+  // other kind has them)
+  uint32_t hacc[KIND == kKindHisto ? 32 : 1];
+  if (KIND == kKindHisto) {
+#pragma unroll
+    for (int i = 0; i < 32; ++i) hacc[i] = 0;
+  }
+  // every kind but the histogram takes ONE trip (gridDim.x = the frame's segments); the body ends with a return
+  for (int seg = blockIdx.x;; seg += gridDim.x) {
   auto stamp = [&](int k) {
     if (a.stamps != nullptr && tid == 0) {
       a.stamps[(static_cast<size_t>(frame) * a.nseg + seg) * 8 + k] =
@@ -144,7 +172,7 @@ __global__ __launch_bounds__(kScanThreads, ((KINDX == kKindHisto && SRC == kSrcR
     }
     if (KIND == kKindStats) {                      // the symbol counters (their own LDS behind everything else)
       uint32_t* const lf0 = reinterpret_cast<uint32_t*>(smem + L::kOffStats);
-      for (int i = tid; i < L::kStatsCopies * kStatsWords; i += kScanThreads) lf0[i] = 0;
+      for (int i = tid; i < L::kStatsCopies * kStatsWords + (COMPACT ? 60 : 0); i += kScanThreads) lf0[i] = 0;   // (+ the hot symbols' sets, compact carve)
     }
   };
 
@@ -198,7 +226,12 @@ __global__ __launch_bounds__(kScanThreads, ((KINDX == kKindHisto && SRC == kSrcR
     const int x0 = mb_x * PX + xs * 8;
     const uint32_t k7471 = 7471u, k32768 = 32768u;             // multiplier operands (low halves)
     constexpr int kNW = (SRC == kSrcRgb24) ? 6 : 8;             // dwords per 8 pixels
-    constexpr int kBatch = 3;                                   // row pairs in flight per thread
+#ifndef SJPEG_HISTO_BATCH
+#define SJPEG_HISTO_BATCH 2
+#endif
+    // (the histogram kind holds 32 registers of counters across its segments: two row pairs in flight keep it
+    // inside the 128 registers of four workgroups per CU)
+    constexpr int kBatch = (KIND == kKindHisto) ? SJPEG_HISTO_BATCH : 3;   // row pairs in flight per thread
     // A segment without clipped MCUs (every segment of a picture whose sides are multiples of the MCU,
     // most segments otherwise) runs a copy of the loop that has no clamped-coordinate path at all:
     // that path's address arithmetic is hoisted in front of the loop by the compiler, and its mere
@@ -360,6 +393,19 @@ __global__ __launch_bounds__(kScanThreads, ((KINDX == kKindHisto && SRC == kSrcR
   uint4* const keep = (a.replay == nullptr) ? nullptr
       : reinterpret_cast<uint4*>(a.replay) + (static_cast<size_t>(frame) * a.nseg + seg) * kScanThreads * 9 + tid;
   constexpr int kKeepRow = kScanThreads;
+  // (SJPEG_KEEP_NT: the kept blocks / coefficients are streamed -- written once, read once by a later launch)
+#ifndef SJPEG_KEEP_NT
+#define SJPEG_KEEP_NT 3
+#endif
+  typedef uint32_t u32x4_nt __attribute__((ext_vector_type(4)));
+  auto keep_store = [&](int idx, uint4 v) {
+    if (SJPEG_KEEP_NT & 1) { const u32x4_nt x = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(x, reinterpret_cast<u32x4_nt*>(keep + idx)); }
+    else keep[idx] = v;
+  };
+  auto keep_load = [&](int idx) -> uint4 {
+    if (SJPEG_KEEP_NT & 2) { const u32x4_nt x = __builtin_nontemporal_load(reinterpret_cast<const u32x4_nt*>(keep + idx)); return make_uint4(x.x, x.y, x.z, x.w); }
+    return keep[idx];
+  };
   // A kept block is 64 + 16 bytes when no AC level of it exceeds 127 (every ordinary block): its entries as BYTES --
   // sign in bit 7, level in bits 0..6 --, rows 0..3, and the tail (masks, DC value, OR of the AC entries) in row 4.
   // A block with a larger level keeps the low bytes there and the high bytes (sign, level bits 8..14) in rows 5..8.
@@ -369,15 +415,15 @@ __global__ __launch_bounds__(kScanThreads, ((KINDX == kKindHisto && SRC == kSrcR
   if (REPLAY) {
     uint4 lo[4], hi[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) lo[j] = keep[j * kKeepRow];
-    const uint4 t = keep[4 * kKeepRow];
+    for (int j = 0; j < 4; ++j) lo[j] = keep_load(j * kKeepRow);
+    const uint4 t = keep_load(4 * kKeepRow);
     nzq[0] = t.x & 0xffffu; nzq[1] = t.x >> 16; nzq[2] = t.y & 0xffffu; nzq[3] = t.y >> 16;
     dc_val = static_cast<int>(t.z);
     any_ac = t.w;
     const bool wide = (any_ac & kWideLevels) != 0u;
     if (wide) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) hi[j] = keep[(5 + j) * kKeepRow];
+      for (int j = 0; j < 4; ++j) hi[j] = keep_load((5 + j) * kKeepRow);
     }
     if (has_slot) {
       const uint32_t dm = static_cast<uint32_t>(dc_val < 0 ? -dc_val : dc_val);
@@ -415,7 +461,7 @@ __global__ __launch_bounds__(kScanThreads, ((KINDX == kKindHisto && SRC == kSrcR
 #pragma unroll
   for (int r = 0; r < 8; ++r) {
     uint4 q = make_uint4(0, 0, 0, 0);
-    if (has_block) q = COEF ? keep[r * kKeepRow] : *reinterpret_cast<const uint4*>(slot + 16 * r);
+    if (has_block) q = COEF ? keep_load(r * kKeepRow) : *reinterpret_cast<const uint4*>(slot + 16 * r);
     p[r][0] = q.x; p[r][1] = q.y; p[r][2] = q.z; p[r][3] = q.w;
   }
 
@@ -504,75 +550,119 @@ __global__ __launch_bounds__(kScanThreads, ((KINDX == kKindHisto && SRC == kSrcR
     return;
   }
   if (KIND == kKindHisto) {
-    // Adaptive-quantization statistics (reference StoreHisto, src/histogram.cc:56-108): for every
-    // natural position, histogram of |coefficient| >> 2 (bins < 128), one histogram per
-    // quantizer table.  8-bit counters packed four to a word in LDS (a workgroup has at most
-    // 252 blocks), flushed as this workgroup's partial; reduce_partials() sums them.
+    // Adaptive-quantization statistics (reference StoreHisto, src/histogram.cc:56-108): for every natural
+    // position, histogram of |coefficient| >> 2 (bins < 128), one histogram per quantizer table.
+    //
+    // Binning is done TRANSPOSED.  With one thread per block every lane of a wave bumps the SAME position at the
+    // same time, and the bins of one position crowd into a few words: an LDS atomic serialises lanes that meet in
+    // a word (round 4: 47 % of the kernel LDS-busy, two thirds of it conflicts, eight replicas of the lowest word
+    // notwithstanding).  Instead a thread stages its coefficients in LDS, half a block at a time (64 bytes + a
+    // tail word: the byte offset of its table's histogram), and the wave reads them back with 16 lanes to a
+    // block -- lane q takes the pair of coefficients 2q, 2q + 1 of the half -- four blocks per step: lanes of a
+    // wave bump 32 different positions, only the four that share a position can meet.  129 words per group of
+    // four positions: consecutive groups start in consecutive banks.  Blocks that are not coded stage 0x7fff: bin
+    // "128 and above", the word nobody reads.  8-bit counters, four to a word (a segment has at most 252 blocks); after the
+    // segment every thread adds sixteen words of them to its 16-bit counters in registers, and the workgroup goes on
+    // to its next segment: ONE partial per workgroup (32 KB) instead of one per segment (16 KB: 13 MB a 4K frame,
+    // written and read back by the summing kernel).
     RACE_POINT(14);
-    __syncthreads();                            // every thread holds its samples: slots are free
+    __syncthreads();                            // every thread holds its samples: the slots are free
     RACE_POINT(15);
-    uint32_t* const lh = reinterpret_cast<uint32_t*>(smem);
-    // LDS layout, 40 words per (table, position): eight replicas of the word of bins 0..3, picked by
-    // lane -- those bins take most of the hits of ordinary pictures and every lane of a wave hits the
-    // SAME word, which an LDS atomic serialises; the replicas are folded at the flush --, the words
-    // of bins 4..127, and one word for bin 128 = everything above (the reference's histogram stops at 127;
-    // never flushed).  8-bit counters: a workgroup has at most 252 blocks, a field cannot overflow.
-    constexpr int kPosWords = 40, kReps = 8;
-    for (int i = tid; i < 2 * 64 * kPosWords; i += kScanThreads) lh[i] = 0;
-    RACE_POINT(16);
-    __syncthreads();
+    {
+      uint4* const hz = reinterpret_cast<uint4*>(smem + kHistoOffBins);
+      for (int i = tid; i < 2 * kHistoTblBytes / 16; i += kScanThreads) hz[i] = make_uint4(0, 0, 0, 0);
+    }
+    unsigned char* const stage = smem + tid * kHistoStageStride;
+    *reinterpret_cast<uint32_t*>(stage + 64) = static_cast<uint32_t>(tbl * kHistoTblBytes);
     int acc[8];
-    const uint32_t one = emits ? 1u : 0u;          // (blocks that are not coded add zero)
-    const uint32_t rep_off = static_cast<uint32_t>(tid & (kReps - 1)) * 4u;
-    auto bump = [&](int row, const int* ac8) {
+    const bool wave_emits = __builtin_amdgcn_ballot_w64(emits) == ~0ull;
+    auto stage_row = [&](int row, const int* ac8) {
       uint32_t cq[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) cq[k] = __builtin_amdgcn_perm(static_cast<uint32_t>(ac8[2 * k + 1]), static_cast<uint32_t>(ac8[2 * k]), 0x07060302u);
       // the coefficients stay behind for the statistics pass of the same call (kKindStatsCoef)
-      if (keep != nullptr) keep[row * kKeepRow] = make_uint4(cq[0], cq[1], cq[2], cq[3]);
+      if (keep != nullptr) keep_store(row * kKeepRow, make_uint4(cq[0], cq[1], cq[2], cq[3]));
+      // (a uniform branch: the waves whose blocks are all coded -- two of four in an ordinary segment -- pay no select)
+      if (!wave_emits) {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        // both coefficients of a pair at once: |c| >> 2, clamped to 128 (packed 16-bit operations)
-        const s16x2 c = as_pk(cq[k]);
-        const u16x2 mag = __builtin_bit_cast(u16x2, __builtin_elementwise_max(c, pk_const(0, 0) - c));
-        uint32_t bins;
-        asm("v_pk_min_u16 %0, %1, %2" : "=v"(bins) : "v"(__builtin_bit_cast(uint32_t, mag >> u16x2{2, 2})), "v"(0x00800080u));
+        for (int k = 0; k < 4; ++k) cq[k] = emits ? cq[k] : 0x7fff7fffu;
+      }
+      *reinterpret_cast<uint4*>(stage + (row & 3) * 16) = make_uint4(cq[0], cq[1], cq[2], cq[3]);
+    };
+    auto bin_half = [&](auto half_tag) {
+      constexpr int HALF = decltype(half_tag)::value;
+      const int q = tid & 15;
+      const unsigned char* const rd = smem + (tid >> 4) * kHistoStageStride;
+      const uint32_t qb = static_cast<uint32_t>(kHistoOffBins + q * kHistoPosBytes);
+      // (the bytes of a word: positions 2q, 2q + 1 of the first half, then of the second)
+      const uint32_t one0 = 1u << (16 * HALF), one1 = 1u << (16 * HALF + 8);
+      // (four steps' reads are in flight before the first is consumed)
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-          const uint32_t bin = half ? bins >> 16 : bins & 0xffffu;
-          const uint32_t base = static_cast<uint32_t>((tbl * 64 + row * 8 + 2 * k + half) * kPosWords * 4);
-          const uint32_t at = bin < 4u ? rep_off : (bin & ~3u) + 28u;            // byte offset inside the position
-          atomicAdd(reinterpret_cast<uint32_t*>(smem + base + at), one << ((bin & 3u) * 8u));
+      for (int s4 = 0; s4 < 16; s4 += 4) {
+        uint32_t d[4], tb[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          d[i] = *reinterpret_cast<const uint32_t*>(rd + (s4 + i) * 16 * kHistoStageStride + q * 4);
+          tb[i] = *reinterpret_cast<const uint32_t*>(rd + (s4 + i) * 16 * kHistoStageStride + 64);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          // both coefficients of the pair at once: (|c| >> 2) * 4 = the byte offset of the bin's word, bins from 128 on
+          // at 512 (packed 16-bit operations)
+          const s16x2 c = as_pk(d[i]);
+          const uint32_t mag = as_u32(__builtin_elementwise_max(c, pk_const(0, 0) - c)) & 0xfffcfffcu;
+          uint32_t off;
+          asm("v_pk_min_u16 %0, %1, %2" : "=v"(off) : "v"(mag), "v"(0x02000200u));
+          const uint32_t base = tb[i] + qb;
+          atomicAdd(reinterpret_cast<uint32_t*>(smem + base + (off & 0xffffu)), one0);
+          atomicAdd(reinterpret_cast<uint32_t*>(smem + base + (off >> 16)), one1);
         }
       }
     };
-    fdct_row8_pk<22725, 21407, 19266, 16384, 12873, 8867, 4520>(p[0], acc); bump(0, acc);
-    fdct_row8_pk<31521, 29692, 26722, 22725, 17855, 12299, 6270>(p[1], acc); bump(1, acc);
-    fdct_row8_pk<29692, 27969, 25172, 21407, 16819, 11585, 5906>(p[2], acc); bump(2, acc);
-    fdct_row8_pk<26722, 25172, 22654, 19266, 15137, 10426, 5315>(p[3], acc); bump(3, acc);
-    fdct_row8_pk<22725, 21407, 19266, 16384, 12873, 8867, 4520>(p[4], acc); bump(4, acc);
-    fdct_row8_pk<26722, 25172, 22654, 19266, 15137, 10426, 5315>(p[5], acc); bump(5, acc);
-    fdct_row8_pk<29692, 27969, 25172, 21407, 16819, 11585, 5906>(p[6], acc); bump(6, acc);
-    fdct_row8_pk<31521, 29692, 26722, 22725, 17855, 12299, 6270>(p[7], acc); bump(7, acc);
-    RACE_POINT(17);
+    fdct_row8_pk<22725, 21407, 19266, 16384, 12873, 8867, 4520>(p[0], acc); stage_row(0, acc);
+    fdct_row8_pk<31521, 29692, 26722, 22725, 17855, 12299, 6270>(p[1], acc); stage_row(1, acc);
+    fdct_row8_pk<29692, 27969, 25172, 21407, 16819, 11585, 5906>(p[2], acc); stage_row(2, acc);
+    fdct_row8_pk<26722, 25172, 22654, 19266, 15137, 10426, 5315>(p[3], acc); stage_row(3, acc);
+    RACE_POINT(16);
     __syncthreads();
+    stamp(2);
+    bin_half(std::integral_constant<int, 0>());
+    RACE_POINT(17);
+    __syncthreads();                            // the first halves are read: the second may take their place
+    stamp(3);
+    fdct_row8_pk<22725, 21407, 19266, 16384, 12873, 8867, 4520>(p[4], acc); stage_row(4, acc);
+    fdct_row8_pk<26722, 25172, 22654, 19266, 15137, 10426, 5315>(p[5], acc); stage_row(5, acc);
+    fdct_row8_pk<29692, 27969, 25172, 21407, 16819, 11585, 5906>(p[6], acc); stage_row(6, acc);
+    fdct_row8_pk<31521, 29692, 26722, 22725, 17855, 12299, 6270>(p[7], acc); stage_row(7, acc);
     RACE_POINT(18);
-    // this workgroup's partial: u8 counters [2][64][128], four to a word
-    uint32_t* const dst = a.partial + (static_cast<size_t>(frame) * a.nseg + seg) * kHistoWords;
-    for (int i = tid; i < kHistoWords; i += kScanThreads) {
-      const int pos = i >> 5, w = i & 31;
-      const uint32_t* const ph = lh + pos * kPosWords;
-      uint32_t v;
-      if (w == 0) {
-        v = 0;
+    __syncthreads();
+    stamp(4);
+    bin_half(std::integral_constant<int, 1>());
+    RACE_POINT(22);
+    __syncthreads();
+    stamp(5);
+    {
+      // words 16 * tid .. 16 * tid + 15 of the [2][16][128] words: group tid >> 3, bins 16 * (tid & 7) ..
+      const uint32_t* const fw = reinterpret_cast<const uint32_t*>(smem + kHistoOffBins) + (tid >> 3) * 129 + (tid & 7) * 16;
 #pragma unroll
-        for (int r = 0; r < kReps; ++r) v += ph[r];
-      } else {
-        v = ph[kReps - 1 + w];
+      for (int m = 0; m < 16; ++m) {
+        const uint32_t w = fw[m];
+        hacc[2 * m] += w & 0x00ff00ffu;
+        hacc[2 * m + 1] += __builtin_amdgcn_perm(0u, w, 0x0c030c01u);        // (w >> 8) & 0x00ff00ff
       }
-      dst[i] = v;
     }
-    return;
+    stamp(6);
+    if (seg + static_cast<int>(gridDim.x) >= a.nseg) {
+      // this workgroup's partial, [8][256] pieces of 16 bytes: a store instruction of a wave covers 1 KiB in one piece
+      uint4* const dst = reinterpret_cast<uint4*>(a.partial) + (static_cast<size_t>(frame) * gridDim.x + blockIdx.x) * (kHistoPartialWords / 4) + tid;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dst[j * kScanThreads] = make_uint4(hacc[4 * j], hacc[4 * j + 1], hacc[4 * j + 2], hacc[4 * j + 3]);
+      return;
+    }
+    RACE_POINT(23);
+    __syncthreads();                            // the counters are folded: the next segment's samples may take the slots
+    stamp(7);
+    continue;
   }
   uint32_t ent[32];                             // natural order, 2 entries per dword
   {
@@ -740,10 +830,10 @@ __global__ __launch_bounds__(kScanThreads, ((KINDX == kKindHisto && SRC == kSrcR
         hb[k] = __builtin_amdgcn_perm(q[k], p[k], 0x07050301u);        // high bytes: sign, level bits 8..14
         if (!wide) lb[k] |= hb[k] & 0x80808080u;
       }
-      keep[j * kKeepRow] = make_uint4(lb[0], lb[1], lb[2], lb[3]);
-      if (wide) keep[(5 + j) * kKeepRow] = make_uint4(hb[0], hb[1], hb[2], hb[3]);
+      keep_store(j * kKeepRow, make_uint4(lb[0], lb[1], lb[2], lb[3]));
+      if (wide) keep_store((5 + j) * kKeepRow, make_uint4(hb[0], hb[1], hb[2], hb[3]));
     }
-    keep[4 * kKeepRow] = make_uint4(nzq[0] | (nzq[1] << 16), nzq[2] | (nzq[3] << 16), static_cast<uint32_t>(dc_val), any_ac);
+    keep_store(4 * kKeepRow, make_uint4(nzq[0] | (nzq[1] << 16), nzq[2] | (nzq[3] << 16), static_cast<uint32_t>(dc_val), any_ac));
   }
   }   // !REPLAY
   const uint32_t nz_lo = nzq[0] | (nzq[1] << 16), nz_hi = nzq[2] | (nzq[3] << 16);
@@ -875,6 +965,12 @@ __global__ __launch_bounds__(kScanThreads, ((KINDX == kKindHisto && SRC == kSrcR
   // wave count the same few symbols most of the time and an LDS atomic serialises the lanes that hit one
   // word; the copies are added up at the flush
   uint32_t* const lf = reinterpret_cast<uint32_t*>(smem + L::kOffStats) + ((KIND == kKindStats && L::kStatsCopies == 2) ? (tid & 1) * kStatsWords : 0);
+  // (compact carve only: ten sets of the hot symbols' counters in the 240 idle bytes between the counters and the scan scratch)
+  constexpr bool HOT = (KIND == kKindStats) && COMPACT;
+  constexpr int kHotCopies = 10;
+  static_assert(!COMPACT || (L::kOffStats + kStatsWords * 4 + kHotCopies * 6 * 4 <= L::kOffMisc), "hot counters of the statistics kind");
+  uint32_t* const hot = reinterpret_cast<uint32_t*>(smem + L::kOffStats + kStatsWords * 4);
+  const int hot_copy = ((tid & 63) * kHotCopies) >> 6;
   if (KIND == kKindStats) {
     // Symbol statistics for optimised Huffman tables (reference AddEntropyStats,
     // src/entropy.cc:208-227): per table, counts of AC symbols (run << 4 | size, ZRL, EOB) and
@@ -942,6 +1038,10 @@ __global__ __launch_bounds__(kScanThreads, ((KINDX == kKindHisto && SRC == kSrcR
         const int b_k = blk % BPM;
         const int b_tbl = (MODE == SJPEG_HIP_YUV420) ? (b_k >= 4) : (MODE == SJPEG_HIP_YUV444 ? (b_k >= 1) : 0);
         uint32_t* const f = lf + b_tbl * 272;
+        // the three symbols that make up half of an ordinary picture's -- a coefficient of 1, 2..3 or 4..7 right
+        // behind the previous one -- are counted in kHotCopies sets of counters picked by lane: an LDS atomic
+        // serialises the lanes that meet in a word, and with one set a third of the wave met in the word of symbol 0x01
+        uint32_t* const fh = HOT ? hot + hot_copy * 6 + b_tbl * 3 - 1 : f;
         const uint16_t* const zz = reinterpret_cast<const uint16_t*>(bslot);
         const int sh = 16 * q;
         uint32_t m = static_cast<uint32_t>(m_all >> sh) & 0xffffu;
@@ -963,7 +1063,8 @@ __global__ __launch_bounds__(kScanThreads, ((KINDX == kKindHisto && SRC == kSrcR
           const int run = i - prev;
           prev = i + 1;
           zrls += static_cast<uint32_t>(run >> 4);           // (counted once behind the loop: no branch in it)
-          atomicAdd(&f[((run & 15) << 4) | (32 - __clz(mag))], 1u);
+          const uint32_t sym = static_cast<uint32_t>(((run & 15) << 4) | (32 - __clz(mag)));
+          atomicAdd(&((HOT && sym - 1u < 3u) ? fh : f)[sym], 1u);
           i = i_next; e = e_next;
         }
         if (zrls != 0u) atomicAdd(&f[0xf0], zrls);
@@ -974,7 +1075,17 @@ __global__ __launch_bounds__(kScanThreads, ((KINDX == kKindHisto && SRC == kSrcR
     __syncthreads();
     uint32_t* const dst = a.partial + (static_cast<size_t>(frame) * a.nseg + seg) * kStatsWords;
     const uint32_t* const lf_all = reinterpret_cast<const uint32_t*>(smem + L::kOffStats);
-    for (int i = tid; i < kStatsWords; i += kScanThreads) dst[i] = lf_all[i] + (L::kStatsCopies == 2 ? lf_all[kStatsWords + i] : 0u);
+    for (int i = tid; i < kStatsWords; i += kScanThreads) {
+      uint32_t v = lf_all[i] + (L::kStatsCopies == 2 ? lf_all[kStatsWords + i] : 0u);
+      if (HOT) {
+        const int t = i >= 272 ? 1 : 0, sym = i - t * 272;
+        if (sym >= 1 && sym <= 3) {
+#pragma unroll
+          for (int c = 0; c < kHotCopies; ++c) v += hot[c * 6 + t * 3 + sym - 1];
+        }
+      }
+      dst[i] = v;
+    }
     return;
   }
 
@@ -1457,5 +1568,7 @@ __global__ __launch_bounds__(kScanThreads, ((KINDX == kKindHisto && SRC == kSrcR
   stamp(7);
   // (SJPEG_HIP_STAMPS=3: the last stamp is the segment's bit count instead -- which segments stitch slowly?)
   if (a.stamps != nullptr && a.stamp_real == 2 && tid == 0) a.stamps[(static_cast<size_t>(frame) * a.nseg + seg) * 8 + 7] = total;
+  return;
+  }   // (the histogram kind's loop over its segments)
 }
 

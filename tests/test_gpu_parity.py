@@ -205,6 +205,37 @@ def test_statistics_kernels_match_oracle(engine, oracle, mode):
         assert (freq[0].cpu().numpy().view(np.uint32) == want).all()
 
 
+def test_histogram_persistent_workgroups(oracle, monkeypatch):
+    """The histogram kind is persistent (a workgroup bins several segments into 16-bit counters and leaves ONE
+    partial): engines that may hold 1 / 3 / 7 / 50 workgroups at once walk many trips per workgroup, with group
+    counts that do and do not divide the segments; a flat 4K picture puts every coefficient of 198 segments into
+    one bin of a group's counters (the 16-bit limit is 266 segments)."""
+    rng = np.random.RandomState(5)
+    for mode, (w, h) in ((1, (1920, 1080)), (3, (1100, 700)), (4, (900, 1500))):
+        imgs = [synth.g_struct(w, h, 41), rng.randint(0, 256, (h, w, 3)).astype(np.uint8), synth.g_struct(w, h, 43)]
+        want = [oracle.histogram(im, mode) for im in imgs]
+        frames = torch.from_numpy(np.stack(imgs)).cuda()
+        for slots in (1, 3, 7, 50, 0):
+            if slots:
+                monkeypatch.setenv("SJPEG_HIP_HISTO_SLOTS", str(slots))
+            else:
+                monkeypatch.delenv("SJPEG_HIP_HISTO_SLOTS", raising=False)
+            eng = sj.Engine(0)
+            for rep in range(2):
+                hist = eng.scan_histogram(frames, mode)
+                torch.cuda.synchronize()
+                for k in range(3):
+                    assert (hist[k].cpu().numpy().view(np.uint32) == want[k]).all(), (mode, slots, k, rep)
+            eng.close()
+    flat = np.full((2160, 3840, 3), 200, np.uint8)
+    monkeypatch.setenv("SJPEG_HIP_HISTO_SLOTS", "1")
+    eng = sj.Engine(0)
+    hist = eng.scan_histogram(dev(flat), 1)
+    torch.cuda.synchronize()
+    assert (hist[0].cpu().numpy().view(np.uint32) == oracle.histogram(flat, 1)).all()
+    eng.close()
+
+
 def test_golden_methods_host_api(golden_small):
     n = 0
     for key, want in golden_small.items():

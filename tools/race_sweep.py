@@ -28,7 +28,7 @@ for i, (img, mode) in enumerate(cases):
         want[(i, method)] = o.encode_method(img, 75.0, mode, method)
 dev = [torch.from_numpy(img).cuda().unsqueeze(0) for (img, _) in cases]
 bad = runs = 0
-for point in range(0, 21):
+for point in range(0, 24):
     for wave in range(8):                          # 0..3: that wave lags; 4..7: that wave runs ahead of the others
         os.environ["SJPEG_HIP_ABLATE"] = str(0x5a000000 | (6 << 16) | (point << 8) | (0x80 if wave >= 4 else 0) | (wave & 3))
         eng = sj.Engine(0)
@@ -40,7 +40,7 @@ for point in range(0, 21):
                     bad += 1
                     print(f"MISMATCH point {point} wave {wave} case {i} method {method}", flush=True)
         eng.close()
-print(f"race sweep K1: {runs} encodes over 21 points x 4 waves, lagging and leading, mismatches: {bad}")
+print(f"race sweep K1: {runs} encodes over 24 points x 4 waves, lagging and leading, mismatches: {bad}")
 
 # ---- the sharp-YUV sweeps, through the host API (the stress code is read per call there)
 import hashlib  # noqa: E402
