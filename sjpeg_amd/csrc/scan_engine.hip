@@ -157,6 +157,14 @@ struct sjpeg_hip_engine {
   // pass of the next
   hipStream_t reduce_stream = nullptr;
   hipEvent_t reduce_ev = nullptr;
+  // ... and its uploads (a part's tables, headers, header offsets) leave EARLY, on `up_stream`, the moment the host has
+  // them -- the call's stream only waits for the event behind the last one (sync_uploads) in front of the kernel that
+  // reads them.  In the call's own stream every upload was a copy kernel between two dependent launches plus the marker
+  // of its pinned block: ~80 us of an idle device per 32-frame call (rocprofv3 trace, round 5).  What makes it safe:
+  // the parts' tables / headers lie side by side (part_first_frame()), and the host only has a part's data once the pass
+  // in front -- hence everything older on the call's stream -- is done (the sums / counts it waited for say so).
+  hipStream_t up_stream = nullptr;
+  hipEvent_t up_wait = nullptr;          // the event behind the last early upload nobody waited for yet (one of stage[].ev)
   DevBuf<unsigned long long> seg_off, chunk_off, stamps;
   DevBuf<uint32_t> hdr_off;
   bool want_stamps = false;
@@ -374,13 +382,29 @@ int upload(sjpeg_hip_engine* e, void* dst, const void* src, size_t bytes, hipStr
   dbg_mark("upload: block sized");
   memcpy(s.p, src, bytes);
   dbg_mark("upload: memcpy");
-  if (int rc = copy_by_kernel(dst, s.dp, bytes, st, hipMemcpyHostToDevice, s.p, dst)) return rc;
+  hipStream_t const us = e->up_stream != nullptr ? e->up_stream : st;
+  if (int rc = copy_by_kernel(dst, s.dp, bytes, us, hipMemcpyHostToDevice, s.p, dst)) return rc;
   dbg_mark("upload: copy launched");
-  HIP_TRY(hipEventRecord(s.ev, st));
+  HIP_TRY(hipEventRecord(s.ev, us));
   dbg_mark("upload: hipEventRecord");
   s.busy = true;
+  if (e->up_stream != nullptr) e->up_wait = s.ev;
   return 0;
 }
+
+// the call's stream waits for the early uploads (sjpeg_hip_engine::up_stream) in front of the kernel that reads them
+int sync_uploads(sjpeg_hip_engine* e, hipStream_t st) {
+  if (e->up_wait != nullptr) {
+    HIP_TRY(hipStreamWaitEvent(st, e->up_wait, 0));
+    e->up_wait = nullptr;
+  }
+  return 0;
+}
+
+// A batch coded in parts: where a part's per-frame tables / headers start in the engine's buffers (frames), and how many
+// frames those buffers are for -- the parts' uploads must not land on each other.
+inline int part_first_frame(const sjpeg_hip_engine* e) { return e->replay_total > 0 ? e->replay_first : 0; }
+inline int part_total_frames(const sjpeg_hip_engine* e, int nframes) { return e->replay_total > 0 ? e->replay_total : nframes; }
 
 // Segment scratch of an encode call, sized from the bytes the caller gives every frame (out_stride)
 // instead of for the worst case: a frame's un-stuffed stream is never longer than its stuffed one, so
@@ -414,7 +438,7 @@ int prepare_scan(sjpeg_hip_engine* e, const sjpeg_hip_source* src,
                  int W, int H, int mode, int nframes, const sjpeg_hip_scan_tables* tables,
                  hipStream_t st, FrameGeo* g, ScanArgs* a, int* src_class, bool per_frame_tables = false,
                  bool piped_encode = false, size_t seg_budget_bytes = 0 /* 0: not an encode, no segment scratch */,
-                 SegPlan* plan_out = nullptr) {
+                 SegPlan* plan_out = nullptr, bool no_tables = false /* the histogram kind reads none */) {
   if (e == nullptr || src == nullptr || src->plane[0] == nullptr || tables == nullptr || nframes <= 0) {
     return fail(SJPEG_HIP_EINVAL, "null argument or nframes <= 0");
   }
@@ -471,7 +495,10 @@ int prepare_scan(sjpeg_hip_engine* e, const sjpeg_hip_source* src,
   }
   int rc;
   const int ntab = per_frame_tables ? nframes : 1;
-  if ((rc = e->tables.ensure(ntab))) return rc;
+  // (per-frame tables of a batch's part lie behind those of the parts in front)
+  const int tab_first = per_frame_tables ? part_first_frame(e) : 0;
+  if (per_frame_tables && tab_first + nframes > part_total_frames(e, nframes)) return fail(SJPEG_HIP_EINVAL, "part outside the batch");
+  if ((rc = e->tables.ensure(per_frame_tables ? part_total_frames(e, nframes) : 1))) return rc;
   const size_t total_segs = static_cast<size_t>(nframes) * g->nseg;
   if ((rc = e->seg_nbits.ensure(total_segs))) return rc;
   SegPlan plan = {0, 0, 0};
@@ -484,19 +511,20 @@ int prepare_scan(sjpeg_hip_engine* e, const sjpeg_hip_source* src,
   }
   if (plan_out != nullptr) *plan_out = plan;
   dbg_mark("prepare: buffers");
-  {
+  if (!no_tables) {
     // (pageable source: the copy has left the host buffer when the call returns)
     std::vector<DevTables> host_tables(ntab);
     for (int i = 0; i < ntab; ++i) digest_tables(tables + i, &host_tables[i]);
-    const bool held = e->tables_held_at == e->tables.p && e->tables_stream == st &&
+    // (early uploads are never skipped: what the buffer holds was put there by another stream's order)
+    const bool held = e->up_stream == nullptr && tab_first == 0 && e->tables_held_at == e->tables.p && e->tables_stream == st &&
                       e->tables_held.size() == static_cast<size_t>(ntab) &&
                       memcmp(e->tables_held.data(), host_tables.data(), sizeof(DevTables) * ntab) == 0;
     dbg_mark("prepare: tables digested");
     if (!held) {
       e->tables_held_at = nullptr;
-      if (int rcu = upload(e, e->tables.p, host_tables.data(), sizeof(DevTables) * ntab, st)) return rcu;
+      if (int rcu = upload(e, e->tables.p + tab_first, host_tables.data(), sizeof(DevTables) * ntab, st)) return rcu;
       dbg_mark("prepare: tables uploaded");
-      if (ntab <= 16) {                            // (a big batch of per-frame tables is not worth holding)
+      if (ntab <= 16 && e->up_stream == nullptr && tab_first == 0) {   // (a big batch of per-frame tables is not worth holding)
         e->tables_held.swap(host_tables);
         e->tables_held_at = e->tables.p; e->tables_stream = st;
       } else {
@@ -508,7 +536,7 @@ int prepare_scan(sjpeg_hip_engine* e, const sjpeg_hip_source* src,
   a->seg_first = 0;
   a->rst = (tables->flags & SJPEG_HIP_RESTART_MARKERS) ? 1 : 0;
   a->has_clip = (W % g->px != 0) || (H % g->px != 0);
-  a->tables = e->tables.p;
+  a->tables = e->tables.p + tab_first;
   a->tables_stride = per_frame_tables ? 1 : 0;
   a->seg_words = e->seg_words.p;
   a->pool = e->pool.p; a->pool_words = plan.pool_words; a->pool_ctr = e->pool_ctr.p; a->seg_xbase = e->seg_xbase.p;
@@ -745,7 +773,7 @@ static int scan_statistics(sjpeg_hip_engine* e, const sjpeg_hip_source* src, int
   FrameGeo g;
   ScanArgs a;
   int cls = 0;
-  int rc = prepare_scan(e, src, width, height, yuv_mode, nframes, tables, st, &g, &a, &cls, per_frame_tables);
+  int rc = prepare_scan(e, src, width, height, yuv_mode, nframes, tables, st, &g, &a, &cls, per_frame_tables, false, 0, nullptr, histogram);
   if (rc) return rc;
   const int words = histogram ? kHistoWords : kStatsWords;
   const int part_total = e->replay_total > 0 ? e->replay_total : nframes;
@@ -792,6 +820,7 @@ static int scan_statistics(sjpeg_hip_engine* e, const sjpeg_hip_source* src, int
     e->replay_w = width; e->replay_h = height; e->replay_mode = yuv_mode; e->replay_nframes = total;
   }
   dbg_mark("statistics: buffers");
+  if ((rc = sync_uploads(e, st))) return rc;
   if (histogram) rc = launch_scan<kKindHisto>(yuv_mode, cls, dim3(groups, nframes), st, a);
   else if (tables != nullptr && (tables->flags & SJPEG_HIP_QUANT_TRELLIS)) rc = launch_scan<kKindStatsTrellis>(yuv_mode, cls, dim3(g.nseg, nframes), st, a);
   else if (coefs_in) rc = launch_scan_src<kKindStatsCoef, kSrcRgb24>(yuv_mode, dim3(g.nseg, nframes), st, a);   // (reads no pixel)
@@ -952,8 +981,9 @@ static int encode_scan_one(sjpeg_hip_engine* e, const sjpeg_hip_source* src, int
       offs[f] = static_cast<uint32_t>(header_offsets[f]);
       if (f > 0 && header_offsets[f] - header_offsets[f - 1] > largest_header) largest_header = header_offsets[f] - header_offsets[f - 1];
     }
-    if ((rc = e->hdr_off.ensure(static_cast<size_t>(nframes) + 1))) return rc;
-    if (int rcu = upload(e, e->hdr_off.p, offs.data(), offs.size() * sizeof(uint32_t), hs)) return rcu;
+    // (a batch's part: its nframes + 1 offsets behind those of the parts in front -- two slots a frame)
+    if ((rc = e->hdr_off.ensure(2 * static_cast<size_t>(part_total_frames(e, nframes)) + 2))) return rc;
+    if (int rcu = upload(e, e->hdr_off.p + 2 * static_cast<size_t>(part_first_frame(e)), offs.data(), offs.size() * sizeof(uint32_t), hs)) return rcu;
   }
   header_size = header == nullptr ? 0 : header_size;
   if (out_stride < largest_header + 2 + 64) {
@@ -966,16 +996,26 @@ static int encode_scan_one(sjpeg_hip_engine* e, const sjpeg_hip_source* src, int
   if ((rc = e->chunk_ff.ensure(static_cast<size_t>(nframes) * max_chunks))) return rc;
   if ((rc = e->chunk_off.ensure(static_cast<size_t>(nframes) * max_chunks))) return rc;
   if ((rc = e->frame_flags.ensure(static_cast<size_t>(nframes)))) return rc;
-  if ((rc = e->header.ensure(header_size > 0 ? header_size : 1))) return rc;
+  // (a batch's part: its headers behind those of the parts in front, kPartHeaderBytes a frame -- what
+  // sjpeg_hip_encode_batch_src builds its headers in)
+  constexpr size_t kPartHeaderBytes = 2048;
+  const size_t hdr_first = (multi && e->replay_total > 0) ? static_cast<size_t>(part_first_frame(e)) * kPartHeaderBytes : 0;
+  const size_t hdr_room = (multi && e->replay_total > 0) ? static_cast<size_t>(e->replay_total) * kPartHeaderBytes : 0;
+  if (e->up_stream != nullptr && hdr_room != 0 && header_size > static_cast<size_t>(nframes) * kPartHeaderBytes) {
+    return fail(SJPEG_HIP_EINVAL, "headers of a batch's part do not fit its share of the header buffer");
+  }
+  if ((rc = e->header.ensure(std::max(hdr_room, hdr_first + (header_size > 0 ? header_size : static_cast<size_t>(1)))))) return rc;
   if (header_size > 0) {
     const uint8_t* const hb = static_cast<const uint8_t*>(header);
-    const bool held = e->header_held_at == e->header.p && e->header_stream == hs &&
+    const bool held = e->up_stream == nullptr && hdr_first == 0 && e->header_held_at == e->header.p && e->header_stream == hs &&
                       e->header_held.size() == header_size && memcmp(e->header_held.data(), hb, header_size) == 0;
     if (!held) {
       e->header_held_at = nullptr;
-      if (int rcu = upload(e, e->header.p, header, header_size, hs)) return rcu;
-      e->header_held.assign(hb, hb + header_size);
-      e->header_held_at = e->header.p; e->header_stream = hs;
+      if (int rcu = upload(e, e->header.p + hdr_first, header, header_size, hs)) return rcu;
+      if (e->up_stream == nullptr && hdr_first == 0) {
+        e->header_held.assign(hb, hb + header_size);
+        e->header_held_at = e->header.p; e->header_stream = hs;
+      }
     }
   }
 
@@ -1010,7 +1050,7 @@ static int encode_scan_one(sjpeg_hip_engine* e, const sjpeg_hip_source* src, int
   s.pool = a.pool; s.pool_words = plan.pool_words; s.seg_xbase = a.seg_xbase; s.pool_ctr = a.pool_ctr;
   s.ubuf = e->ubuf.p; s.ubuf_words = ubuf_words;
   s.chunk_ff = e->chunk_ff.p; s.chunk_off = e->chunk_off.p; s.max_chunks = max_chunks;
-  s.header = e->header.p; s.header_size = static_cast<uint32_t>(header_size);
+  s.header = e->header.p + hdr_first; s.header_size = static_cast<uint32_t>(header_size);
   s.append_eoi = append_eoi;
   s.out = static_cast<uint8_t*>(d_out); s.out_stride = out_stride;
   s.sizes = reinterpret_cast<unsigned long long*>(d_sizes);
@@ -1023,7 +1063,7 @@ static int encode_scan_one(sjpeg_hip_engine* e, const sjpeg_hip_source* src, int
     s.wide_subs = s.subs > 1u ? 1u : 0u;
     if (!s.wide_subs) s.subs = 1;
   }
-  s.hdr_off = multi ? e->hdr_off.p : nullptr;
+  s.hdr_off = multi ? e->hdr_off.p + 2 * static_cast<size_t>(part_first_frame(e)) : nullptr;
   s.seg_first = a.seg_first; s.rst_tail = rst_tail;
   s.frame_flags = e->frame_flags.p;
   // few, small frames (the launches whose time is launch latency): K4 inside K5 -- one dependent launch less.  (Not
@@ -1038,6 +1078,8 @@ static int encode_scan_one(sjpeg_hip_engine* e, const sjpeg_hip_source* src, int
     a.clear_per = (max_chunks + static_cast<uint32_t>(g.nseg) - 1u) / static_cast<uint32_t>(g.nseg);
   }
 
+  if ((rc = sync_uploads(e, st))) return rc;
+  if (hs != st && (rc = sync_uploads(e, hs))) return rc;
   if (e->timing) HIP_TRY(hipEventRecord(e->ev[0], st));
   if (tables->flags & SJPEG_HIP_QUANT_REPLAY) {
     const int first = e->replay_total > 0 ? e->replay_first : 0;
@@ -1133,7 +1175,10 @@ static int encode_scan_impl(sjpeg_hip_engine* e, const sjpeg_hip_source* src, in
       // (a replay call addresses the kept blocks of frames [replay_first, replay_first + nframes) of a buffer for
       // replay_total frames: every launch its own range of it)
       const bool replay = tables != nullptr && (tables->flags & SJPEG_HIP_QUANT_REPLAY) != 0;
-      struct Restore { sjpeg_hip_engine* e; int first, total; ~Restore() { e->replay_first = first; e->replay_total = total; } } restore{e, e->replay_first, e->replay_total};
+      // (the launches share what is uploaded once for all of them -- the header blob -- and follow each other: their
+      // uploads stay in the call's stream)
+      struct Restore { sjpeg_hip_engine* e; int first, total; hipStream_t up; ~Restore() { e->replay_first = first; e->replay_total = total; e->up_stream = up; } } restore{e, e->replay_first, e->replay_total, e->up_stream};
+      e->up_stream = nullptr;
       if (replay && e->replay_total <= 0) { e->replay_total = nframes; e->replay_first = 0; }
       const int base_first = e->replay_first;
       for (int f0 = 0; f0 < nframes; f0 += static_cast<int>(fit)) {
@@ -1378,11 +1423,13 @@ struct BatchScratch {                 // per host thread: device scratch of sjpe
     for (auto& e : ev) { if (e) (void)hipEventDestroy(e); e = nullptr; }
     if (pass_done) (void)hipEventDestroy(pass_done);
     if (side) { (void)hipStreamSynchronize(side); (void)hipStreamDestroy(side); }
-    pass_done = nullptr; side = nullptr;
+    if (up) { (void)hipStreamSynchronize(up); (void)hipStreamDestroy(up); }
+    pass_done = nullptr; side = nullptr; up = nullptr;
     d_hist = d_sums = d_freq = h_pinned = d_pinned = nullptr; hist_cap = sums_cap = freq_cap = pinned_cap = 0;
   }
   hipEvent_t ev[8] = {};                         // behind the read-backs of a part: sums [0..3], counts [4..7]
   hipStream_t side = nullptr;                    // the sums of a part (and their read-back) under the next part's pass
+  hipStream_t up = nullptr;                      // a part's uploads, early (sjpeg_hip_engine::up_stream)
   hipEvent_t pass_done = nullptr;
   bool EnsureEvents() {
     for (auto& e : ev) {
@@ -1390,6 +1437,7 @@ struct BatchScratch {                 // per host thread: device scratch of sjpe
     }
     if (pass_done == nullptr && hipEventCreateWithFlags(&pass_done, hipEventDisableTiming) != hipSuccess) { pass_done = nullptr; return false; }
     if (side == nullptr && hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess) { side = nullptr; return false; }
+    if (up == nullptr && hipStreamCreateWithFlags(&up, hipStreamNonBlocking) != hipSuccess) { up = nullptr; return false; }
     return true;
   }
   bool EnsurePinned(size_t need) {
@@ -1429,7 +1477,7 @@ int sjpeg_hip_encode_batch_src(sjpeg_hip_engine* engine, const sjpeg_hip_source*
   if (method > 6) return fail(SJPEG_HIP_EINVAL, "sjpeg_hip_encode_batch_src: methods 0..6 (trellis goes through the host API)");
   struct PartsGuard {                              // the engine addresses whole calls again when this returns
     sjpeg_hip_engine* e;
-    ~PartsGuard() { e->replay_first = 0; e->replay_total = 0; e->reduce_stream = nullptr; e->reduce_ev = nullptr; e->coefs_keep = e->coefs_use = false; }
+    ~PartsGuard() { e->replay_first = 0; e->replay_total = 0; e->reduce_stream = nullptr; e->reduce_ev = nullptr; e->coefs_keep = e->coefs_use = false; e->up_stream = nullptr; e->up_wait = nullptr; }
   } parts_guard{engine};
   try {
     const bool adaptive = method >= 3, optimize = (method != 0) && (method != 3);
@@ -1489,6 +1537,8 @@ int sjpeg_hip_encode_batch_src(sjpeg_hip_engine* engine, const sjpeg_hip_source*
       engine->reduce_stream = sc.side; engine->reduce_ev = sc.pass_done;
       engine->replay_total = nframes;
       rs = sc.side;
+      static const bool late_uploads = getenv("SJPEG_HIP_LATE_UPLOADS") != nullptr;       // (A/B: uploads in the call's own stream)
+      if (!late_uploads) engine->up_stream = sc.up;
     }
     // device -> the pinned block, on the side stream: a kernel writes it over the bus (no runtime copy: stage_copy_kernel)
     auto read_back = [&](void* h_dst, const void* d_src, size_t bytes) -> int {
@@ -1585,6 +1635,7 @@ int sjpeg_hip_encode_batch_src(sjpeg_hip_engine* engine, const sjpeg_hip_source*
         offs[f - f0 + 1] = headers.size();
       }
       const sjpeg_hip_source ps = part_source(f0);
+      if (engine->replay_total > 0) engine->replay_first = static_cast<int>(f0);     // (where this part's tables / headers lie)
       const int rc_enc = sjpeg_hip_encode_scan_multi(engine, &ps, width, height, yuv_mode, static_cast<int>(nf), &tables[f0], headers.data(),
                                                      offs.data(), /*append_eoi=*/1, static_cast<uint8_t*>(d_out) + f0 * out_stride,
                                                      out_stride, d_sizes + f0, stream);
