@@ -72,6 +72,8 @@ elif cfg == "one4k":
     step, px, sizes = plain([synth.g_struct(3840, 2160, 7654321)], 75.0, 1)
 elif cfg == "m4":
     step, px, sizes = batch([synth.g_struct(3840, 2160, 7654321 + k) for k in range(4)] * 8, 1, 4)
+elif cfg.startswith("m4n"):                      # m4n<N>: N 4K frames, default parameters
+    step, px, sizes = batch([synth.g_struct(3840, 2160, 7654321 + k % 4) for k in range(int(cfg[3:]))], 1, 4)
 elif cfg == "c5m0":
     step, px, sizes = plain([synth.g_struct(3840, 2160, 7654321)] * 16, 75.0, 1, quant=c5_quant())
 elif cfg == "c5m4":
