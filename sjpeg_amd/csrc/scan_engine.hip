@@ -165,6 +165,14 @@ struct sjpeg_hip_engine {
   // in front -- hence everything older on the call's stream -- is done (the sums / counts it waited for say so).
   hipStream_t up_stream = nullptr;
   hipEvent_t up_wait = nullptr;          // the event behind the last early upload nobody waited for yet (one of stage[].ev)
+  // The two streams of a batch in parts, made WITH the engine: a stream made late in the life of a process -- behind
+  // the first asynchronous copy, it seems; bench.py's batch lines came a minute in -- shares the hardware queue of
+  // an older one, the caller's as it turned out: the side stream's sums then queue behind the next part's pass, the
+  // early uploads behind the kernel they should run under, and the call takes what it takes with everything in one
+  // stream (1.33 ms against 1.19 for 32 4K frames; not the number of hardware queues -- GPU_MAX_HW_QUEUES 8 / 16 the
+  // same --, not their priority -- the greatest made it 1.46).  Streams made when the engine is, early, keep queues of
+  // their own (bisected in bench.py, round 5; profiles/HISTORY.md).
+  hipStream_t batch_side = nullptr, batch_up = nullptr;
   DevBuf<unsigned long long> seg_off, chunk_off, stamps;
   DevBuf<uint32_t> hdr_off;
   bool want_stamps = false;
@@ -593,6 +601,12 @@ int sjpeg_hip_engine_create(int device, sjpeg_hip_engine** engine) {
   if (e == nullptr) return fail(SJPEG_HIP_ENOMEM, "host allocation failed");
   e->device = device;
   if (prop.multiProcessorCount > 0) e->cu_count = prop.multiProcessorCount;
+  if (hipStreamCreateWithFlags(&e->batch_side, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&e->batch_up, hipStreamNonBlocking) != hipSuccess) {
+    if (e->batch_side) (void)hipStreamDestroy(e->batch_side);
+    delete e;
+    return fail(SJPEG_HIP_ERUNTIME, "hipStreamCreate failed");
+  }
   if (const char* ab = getenv("SJPEG_HIP_ABLATE")) {                       // profiling / race-stress aid only
     e->ablate = atoi(ab);
     if (e->ablate != 0) {
@@ -621,6 +635,7 @@ void sjpeg_hip_engine_destroy(sjpeg_hip_engine* e) {
   }
   e->seg_words2.release(); e->seg_nbits2.release(); e->pool2.release(); e->pool_ctr2.release(); e->seg_xbase2.release();
   if (e->side) { (void)hipStreamSynchronize(e->side); (void)hipStreamDestroy(e->side); }
+  for (hipStream_t bs : {e->batch_side, e->batch_up}) if (bs) { (void)hipStreamSynchronize(bs); (void)hipStreamDestroy(bs); }
   for (hipEvent_t ev : {e->k1_done, e->side_done, e->k3_done[0], e->k3_done[1], e->cross_ev}) if (ev) (void)hipEventDestroy(ev);
   delete e;
 }
@@ -1422,22 +1437,16 @@ struct BatchScratch {                 // per host thread: device scratch of sjpe
     if (h_pinned) (void)hipHostFree(h_pinned);
     for (auto& e : ev) { if (e) (void)hipEventDestroy(e); e = nullptr; }
     if (pass_done) (void)hipEventDestroy(pass_done);
-    if (side) { (void)hipStreamSynchronize(side); (void)hipStreamDestroy(side); }
-    if (up) { (void)hipStreamSynchronize(up); (void)hipStreamDestroy(up); }
-    pass_done = nullptr; side = nullptr; up = nullptr;
+    pass_done = nullptr;
     d_hist = d_sums = d_freq = h_pinned = d_pinned = nullptr; hist_cap = sums_cap = freq_cap = pinned_cap = 0;
   }
   hipEvent_t ev[8] = {};                         // behind the read-backs of a part: sums [0..3], counts [4..7]
-  hipStream_t side = nullptr;                    // the sums of a part (and their read-back) under the next part's pass
-  hipStream_t up = nullptr;                      // a part's uploads, early (sjpeg_hip_engine::up_stream)
   hipEvent_t pass_done = nullptr;
   bool EnsureEvents() {
     for (auto& e : ev) {
       if (e == nullptr && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { e = nullptr; return false; }
     }
     if (pass_done == nullptr && hipEventCreateWithFlags(&pass_done, hipEventDisableTiming) != hipSuccess) { pass_done = nullptr; return false; }
-    if (side == nullptr && hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess) { side = nullptr; return false; }
-    if (up == nullptr && hipStreamCreateWithFlags(&up, hipStreamNonBlocking) != hipSuccess) { up = nullptr; return false; }
     return true;
   }
   bool EnsurePinned(size_t need) {
@@ -1537,11 +1546,11 @@ int sjpeg_hip_encode_batch_src(sjpeg_hip_engine* engine, const sjpeg_hip_source*
     // the partials, so that the next part's pass starts right behind this one's)
     hipStream_t rs = st;
     if (nparts > 1) {
-      engine->reduce_stream = sc.side; engine->reduce_ev = sc.pass_done;
+      engine->reduce_stream = engine->batch_side; engine->reduce_ev = sc.pass_done;
       engine->replay_total = nframes;
-      rs = sc.side;
+      rs = engine->batch_side;
       static const bool late_uploads = getenv("SJPEG_HIP_LATE_UPLOADS") != nullptr;       // (A/B: uploads in the call's own stream)
-      if (!late_uploads) engine->up_stream = sc.up;
+      if (!late_uploads) engine->up_stream = engine->batch_up;
     }
     // device -> the pinned block, on the side stream: a kernel writes it over the bus (no runtime copy: stage_copy_kernel)
     auto read_back = [&](void* h_dst, const void* d_src, size_t bytes) -> int {
