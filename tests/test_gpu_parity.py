@@ -227,6 +227,14 @@ def test_histogram_persistent_workgroups(oracle, monkeypatch):
                 for k in range(3):
                     assert (hist[k].cpu().numpy().view(np.uint32) == want[k]).all(), (mode, slots, k, rep)
             eng.close()
+    # one large frame: more groups than one workgroup of the summing kernel walks -- its slices meet with atomics
+    monkeypatch.delenv("SJPEG_HIP_HISTO_SLOTS", raising=False)
+    big = synth.g_struct(7680, 4320, 47)
+    eng = sj.Engine(0)
+    hist = eng.scan_histogram(dev(big), 3)
+    torch.cuda.synchronize()
+    assert (hist[0].cpu().numpy().view(np.uint32) == oracle.histogram(big, 3)).all()
+    eng.close()
     flat = np.full((2160, 3840, 3), 200, np.uint8)
     monkeypatch.setenv("SJPEG_HIP_HISTO_SLOTS", "1")
     eng = sj.Engine(0)
