@@ -84,6 +84,12 @@ __global__ __launch_bounds__(kScanThreads, ((KINDX == kKindHisto && SRC == kSrcR
   constexpr bool COEF = (KINDX == kKindStatsCoef);
   constexpr int KIND = (KINDX == kKindEncodeTrellis || KINDX == kKindEncodeReplay) ? kKindEncode : (KINDX == kKindStatsTrellis || COEF) ? kKindStats : KINDX;
   constexpr bool COMPACT = kCompactLds<MODE, KINDX, SRC>;
+  // The statistics kinds (but the trellis one) count a block's symbols straight out of the thread's registers, zig-zag
+  // position by position -- no entries in LDS, no parts, no sort, no walk (below, "kKindStats, direct")
+#ifndef SJPEG_STATS_DIRECT
+#define SJPEG_STATS_DIRECT 1
+#endif
+  constexpr bool DIRECT = SJPEG_STATS_DIRECT && (KINDX == kKindStats || KINDX == kKindStatsCoef);
   using L = Lds<COMPACT>;
   constexpr int kWinWords = L::kWinWords;
   using G = Geo<MODE>;
@@ -694,7 +700,16 @@ __global__ __launch_bounds__(kScanThreads, ((KINDX == kKindHisto && SRC == kSrcR
     }
   }
   // zig-zag reorder with byte permutes, 4 entries per ds_write_b64
-  if (has_slot) {
+  uint32_t zz[DIRECT ? 32 : 1];                    // DIRECT: the zig-zag order in registers, for the kept block only
+  if (DIRECT) {                                    // (only the DC entry goes to the slot: the next block's predictor)
+    if (has_slot) *reinterpret_cast<u16_may_alias*>(slot) = static_cast<uint16_t>(ent[0] & 0xffffu);
+    if (keep != nullptr) {
+#pragma unroll
+      for (int i = 0; i < 64; i += 2) {
+        zz[i >> 1] = __builtin_amdgcn_perm(ent[kZig(i + 1) >> 1], ent[kZig(i) >> 1], kPairSel(kZig(i), kZig(i + 1)));
+      }
+    }
+  } else if (has_slot) {
 #pragma unroll
     for (int i = 0; i < 64; i += 4) {
       const uint32_t w0 = __builtin_amdgcn_perm(ent[kZig(i + 1) >> 1], ent[kZig(i) >> 1],
@@ -821,7 +836,13 @@ __global__ __launch_bounds__(kScanThreads, ((KINDX == kKindHisto && SRC == kSrcR
     const bool wide = (any_ac & kWideLevels) != 0u;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const uint4 ra = *reinterpret_cast<const uint4*>(slot + 32 * j), rb = *reinterpret_cast<const uint4*>(slot + 32 * j + 16);
+      uint4 ra, rb;
+      if (DIRECT) {
+        ra = make_uint4(zz[(8 * j) % (DIRECT ? 32 : 1)], zz[(8 * j + 1) % (DIRECT ? 32 : 1)], zz[(8 * j + 2) % (DIRECT ? 32 : 1)], zz[(8 * j + 3) % (DIRECT ? 32 : 1)]);
+        rb = make_uint4(zz[(8 * j + 4) % (DIRECT ? 32 : 1)], zz[(8 * j + 5) % (DIRECT ? 32 : 1)], zz[(8 * j + 6) % (DIRECT ? 32 : 1)], zz[(8 * j + 7) % (DIRECT ? 32 : 1)]);
+      } else {
+        ra = *reinterpret_cast<const uint4*>(slot + 32 * j); rb = *reinterpret_cast<const uint4*>(slot + 32 * j + 16);
+      }
       const uint32_t p[4] = {ra.x, ra.z, rb.x, rb.z}, q[4] = {ra.y, ra.w, rb.y, rb.w};
       uint32_t lb[4], hb[4];
 #pragma unroll
@@ -834,6 +855,71 @@ __global__ __launch_bounds__(kScanThreads, ((KINDX == kKindHisto && SRC == kSrcR
       if (wide) keep_store((5 + j) * kKeepRow, make_uint4(hb[0], hb[1], hb[2], hb[3]));
     }
     keep_store(4 * kKeepRow, make_uint4(nzq[0] | (nzq[1] << 16), nzq[2] | (nzq[3] << 16), static_cast<uint32_t>(dc_val), any_ac));
+  }
+  if (DIRECT) {
+    // kKindStats, direct: symbol statistics for optimised Huffman tables (reference AddEntropyStats,
+    // src/entropy.cc:208-227; the run/size walk of src/entropy.cc:161-198) by the block's own thread, out of the
+    // registers its quantizer left the entries in.  The walk of sorted parts (below: the trellis kind still takes it)
+    // read every entry back from LDS at a lane's own address and bumped a counter per symbol with all 64 lanes at
+    // it: 70 % of the kernel LDS-busy, two thirds of that conflicts.  Here position i of the zig-zag scan is a
+    // compile-time constant -- the entry's register and half, whether a run of 16 can end in it (i >= 17), whether
+    // the position is dense enough for the hot symbols' own counters (i <= 16) -- and only the lanes with a
+    // non-zero level at i execute: a few lanes per atomic instead of a wave, no sort, no list, no loop.
+    __syncthreads();                               // the DC entries are in the slots
+    RACE_POINT(24);
+    if (emits) {
+      int pred_dc = 0;
+      int prevb;
+      if (MODE == SJPEG_HIP_YUV420) prevb = (k == 0) ? tid - 3 : (k <= 3 ? tid - 1 : tid - 6);
+      else prevb = tid - BPM;
+      if (!(prevb < BPM && !halo)) {
+        const uint32_t e = *reinterpret_cast<const u16_may_alias*>(smem + prevb * kSlotBytes);
+        const int mag = static_cast<int>(e & 0x7fffu);
+        pred_dc = (e & 0x8000u) ? -mag : mag;
+      }
+      uint32_t* const f = reinterpret_cast<uint32_t*>(smem + L::kOffStats) + ((L::kStatsCopies == 2) ? (tid & 1) * kStatsWords : 0) + tbl * 272;
+      uint32_t* const fhot = COMPACT ? reinterpret_cast<uint32_t*>(smem + L::kOffStats + kStatsWords * 4) + (((tid & 63) * 10) >> 6) * 6 + tbl * 3 - 1 : f;
+      {
+        const int diff = dc_val - pred_dc;
+        const int ad = diff < 0 ? -diff : diff;
+        atomicAdd(&f[256 + (32 - __clz(ad))], 1u);
+      }
+      int prev = 1;                                // zig-zag position behind the last non-zero coefficient
+      uint32_t zrls = 0;
+#pragma unroll
+      for (int i = 1; i < 64; ++i) {
+        const int j = kZig(i);
+        const uint32_t mag = (j & 1) ? ((ent[j >> 1] >> 16) & 0x7fffu) : (ent[j >> 1] & 0x7fffu);
+        if (mag != 0u) {
+          const int run = i - prev;
+          prev = i + 1;
+          uint32_t sym;
+          if (i >= 17) { zrls += static_cast<uint32_t>(run >> 4); sym = static_cast<uint32_t>((run & 15) << 4); }
+          else sym = static_cast<uint32_t>(run << 4);
+          sym += 32u - static_cast<uint32_t>(__clz(mag));
+          if (COMPACT && i <= 16) atomicAdd(&((sym - 1u < 3u) ? fhot : f)[sym], 1u);
+          else atomicAdd(&f[sym], 1u);
+        }
+      }
+      if (zrls != 0u) atomicAdd(&f[0xf0], zrls);
+      if (prev <= 63) atomicAdd(&f[0x00], 1u);
+    }
+    RACE_POINT(25);
+    __syncthreads();
+    uint32_t* const dst = a.partial + (static_cast<size_t>(frame) * a.nseg + seg) * kStatsWords;
+    const uint32_t* const lf_all = reinterpret_cast<const uint32_t*>(smem + L::kOffStats);
+    for (int i = tid; i < kStatsWords; i += kScanThreads) {
+      uint32_t v = lf_all[i] + (L::kStatsCopies == 2 ? lf_all[kStatsWords + i] : 0u);
+      if (COMPACT) {
+        const int t = i >= 272 ? 1 : 0, sym = i - t * 272;
+        if (sym >= 1 && sym <= 3) {
+#pragma unroll
+          for (int c = 0; c < 10; ++c) v += lf_all[kStatsWords + c * 6 + t * 3 + sym - 1];
+        }
+      }
+      dst[i] = v;
+    }
+    return;
   }
   }   // !REPLAY
   const uint32_t nz_lo = nzq[0] | (nzq[1] << 16), nz_hi = nzq[2] | (nzq[3] << 16);

@@ -1,7 +1,7 @@
 """Race sweep (needs the stress build: make -C sjpeg_amd/csrc STRESS=1): for every race point and
 every wave of the workgroup, that wave is held back ~50 000 cycles at that point, and a small set
 of encodes is compared with the oracle.  A wave that may not lag (or whose partners may not run
-ahead) without a barrier in between shows up as a mismatch.  Points 0..23: K1 (encode, histogram,
+ahead) without a barrier in between shows up as a mismatch.  Points 0..25: K1 (encode, histogram,
 statistics, replay kinds); points 32..47: the sharp-YUV sweeps (sharp_yuv.hip), driven through the
 host API on BASELINE config C1 (SjpegCompress of test128.rgb: AUTO -> sharp, method 4), a small
 sharp picture and one wide enough for the general sweep kernel.  The kernels without any
@@ -31,7 +31,7 @@ bad = runs = 0
 # (the persistent histogram kind: three workgroups in all, so that every workgroup walks many segments -- the barriers
 # at the end of a segment, points 22 / 23, are only met from the second one on)
 os.environ["SJPEG_HIP_HISTO_SLOTS"] = "3"
-for point in range(0, 24):
+for point in range(0, 26):
     for wave in range(8):                          # 0..3: that wave lags; 4..7: that wave runs ahead of the others
         os.environ["SJPEG_HIP_ABLATE"] = str(0x5a000000 | (6 << 16) | (point << 8) | (0x80 if wave >= 4 else 0) | (wave & 3))
         eng = sj.Engine(0)
@@ -43,7 +43,7 @@ for point in range(0, 24):
                     bad += 1
                     print(f"MISMATCH point {point} wave {wave} case {i} method {method}", flush=True)
         eng.close()
-print(f"race sweep K1: {runs} encodes over 24 points x 4 waves, lagging and leading, mismatches: {bad}")
+print(f"race sweep K1: {runs} encodes over 26 points x 4 waves, lagging and leading, mismatches: {bad}")
 
 # ---- the sharp-YUV sweeps, through the host API (the stress code is read per call there)
 import hashlib  # noqa: E402
