@@ -210,15 +210,20 @@ struct sjpeg_hip_engine {
 
 namespace {
 
-void digest_tables(const sjpeg_hip_scan_tables* t, DevTables* d) {
+// the quantizer part of DevTables (its first KiB)
+void digest_quant(const sjpeg_hip_scan_tables* t, uint4 (*q)[32]) {
   for (int c = 0; c < 2; ++c) {
     for (int j = 0; j < 64; ++j) {
-      uint4& e = d->q[c][j >> 1];
+      uint4& e = q[c][j >> 1];
       const uint32_t iq = t->iquant[c][j], biq = static_cast<uint32_t>(t->bias[c][j]) * iq;
       const uint32_t qv = t->quant[c][j];
       if ((j & 1) == 0) { e.x = iq; e.y = biq; e.w = qv; } else { e.x |= iq << 16; e.z = biq; e.w |= qv << 16; }
     }
   }
+}
+
+void digest_tables(const sjpeg_hip_scan_tables* t, DevTables* d) {
+  digest_quant(t, d->q);
   memset(d->pad_a, 0, sizeof(d->pad_a));
   memcpy(d->dc, t->dc_codes, sizeof(d->dc));
   memcpy(d->ac, t->ac_codes, sizeof(d->ac));
@@ -1533,7 +1538,8 @@ int sjpeg_hip_encode_batch_src(sjpeg_hip_engine* engine, const sjpeg_hip_source*
     }
     if (optimize && !sc.Ensure(&sc.d_freq, &sc.freq_cap, n * kFreq)) return fail(SJPEG_HIP_ENOMEM, "hipMalloc(batch scratch) failed");
     if (!sc.EnsurePinned(n * (kSums + kTot + kFreq)) || !sc.EnsureEvents()) return fail(SJPEG_HIP_ENOMEM, "hipHostMalloc / hipEventCreate(batch scratch) failed");
-    uint8_t* const h_sums = static_cast<uint8_t*>(sc.h_pinned);                  // [n][kSums] then [n][kTot]
+    // (a part's sums and totals lie back to back -- [nf][kSums] then [nf][kTot] at f0 * (kSums + kTot) --: ONE read-back)
+    uint8_t* const h_sums = static_cast<uint8_t*>(sc.h_pinned);
     uint8_t* const h_freq = h_sums + n * (kSums + kTot);                          // [n][kFreq]
     auto part_source = [&](size_t f0) {
       sjpeg_hip_source s = *src;
@@ -1560,21 +1566,19 @@ int sjpeg_hip_encode_batch_src(sjpeg_hip_engine* engine, const sjpeg_hip_source*
     static const bool no_coefs = getenv("SJPEG_HIP_NO_COEF_KEEP") != nullptr;       // (A/B: every pass from the pixels)
     engine->coefs_keep = adaptive && optimize && !no_coefs;
     if (adaptive) {
-      int64_t* const d_sums = static_cast<int64_t*>(sc.d_sums);
-      int32_t* const d_tot = reinterpret_cast<int32_t*>(static_cast<uint8_t*>(sc.d_sums) + n * kSums);
       for (int p = 0; p < nparts; ++p) {
         const size_t f0 = part_lo[p], nf = part_lo[p + 1] - f0;
         const sjpeg_hip_source ps = part_source(f0);
         uint32_t* const d_hist = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(sc.d_hist) + f0 * kHist);
+        uint8_t* const d_part = static_cast<uint8_t*>(sc.d_sums) + f0 * (kSums + kTot);
         engine->replay_first = static_cast<int>(f0);
         int rc = sjpeg_hip_scan_histogram_src(engine, &ps, width, height, yuv_mode, static_cast<int>(nf), d_hist, stream);
         if (rc == 0) {
           rc = sjpeg_hip_adapt_sums(d_hist, static_cast<int>(nf), reinterpret_cast<const uint8_t(*)[64]>(&quant[0]), min_quant,
-                                    d_sums + f0 * (kSums / sizeof(int64_t)), d_tot + f0 * (kTot / sizeof(int32_t)), rs);
+                                    reinterpret_cast<int64_t*>(d_part), reinterpret_cast<int32_t*>(d_part + nf * kSums), rs);
         }
         if (rc != 0) return rc;
-        if (int rcc = read_back(h_sums + f0 * kSums, d_sums + f0 * (kSums / sizeof(int64_t)), nf * kSums)) return rcc;
-        if (int rcc = read_back(h_sums + n * kSums + f0 * kTot, d_tot + f0 * (kTot / sizeof(int32_t)), nf * kTot)) return rcc;
+        if (int rcc = read_back(h_sums + f0 * (kSums + kTot), d_part, nf * (kSums + kTot))) return rcc;
         HIP_TRY(hipEventRecord(sc.ev[p], rs));
       }
     }
@@ -1595,8 +1599,8 @@ int sjpeg_hip_encode_batch_src(sjpeg_hip_engine* engine, const sjpeg_hip_source*
         HIP_TRY(hipEventSynchronize(sc.ev[p]));
         mark("sums here", p);
         for (size_t f = f0; f < f0 + nf; ++f) {
-          sjpeg_hip_adapt_quant_sums(reinterpret_cast<const int64_t*>(h_sums + f * kSums),
-                                     reinterpret_cast<const int32_t*>(h_sums + n * kSums + f * kTot), yuv_mode,
+          sjpeg_hip_adapt_quant_sums(reinterpret_cast<const int64_t*>(h_sums + f0 * (kSums + kTot) + (f - f0) * kSums),
+                                     reinterpret_cast<const int32_t*>(h_sums + f0 * (kSums + kTot) + nf * kSums + (f - f0) * kTot), yuv_mode,
                                      reinterpret_cast<uint8_t(*)[64]>(&quant[f * 128]), min_quant, q_bias,
                                      qdelta_max_luma, qdelta_max_chroma, &tables[f]);
         }
