@@ -317,7 +317,10 @@ int sjpeg_hip_scan_symbol_stats_src(sjpeg_hip_engine* engine, const sjpeg_hip_so
  * `stream`).  quant = the two starting matrices (natural order, e.g. sjpeg_hip_quality_matrices),
  * min_quant NULL = ones, q_bias / qdelta_max_* as EncoderParam (0x78, 12, 1).  method 0..6 as
  * SjpegEncode (trellis methods: host API).  Output as sjpeg_hip_encode_scan_src (complete JPEGs,
- * EOI included). */
+ * EOI included).  A batch of 80 Mpixels or more (or 24 frames) is coded in two parts whose device passes
+ * and host analysis overlap, on two more streams the ENGINE owns: make the engine early in the life of
+ * the process -- a stream made late shares a hardware queue with an older one, the caller's as a rule,
+ * and nothing overlaps (measured: 1.33 ms against 1.18 for 32 4K frames). */
 int sjpeg_hip_encode_batch_src(sjpeg_hip_engine* engine, const sjpeg_hip_source* src,
                                int width, int height, int yuv_mode, int nframes,
                                const uint8_t quant[2][64], const uint8_t* min_quant /*[2][64]*/, int q_bias,
@@ -331,7 +334,8 @@ int sjpeg_hip_encode_batch_src(sjpeg_hip_engine* engine, const sjpeg_hip_source*
  * only after sjpeg_hip_engine_wait(engine, stream) -- which makes `stream` wait for everything
  * the engine has in flight -- or a device synchronisation; do not touch them in between.
  * Results are the same bytes.  The other entry points stay ordered on the caller's stream (they
- * wait for the engine's stream first).  Off by default; switching it off drains the engine. */
+ * wait for the engine's stream first).  Off by default; switching it off drains the engine.  (The
+ * engine's stream is made by the first call that switches the mode on: do that early too.) */
 int sjpeg_hip_engine_set_pipelined(sjpeg_hip_engine* engine, int on);
 int sjpeg_hip_engine_wait(sjpeg_hip_engine* engine, void* stream);
 
