@@ -1445,7 +1445,7 @@ struct BatchScratch {                 // per host thread: device scratch of sjpe
     pass_done = nullptr;
     d_hist = d_sums = d_freq = h_pinned = d_pinned = nullptr; hist_cap = sums_cap = freq_cap = pinned_cap = 0;
   }
-  hipEvent_t ev[8] = {};                         // behind the read-backs of a part: sums [0..3], counts [4..7]
+  hipEvent_t ev[12] = {};                        // behind the read-backs of a part: sums [0..7] (two halves a part), counts [8..11]
   hipEvent_t pass_done = nullptr;
   bool EnsureEvents() {
     for (auto& e : ev) {
@@ -1563,6 +1563,8 @@ int sjpeg_hip_encode_batch_src(sjpeg_hip_engine* engine, const sjpeg_hip_source*
       void* const dv = sc.d_pinned == nullptr ? nullptr : static_cast<uint8_t*>(sc.d_pinned) + (static_cast<uint8_t*>(h_dst) - static_cast<uint8_t*>(sc.h_pinned));
       return copy_by_kernel(dv, d_src, bytes, rs, hipMemcpyDeviceToHost, d_src, h_dst);
     };
+    static const int groups_env = getenv("SJPEG_HIP_SUMS_GROUPS") ? atoi(getenv("SJPEG_HIP_SUMS_GROUPS")) : 0;   // (A/B: 1 = one group a part)
+    auto sums_groups = [&](size_t nf) -> int { return (groups_env == 1 || nf < 8) ? 1 : 2; };
     static const bool no_coefs = getenv("SJPEG_HIP_NO_COEF_KEEP") != nullptr;       // (A/B: every pass from the pixels)
     engine->coefs_keep = adaptive && optimize && !no_coefs;
     if (adaptive) {
@@ -1570,16 +1572,21 @@ int sjpeg_hip_encode_batch_src(sjpeg_hip_engine* engine, const sjpeg_hip_source*
         const size_t f0 = part_lo[p], nf = part_lo[p + 1] - f0;
         const sjpeg_hip_source ps = part_source(f0);
         uint32_t* const d_hist = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(sc.d_hist) + f0 * kHist);
-        uint8_t* const d_part = static_cast<uint8_t*>(sc.d_sums) + f0 * (kSums + kTot);
         engine->replay_first = static_cast<int>(f0);
         int rc = sjpeg_hip_scan_histogram_src(engine, &ps, width, height, yuv_mode, static_cast<int>(nf), d_hist, stream);
-        if (rc == 0) {
-          rc = sjpeg_hip_adapt_sums(d_hist, static_cast<int>(nf), reinterpret_cast<const uint8_t(*)[64]>(&quant[0]), min_quant,
-                                    reinterpret_cast<int64_t*>(d_part), reinterpret_cast<int32_t*>(d_part + nf * kSums), rs);
-        }
         if (rc != 0) return rc;
-        if (int rcc = read_back(h_sums + f0 * (kSums + kTot), d_part, nf * (kSums + kTot))) return rcc;
-        HIP_TRY(hipEventRecord(sc.ev[p], rs));
+        // the analysis sums in TWO groups, each with its read-back and event: the host fits the first half of the part
+        // while the second is still on its way (what comes back between a part's histogram pass and its statistics
+        // launch is on the critical path of the call: the device waits for that launch)
+        for (int h = 0; h < sums_groups(nf); ++h) {
+          const size_t g0 = f0 + (nf * h) / sums_groups(nf), gn = f0 + (nf * (h + 1)) / sums_groups(nf) - g0;
+          uint8_t* const d_grp = static_cast<uint8_t*>(sc.d_sums) + g0 * (kSums + kTot);      // [gn][kSums] then [gn][kTot]
+          rc = sjpeg_hip_adapt_sums(d_hist + (g0 - f0) * (kHist / sizeof(uint32_t)), static_cast<int>(gn), reinterpret_cast<const uint8_t(*)[64]>(&quant[0]), min_quant,
+                                    reinterpret_cast<int64_t*>(d_grp), reinterpret_cast<int32_t*>(d_grp + gn * kSums), rs);
+          if (rc != 0) return rc;
+          if (int rcc = read_back(h_sums + g0 * (kSums + kTot), d_grp, gn * (kSums + kTot))) return rcc;
+          HIP_TRY(hipEventRecord(sc.ev[2 * p + h], rs));
+        }
       }
     }
     static const bool batch_debug = getenv("SJPEG_HIP_BATCH_DEBUG") != nullptr;      // (measurement aid: host timeline on stderr)
@@ -1595,14 +1602,18 @@ int sjpeg_hip_encode_batch_src(sjpeg_hip_engine* engine, const sjpeg_hip_source*
     for (int p = 0; p < nparts; ++p) {
       const size_t f0 = part_lo[p], nf = part_lo[p + 1] - f0;
       if (adaptive) {
-        mark("wait sums", p);
-        HIP_TRY(hipEventSynchronize(sc.ev[p]));
-        mark("sums here", p);
-        for (size_t f = f0; f < f0 + nf; ++f) {
-          sjpeg_hip_adapt_quant_sums(reinterpret_cast<const int64_t*>(h_sums + f0 * (kSums + kTot) + (f - f0) * kSums),
-                                     reinterpret_cast<const int32_t*>(h_sums + f0 * (kSums + kTot) + nf * kSums + (f - f0) * kTot), yuv_mode,
-                                     reinterpret_cast<uint8_t(*)[64]>(&quant[f * 128]), min_quant, q_bias,
-                                     qdelta_max_luma, qdelta_max_chroma, &tables[f]);
+        for (int h = 0; h < sums_groups(nf); ++h) {
+          const size_t g0 = f0 + (nf * h) / sums_groups(nf), gn = f0 + (nf * (h + 1)) / sums_groups(nf) - g0;
+          mark("wait sums", p);
+          HIP_TRY(hipEventSynchronize(sc.ev[2 * p + h]));
+          mark("sums here", p);
+          const uint8_t* const grp = h_sums + g0 * (kSums + kTot);
+          for (size_t f = g0; f < g0 + gn; ++f) {
+            sjpeg_hip_adapt_quant_sums(reinterpret_cast<const int64_t*>(grp + (f - g0) * kSums),
+                                       reinterpret_cast<const int32_t*>(grp + gn * kSums + (f - g0) * kTot), yuv_mode,
+                                       reinterpret_cast<uint8_t(*)[64]>(&quant[f * 128]), min_quant, q_bias,
+                                       qdelta_max_luma, qdelta_max_chroma, &tables[f]);
+          }
         }
       }
       mark("adapted", p);
@@ -1619,7 +1630,7 @@ int sjpeg_hip_encode_batch_src(sjpeg_hip_engine* engine, const sjpeg_hip_source*
         if (rc != 0) return rc;
         if (int rcc = read_back(h_freq + f0 * kFreq, d_freq, nf * kFreq)) return rcc;
         dbg_mark("batch: counts read back");
-        HIP_TRY(hipEventRecord(sc.ev[kMaxParts + p], rs));
+        HIP_TRY(hipEventRecord(sc.ev[2 * kMaxParts + p], rs));
         dbg_mark("batch: event recorded");
         mark("stats launched", p);
       }
@@ -1631,7 +1642,7 @@ int sjpeg_hip_encode_batch_src(sjpeg_hip_engine* engine, const sjpeg_hip_source*
       const size_t f0 = part_lo[p], nf = part_lo[p + 1] - f0;
       if (optimize) {
         mark("wait freq", p);
-        HIP_TRY(hipEventSynchronize(sc.ev[kMaxParts + p]));
+        HIP_TRY(hipEventSynchronize(sc.ev[2 * kMaxParts + p]));
         mark("freq here", p);
         for (size_t f = f0; f < f0 + nf; ++f) {
           tables[f].flags = (tables[f].flags & ~SJPEG_HIP_QUANT_KEEP) | SJPEG_HIP_QUANT_REPLAY;
