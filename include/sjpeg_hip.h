@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SJPEG_HIP_ABI_VERSION 17
+#define SJPEG_HIP_ABI_VERSION 18
 
 enum {
   SJPEG_HIP_OK = 0,
@@ -403,6 +403,15 @@ void sjpeg_hip_adapt_quant_sums(const int64_t* sums, const int32_t* totlast, int
                                 uint8_t quant[2][64], const uint8_t* min_quant /*[2][64]*/, int q_bias,
                                 int qdelta_max_luma, int qdelta_max_chroma,
                                 sjpeg_hip_scan_tables* tables);
+/* ... and the float half on the DEVICE too, behind sjpeg_hip_adapt_sums() on the same stream (src/histogram.cc:169-312:
+ * the two-cloud line fit per position over the candidate steps, lambda from the slopes summed over the live positions
+ * in ascending order, the choice of a step per position -- every expression and accumulation in the reference's order,
+ * IEEE double, no contraction: the result is the host's, bit for bit): d_quant_out[nframes][2][64] = the adapted
+ * matrices (4:0:0: table 0 only is written).  quant = the starting matrices the sums were made for (host array);
+ * sjpeg_hip_finalize_quant() turns a frame's result into its tables.  What sjpeg_hip_encode_batch_src runs: 128 bytes a
+ * frame come back from the device instead of 52 KB, and no regression on the host sits between two device passes. */
+int sjpeg_hip_adapt_decide(const int64_t* d_sums, const int32_t* d_totlast, int nframes, const uint8_t quant[2][64],
+                           int yuv_mode, int qdelta_max_luma, int qdelta_max_chroma, uint8_t* d_quant_out, void* stream);
 
 /* CompileEntropyStats / BuildOptimalTable (src/entropy.cc:254-444) on ONE frame's symbol
  * statistics (host memory, uint32 [2][272]): fills specs[4] = {DC luma, DC chroma, AC luma,

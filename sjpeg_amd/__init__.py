@@ -242,7 +242,7 @@ EXPORTED_C_SYMBOLS = [
     "sjpeg_hip_encode_scan", "sjpeg_hip_scan_coeffs", "sjpeg_hip_quality_matrices",
     "sjpeg_hip_finalize_quant", "sjpeg_hip_default_huffman", "sjpeg_hip_make_header",
     "sjpeg_hip_scan_histogram", "sjpeg_hip_scan_symbol_stats", "sjpeg_hip_adapt_quant",
-    "sjpeg_hip_adapt_sums", "sjpeg_hip_adapt_quant_sums",
+    "sjpeg_hip_adapt_sums", "sjpeg_hip_adapt_quant_sums", "sjpeg_hip_adapt_decide",
     "sjpeg_hip_encode_scan_src", "sjpeg_hip_scan_coeffs_src", "sjpeg_hip_scan_histogram_src",
     "sjpeg_hip_scan_symbol_stats_src", "sjpeg_hip_scan_quant_error_src", "sjpeg_hip_engine_entropy_bits",
     "sjpeg_hip_engine_trim", "sjpeg_hip_host_trim",
@@ -506,6 +506,32 @@ def adapt_quant_device_batch(hists_dev, yuv_mode, quant, min_quant=None, q_bias=
         L.sjpeg_hip_default_huffman(C.byref(t))
         res.append((t, q))
     return res
+
+
+def adapt_quant_on_device(hists_dev, yuv_mode, quant, min_quant=None, dmax_luma=12, dmax_chroma=1, q_bias=0x78):
+    """AnalyseHisto for a batch with BOTH halves on the GPU (sjpeg_hip_adapt_sums + sjpeg_hip_adapt_decide): hists_dev =
+    CUDA int32 tensor [F, 2, 64, 128]; returns the adapted matrices, uint8 [F, 2, 64] (4:0:0: table 1 = quant's).  The
+    starting matrices are finalized first (raised to min_quant), as adapt_quant() and the batch path do."""
+    import torch
+    q0 = np.ascontiguousarray(quant, np.uint8).reshape(2, 64).copy()
+    mq = None if min_quant is None else np.ascontiguousarray(min_quant, np.uint8).reshape(2, 64)
+    mqp = mq.ctypes.data if mq is not None else None
+    lib().sjpeg_hip_finalize_quant(q0.ctypes.data, mqp, q_bias, C.byref(ScanTables()))
+    f = hists_dev.shape[0]
+    sums = torch.zeros((f, 2, 64, 25, 2), dtype=torch.int64, device=hists_dev.device)
+    totlast = torch.zeros((f, 2, 64, 2), dtype=torch.int32, device=hists_dev.device)
+    out = torch.from_numpy(np.broadcast_to(q0, (f, 2, 64)).copy()).to(hists_dev.device)
+    L = lib()
+    st = torch.cuda.current_stream().cuda_stream
+    L.sjpeg_hip_adapt_decide.restype = C.c_int
+    L.sjpeg_hip_adapt_decide.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    rc = L.sjpeg_hip_adapt_sums(hists_dev.contiguous().data_ptr(), f, q0.ctypes.data, mqp, sums.data_ptr(), totlast.data_ptr(), st)
+    if rc == 0:
+        rc = L.sjpeg_hip_adapt_decide(sums.data_ptr(), totlast.data_ptr(), f, q0.ctypes.data, yuv_mode, dmax_luma, dmax_chroma,
+                                      out.data_ptr(), st)
+    if rc != 0:
+        raise SjpegError("sjpeg_hip_adapt_sums / _decide: " + L.sjpeg_hip_last_error().decode())
+    return out.cpu().numpy()
 
 
 def adapt_quant_device(hist_dev, yuv_mode, quant, min_quant=None, q_bias=0x78, dmax_luma=12, dmax_chroma=1):

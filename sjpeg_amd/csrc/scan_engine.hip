@@ -1405,6 +1405,35 @@ int sjpeg_hip_stitch_bands(sjpeg_hip_engine* e, int nbands, const uint32_t* d_wo
   return 0;
 }
 
+namespace {
+// adapt_decide_kernel behind sjpeg_hip_adapt_sums on the same stream: d_quant_out[nframes][2][64]
+int adapt_decide(const int64_t* d_sums, const int32_t* d_totlast, int nframes, const uint8_t quant[2][64], int ntables,
+                 int qdelta_max_luma, int qdelta_max_chroma, uint8_t* d_quant_out, hipStream_t st) {
+  DecideArgs a;
+  a.sums = reinterpret_cast<const long long*>(d_sums);
+  a.totlast = d_totlast;
+  a.quant_out = d_quant_out;
+  memcpy(a.quant_in, quant, sizeof(a.quant_in));
+  a.last_step[0] = qdelta_max_luma + 12;
+  a.last_step[1] = qdelta_max_chroma + 12;
+  hipLaunchKernelGGL(adapt_decide_kernel, dim3(ntables, nframes), dim3(64), 0, st, a);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+}  // namespace
+
+int sjpeg_hip_adapt_decide(const int64_t* d_sums, const int32_t* d_totlast, int nframes, const uint8_t quant[2][64],
+                           int yuv_mode, int qdelta_max_luma, int qdelta_max_chroma, uint8_t* d_quant_out, void* stream) {
+  if (d_sums == nullptr || d_totlast == nullptr || quant == nullptr || d_quant_out == nullptr || nframes <= 0 || nframes > 65535) {
+    return fail(SJPEG_HIP_EINVAL, "null argument or bad nframes");
+  }
+  if (qdelta_max_luma < -12 || qdelta_max_luma > 12 || qdelta_max_chroma < -12 || qdelta_max_chroma > 12) {
+    return fail(SJPEG_HIP_EINVAL, "qdelta_max outside -12 .. 12");
+  }
+  return adapt_decide(d_sums, d_totlast, nframes, quant, yuv_mode == SJPEG_HIP_YUV400 ? 1 : 2, qdelta_max_luma, qdelta_max_chroma,
+                      d_quant_out, static_cast<hipStream_t>(stream));
+}
+
 int sjpeg_hip_adapt_sums(const uint32_t* d_hist, int nframes, const uint8_t quant[2][64],
                          const uint8_t* min_quant, int64_t* d_sums, int32_t* d_totlast, void* stream) {
   if (d_hist == nullptr || quant == nullptr || d_sums == nullptr || d_totlast == nullptr || nframes <= 0 || nframes > 65535) {
@@ -1533,7 +1562,7 @@ int sjpeg_hip_encode_batch_src(sjpeg_hip_engine* engine, const sjpeg_hip_source*
     constexpr size_t kHist = 2 * 64 * 128 * sizeof(uint32_t);
     constexpr size_t kSums = 2 * 64 * kAdaptDeltas * 2 * sizeof(int64_t), kTot = 2 * 64 * 2 * sizeof(int32_t);
     constexpr size_t kFreq = 2 * 272 * sizeof(uint32_t);
-    if (adaptive && (!sc.Ensure(&sc.d_hist, &sc.hist_cap, n * kHist) || !sc.Ensure(&sc.d_sums, &sc.sums_cap, n * (kSums + kTot)))) {
+    if (adaptive && (!sc.Ensure(&sc.d_hist, &sc.hist_cap, n * kHist) || !sc.Ensure(&sc.d_sums, &sc.sums_cap, n * (kSums + kTot + 128)))) {
       return fail(SJPEG_HIP_ENOMEM, "hipMalloc(batch scratch) failed");
     }
     if (optimize && !sc.Ensure(&sc.d_freq, &sc.freq_cap, n * kFreq)) return fail(SJPEG_HIP_ENOMEM, "hipMalloc(batch scratch) failed");
@@ -1565,6 +1594,7 @@ int sjpeg_hip_encode_batch_src(sjpeg_hip_engine* engine, const sjpeg_hip_source*
     };
     static const int groups_env = getenv("SJPEG_HIP_SUMS_GROUPS") ? atoi(getenv("SJPEG_HIP_SUMS_GROUPS")) : 0;   // (A/B: 1 = one group a part)
     auto sums_groups = [&](size_t nf) -> int { return (groups_env == 1 || nf < 8) ? 1 : 2; };
+    static const bool device_decide = getenv("SJPEG_HIP_HOST_REGRESSION") == nullptr;   // (A/B: the float half of the analysis on the host)
     static const bool no_coefs = getenv("SJPEG_HIP_NO_COEF_KEEP") != nullptr;       // (A/B: every pass from the pixels)
     engine->coefs_keep = adaptive && optimize && !no_coefs;
     if (adaptive) {
@@ -1584,7 +1614,17 @@ int sjpeg_hip_encode_batch_src(sjpeg_hip_engine* engine, const sjpeg_hip_source*
           rc = sjpeg_hip_adapt_sums(d_hist + (g0 - f0) * (kHist / sizeof(uint32_t)), static_cast<int>(gn), reinterpret_cast<const uint8_t(*)[64]>(&quant[0]), min_quant,
                                     reinterpret_cast<int64_t*>(d_grp), reinterpret_cast<int32_t*>(d_grp + gn * kSums), rs);
           if (rc != 0) return rc;
-          if (int rcc = read_back(h_sums + g0 * (kSums + kTot), d_grp, gn * (kSums + kTot))) return rcc;
+          if (device_decide) {
+            // the regression too (adapt_decide_kernel): 128 bytes a frame come back instead of 52 KB, and the host's 7 us a frame
+            // between a part's histogram pass and its statistics launch are gone
+            uint8_t* const d_q = static_cast<uint8_t*>(sc.d_sums) + n * (kSums + kTot) + g0 * 128;
+            if ((rc = adapt_decide(reinterpret_cast<const int64_t*>(d_grp), reinterpret_cast<const int32_t*>(d_grp + gn * kSums), static_cast<int>(gn),
+                                   reinterpret_cast<const uint8_t(*)[64]>(&quant[0]), yuv_mode == SJPEG_HIP_YUV400 ? 1 : 2,
+                                   qdelta_max_luma, qdelta_max_chroma, d_q, rs))) return rc;
+            if (int rcc = read_back(h_sums + g0 * 128, d_q, gn * 128)) return rcc;
+          } else {
+            if (int rcc = read_back(h_sums + g0 * (kSums + kTot), d_grp, gn * (kSums + kTot))) return rcc;
+          }
           HIP_TRY(hipEventRecord(sc.ev[2 * p + h], rs));
         }
       }
@@ -1608,6 +1648,14 @@ int sjpeg_hip_encode_batch_src(sjpeg_hip_engine* engine, const sjpeg_hip_source*
           HIP_TRY(hipEventSynchronize(sc.ev[2 * p + h]));
           mark("sums here", p);
           const uint8_t* const grp = h_sums + g0 * (kSums + kTot);
+          if (device_decide) {
+            const int ntab = yuv_mode == SJPEG_HIP_YUV400 ? 1 : 2;
+            for (size_t f = g0; f < g0 + gn; ++f) {
+              memcpy(&quant[f * 128], h_sums + f * 128, static_cast<size_t>(ntab) * 64);
+              sjpeg_hip_finalize_quant(reinterpret_cast<uint8_t(*)[64]>(&quant[f * 128]), min_quant, q_bias, &tables[f]);
+            }
+            continue;
+          }
           for (size_t f = g0; f < g0 + gn; ++f) {
             sjpeg_hip_adapt_quant_sums(reinterpret_cast<const int64_t*>(grp + (f - g0) * kSums),
                                        reinterpret_cast<const int32_t*>(grp + gn * kSums + (f - g0) * kTot), yuv_mode,

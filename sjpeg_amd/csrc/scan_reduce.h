@@ -127,3 +127,93 @@ __global__ __launch_bounds__(64) void adapt_sums_kernel(const AdaptArgs a) {
   a.sums[(cell * 25 + delta) * 2] = bsum;
   a.sums[(cell * 25 + delta) * 2 + 1] = dsum;
 }
+
+// ------------------------------------------------------------------------------------
+// The float / double half of AnalyseHisto (reference src/histogram.cc:169-312; this library's host form: AdaptDecide,
+// jpeg_host.cc) on the device, behind adapt_sums_kernel: the host's regression -- 7 us a frame, read out of 52 KB of
+// pinned memory a frame -- sat between a part's histogram pass and its statistics launch, which the device waits for.
+// One wave per (table, frame), a lane per coefficient position.  Every accumulated term and the score are the host
+// form's expressions in the host form's ORDER (normative for the rounding; no contraction: -ffp-contract=off): a lane fits
+// its own position's two clouds over the 25 candidate steps; the two slope sums over the live positions are added up by
+// ONE lane in ascending position order, as the host's loop does; then every lane picks its step.  IEEE double add / mul /
+// div, int64 -> double and double -> float conversions round to nearest even on this device as on the host.
+struct DecideArgs {
+  const long long* sums;            // [nframes][2][64][25][2] (adapt_sums_kernel)
+  const int* totlast;               // [nframes][2][64][2]
+  uint8_t* quant_out;               // [nframes][2][64]: the adapted matrices (tables the launch does not run keep quant_in)
+  uint8_t quant_in[2][64];
+  int last_step[2];                 // qdelta_max of the table - kQDeltaMin
+};
+__global__ __launch_bounds__(64) void adapt_decide_kernel(const DecideArgs a) {
+  __shared__ double cov_d[64], cov_r[64];
+  __shared__ double lam;
+  const int idx = blockIdx.x, frame = blockIdx.y, pos = threadIdx.x;
+  constexpr float kWeight[25] = {0, 0, 0, 0, 0, 1, 5, 16, 43, 94, 164, 228, 255, 228, 164, 94, 43, 16, 5, 1, 0, 0, 0, 0, 0};
+  const size_t cell = (static_cast<size_t>(frame) * 2 + idx) * 64 + pos;
+  bool live = !((0x103ull >> pos) & 1ull);                        // DC and its two neighbours are never touched
+  if (live && a.totlast[cell * 2] < 0.5 * a.totlast[cell * 2 + 1]) live = false;   // sparse histogram
+  float dist[25], rate[25];
+  double cd = 0., cr = 0.;
+  if (live) {
+    double w = 0., x = 0., xx = 0., d = 0., dd = 0., xd = 0., r = 0., xr = 0.;
+#pragma unroll
+    for (int k = 0; k < 25; ++k) {
+      const long long s0 = a.sums[(cell * 25 + k) * 2], s1 = a.sums[(cell * 25 + k) * 2 + 1];
+      if (s1 == static_cast<long long>(0x8000000000000000ull)) {   // quantizer out of range
+        dist[k] = 3.402823466e+38f;
+        rate[k] = 0.f;
+        continue;
+      }
+      const double ra = static_cast<double>(s0), di = static_cast<double>(s1);
+      dist[k] = static_cast<float>(di);
+      rate[k] = static_cast<float>(ra);
+      if (kWeight[k] > 0.f) {
+        const double weight = kWeight[k], step = static_cast<double>(k - 12);
+        w += weight;
+        x += weight * step;
+        xx += weight * step * step;
+        d += weight * di;
+        dd += weight * di * di;
+        r += weight * ra;
+        xd += weight * di * step;
+        xr += weight * ra * step;
+      }
+    }
+    cd = w * xd - x * d;
+    cr = w * xr - x * r;
+    if (cd * cd < 0.5 * (w * xx - x * x) * (w * dd - d * d)) live = false;     // not (nearly) linear in the step
+  }
+  cov_d[pos] = live ? cd : 0.;
+  cov_r[pos] = live ? cr : 0.;
+  const unsigned long long live_mask = __ballot(live);
+  __syncthreads();
+  if (pos == 0) {
+    double sd = 0., sr = 0.;
+    for (int p = 0; p < 64; ++p) {
+      if ((live_mask >> p) & 1ull) { sd += cov_d[p]; sr += cov_r[p]; }
+    }
+    double lambda = 128.;
+    if (sd > 1000. && sr < -10.) {
+      lambda = -sd / sr;
+      if (lambda < 1.) lambda = 1.;
+    }
+    lam = lambda;
+  }
+  __syncthreads();
+  int q = a.quant_in[idx][pos];
+  if (live) {
+    const double lambda = lam;
+    float best = 3.402823466e+38f;
+    int step = 0;
+    const int last = a.last_step[idx];
+#pragma unroll
+    for (int k = 0; k < 25; ++k) {
+      if (k > last) break;
+      if (!(dist[k] < 3.402823466e+38f)) continue;
+      const float score = dist[k] + lambda * rate[k];
+      if (score < best) { best = score; step = k - 12; }
+    }
+    q += step;
+  }
+  a.quant_out[cell] = static_cast<uint8_t>(q);
+}

@@ -1044,6 +1044,54 @@ def test_adaptive_analysis_on_device_equals_host(engine):
                     assert bytes(t_host) == bytes(t_dev)
 
 
+def test_adaptive_decision_on_device_equals_host(engine):
+    """The float half of AnalyseHisto on the GPU (sjpeg_hip_adapt_decide: line fits, lambda, step per position -- what
+    sjpeg_hip_encode_batch_src runs) == the host's (which the CPU tests pin against the oracle): pictures, and synthetic
+    histograms that sit on its branches -- sparse positions, flat and single-bin ones, huge counts, steps cut off by
+    min_quant / 255, every qdelta_max, 4:0:0."""
+    rng = np.random.RandomState(1234)
+    hists = []
+    for (w, h, mode) in ((640, 360, 1), (333, 211, 3), (97, 61, 4), (1920, 1080, 1)):
+        img = synth.g_struct(w, h, 17) if w != 333 else rng.randint(0, 256, (h, w, 3)).astype(np.uint8)
+        hists.append((engine.scan_histogram(dev(img), mode)[0].cpu().numpy().view(np.uint32).reshape(2, 64, 128), mode))
+    for k in range(40):                                   # synthetic: geometric tails of random scale and population
+        hs = np.zeros((2, 64, 128), np.uint32)
+        for t in range(2):
+            for pos in range(64):
+                kind = rng.randint(6)
+                n = int(rng.choice([0, 3, 50, 5000, 400000, 20000000]))
+                if kind == 0 or n == 0:
+                    continue
+                if kind == 1:
+                    hs[t, pos, rng.randint(128)] = n
+                elif kind == 2:
+                    hs[t, pos, :] = n // 128
+                else:
+                    scale = float(rng.choice([0.3, 2.0, 9.0, 40.0]))
+                    bins = np.minimum(rng.geometric(1.0 / (1.0 + scale), size=min(n, 20000)) - 1, 140)
+                    cnt = np.bincount(bins[bins < 128], minlength=128).astype(np.uint64) * max(n // min(n, 20000), 1)
+                    hs[t, pos, :] = np.minimum(cnt, 0xffffffff).astype(np.uint32)
+        hists.append((hs, int(rng.choice([1, 3, 4]))))
+    checked = 0
+    for hs, mode in hists:
+        hd = torch.from_numpy(hs.view(np.int32).copy()).cuda().unsqueeze(0)
+        for q in (8.0, 50.0, 75.0, 97.0):
+            quant = sj.make_tables(quality=q)[1]
+            for mq in (None, np.maximum(quant, 4), np.minimum(quant.astype(np.int32) + 3, 255).astype(np.uint8)):
+                for (dl, dc) in ((12, 1), (5, 7), (0, 0), (-3, 12)):
+                    _, q_host = sj.adapt_quant(hs, mode, quant, mq, 0x78, dl, dc)
+                    q_dev = sj.adapt_quant_on_device(hd, mode, quant, mq, dl, dc)[0]
+                    ntab = 1 if mode == 4 else 2
+                    want = np.asarray(q_host, np.uint8).reshape(2, 64)
+                    # (the host clamps to min_quant when it finalizes; the device result is the step choice itself)
+                    t_dev = sj.ScanTables()
+                    qd = q_dev.copy()
+                    sj.lib().sjpeg_hip_finalize_quant(qd.ctypes.data, None if mq is None else np.ascontiguousarray(mq, np.uint8).ctypes.data, 0x78, C.byref(t_dev))
+                    assert np.array_equal(qd[:ntab], want[:ntab]), (mode, q, dl, dc, checked)
+                    checked += 1
+    assert checked == 44 * 4 * 3 * 4
+
+
 def test_keep_and_replay_flags(oracle):
     """SJPEG_HIP_QUANT_KEEP / REPLAY: the statistics pass leaves its quantized blocks behind and the
     encode pass entropy-codes them without touching the pixels again (plain and trellis)."""

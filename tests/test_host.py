@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_library_loads_and_exports_declared_symbols():
     lib = sj.lib()
     assert lib.SjpegVersion() == 0x000101
-    assert lib.sjpeg_hip_abi_version() == 17
+    assert lib.sjpeg_hip_abi_version() == 18
     declared = set()
     for hdr in ("include/sjpeg_hip.h", "include/sjpeg.h"):
         text = open(os.path.join(ROOT, hdr)).read()
