@@ -1593,8 +1593,10 @@ int sjpeg_hip_encode_batch_src(sjpeg_hip_engine* engine, const sjpeg_hip_source*
       return copy_by_kernel(dv, d_src, bytes, rs, hipMemcpyDeviceToHost, d_src, h_dst);
     };
     static const int groups_env = getenv("SJPEG_HIP_SUMS_GROUPS") ? atoi(getenv("SJPEG_HIP_SUMS_GROUPS")) : 0;   // (A/B: 1 = one group a part)
-    auto sums_groups = [&](size_t nf) -> int { return (groups_env == 1 || nf < 8) ? 1 : 2; };
     static const bool device_decide = getenv("SJPEG_HIP_HOST_REGRESSION") == nullptr;   // (A/B: the float half of the analysis on the host)
+    // (two groups pay when the HOST fits the steps -- it fits the first half while the second is on its way; with the fit on
+    // the device the second group's launches only lengthen the chain: 1.150 against 1.141 ms)
+    auto sums_groups = [&](size_t nf) -> int { return (groups_env == 1 || nf < 8 || (device_decide && groups_env != 2)) ? 1 : 2; };
     static const bool no_coefs = getenv("SJPEG_HIP_NO_COEF_KEEP") != nullptr;       // (A/B: every pass from the pixels)
     engine->coefs_keep = adaptive && optimize && !no_coefs;
     if (adaptive) {

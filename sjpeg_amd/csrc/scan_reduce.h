@@ -183,15 +183,14 @@ __global__ __launch_bounds__(64) void adapt_decide_kernel(const DecideArgs a) {
     cr = w * xr - x * r;
     if (cd * cd < 0.5 * (w * xx - x * x) * (w * dd - d * d)) live = false;     // not (nearly) linear in the step
   }
+  // (a position that is not live adds +0.0: x + 0.0 == x, so all 64 are added, in order, without a test -- the reads pipeline)
   cov_d[pos] = live ? cd : 0.;
   cov_r[pos] = live ? cr : 0.;
-  const unsigned long long live_mask = __ballot(live);
   __syncthreads();
   if (pos == 0) {
     double sd = 0., sr = 0.;
-    for (int p = 0; p < 64; ++p) {
-      if ((live_mask >> p) & 1ull) { sd += cov_d[p]; sr += cov_r[p]; }
-    }
+#pragma unroll
+    for (int p = 0; p < 64; ++p) { sd += cov_d[p]; sr += cov_r[p]; }
     double lambda = 128.;
     if (sd > 1000. && sr < -10.) {
       lambda = -sd / sr;
