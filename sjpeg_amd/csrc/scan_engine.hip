@@ -1550,9 +1550,10 @@ int sjpeg_hip_encode_batch_src(sjpeg_hip_engine* engine, const sjpeg_hip_source*
     static const int parts_env = getenv("SJPEG_HIP_BATCH_PARTS") ? atoi(getenv("SJPEG_HIP_BATCH_PARTS")) : 0;   // (experiments)
     // (measured: 32 4K frames 1.84 -> 1.61 ms in two parts, 16 frames 1.13 -> 1.21: parts of fewer than a dozen
     // frames lose more to their smaller launches than the overlap gives)
-    // (round 5, with the persistent histogram kind and early uploads: 4K frames -- 8 frames 0.46 ms in one part, 0.48 in
-    // two; 12 frames 0.64 / 0.57; 16 frames 0.93 / 0.86; 20 frames 0.96 / 0.82: two parts from 80 Mpixels on)
-    const bool big = n >= 2 && static_cast<double>(n) * width * height >= 80e6;
+    // (round 5, with the persistent histogram kind, early uploads and the fit on the device: 4K frames -- 8 frames 0.40 ms
+    // in one part, 0.44 in two; 12 frames 0.54 / 0.55; 16 frames 0.68 / 0.66; 20 frames 0.80 / 0.79; 24 frames 0.99 / 0.89:
+    // two parts from 125 Mpixels on.  With the regression on the host it was 80: 12 frames 0.64 / 0.57)
+    const bool big = n >= 2 && static_cast<double>(n) * width * height >= 125e6;
     int nparts = ((n >= 24 || big) && (adaptive || optimize)) ? 2 : 1;
     if (parts_env >= 1 && parts_env <= kMaxParts && (adaptive || optimize) && n >= static_cast<size_t>(parts_env)) nparts = parts_env;
     size_t part_lo[kMaxParts + 1];
