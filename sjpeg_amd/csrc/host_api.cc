@@ -559,7 +559,7 @@ bool Encoder::RunImpl() {
   if (adaptive) {
     // CollectHistograms on the GPU (src/enc.cc:425-429, src/dichotomy.cc:117-121); the histogram
     // stays on the device, only the sums AnalyseHisto makes of it come back
-    if (!ctx.Ensure(&ctx.d_hist, &ctx.hist_cap, kHistBytes + kSumsBytes + kTotLastBytes)) return false;
+    if (!ctx.Ensure(&ctx.d_hist, &ctx.hist_cap, kHistBytes + kSumsBytes + kTotLastBytes + 128)) return false;
     if (sjpeg_hip_scan_histogram_src(ctx.engine, &dsrc, W_, H_, mode, 1,
                                  static_cast<uint32_t*>(ctx.d_hist), ctx.stream) != 0) {
       return FailHip("sjpeg_hip_scan_histogram");
@@ -572,6 +572,25 @@ bool Encoder::RunImpl() {
     int32_t* const d_totlast = reinterpret_cast<int32_t*>(base + kHistBytes + kSumsBytes);
     static thread_local int64_t sums[2][64][sjpeg_host::kAdaptDeltas][2];
     static thread_local int32_t totlast[2][64][2];
+    // the float half on the device too (sjpeg_hip_adapt_decide: the host's result bit for bit; 128 bytes come back instead
+    // of 52 KB) -- for the step limits the kernel's 25 candidates cover; others take the host's form below
+    if (qdelta_luma_ >= -12 && qdelta_luma_ <= 12 && qdelta_chroma_ >= -12 && qdelta_chroma_ <= 12) {
+      uint8_t* const d_q = base + kHistBytes + kSumsBytes + kTotLastBytes;
+      uint8_t q_new[2][64];
+      if (sjpeg_hip_adapt_sums(static_cast<const uint32_t*>(ctx.d_hist), 1, quant_, &min_quant_[0][0], d_sums,
+                               d_totlast, ctx.stream) != 0 ||
+          sjpeg_hip_adapt_decide(d_sums, d_totlast, 1, quant_, nb_comps == 1 ? SJPEG_HIP_YUV400 : SJPEG_HIP_YUV420,
+                                 qdelta_luma_, qdelta_chroma_, d_q, ctx.stream) != 0 ||
+          !ctx.ToHost(q_new, d_q, sizeof(q_new))) {
+        adapt_ok = false;
+        return;
+      }
+      memcpy(quant_, q_new, static_cast<size_t>(ntables) * 64);
+      for (int idx = (nb_comps > 1 ? 1 : 0); idx >= 0; --idx) {
+        sjpeg_host::FinalizeQuantizer(quant_[idx], min_quant_[idx], q_bias_, idx, &tables);
+      }
+      return;
+    }
     if (sjpeg_hip_adapt_sums(static_cast<const uint32_t*>(ctx.d_hist), 1, quant_, &min_quant_[0][0], d_sums,
                              d_totlast, ctx.stream) != 0 ||
         !ctx.ToHost(sums, d_sums, kSumsBytes) ||
