@@ -1471,16 +1471,19 @@ struct BatchScratch {                 // per host thread: device scratch of sjpe
     if (h_pinned) (void)hipHostFree(h_pinned);
     for (auto& e : ev) { if (e) (void)hipEventDestroy(e); e = nullptr; }
     if (pass_done) (void)hipEventDestroy(pass_done);
-    pass_done = nullptr;
+    if (call_begin) (void)hipEventDestroy(call_begin);
+    pass_done = nullptr; call_begin = nullptr;
     d_hist = d_sums = d_freq = h_pinned = d_pinned = nullptr; hist_cap = sums_cap = freq_cap = pinned_cap = 0;
   }
   hipEvent_t ev[12] = {};                        // behind the read-backs of a part: sums [0..7] (two halves a part), counts [8..11]
   hipEvent_t pass_done = nullptr;
+  hipEvent_t call_begin = nullptr;                 // on the call's stream before anything of the call: the early uploads wait for it
   bool EnsureEvents() {
     for (auto& e : ev) {
       if (e == nullptr && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { e = nullptr; return false; }
     }
     if (pass_done == nullptr && hipEventCreateWithFlags(&pass_done, hipEventDisableTiming) != hipSuccess) { pass_done = nullptr; return false; }
+    if (call_begin == nullptr && hipEventCreateWithFlags(&call_begin, hipEventDisableTiming) != hipSuccess) { call_begin = nullptr; return false; }
     return true;
   }
   bool EnsurePinned(size_t need) {
@@ -1586,7 +1589,22 @@ int sjpeg_hip_encode_batch_src(sjpeg_hip_engine* engine, const sjpeg_hip_source*
       engine->replay_total = nframes;
       rs = engine->batch_side;
       static const bool late_uploads = getenv("SJPEG_HIP_LATE_UPLOADS") != nullptr;       // (A/B: uploads in the call's own stream)
-      if (!late_uploads) engine->up_stream = engine->batch_up;
+      if (!late_uploads) {
+        // The early uploads overwrite what the PREVIOUS call's kernels may still be reading -- its per-frame tables (K1 on
+        // its stream), its headers and header offsets (the stitch kernels; the engine's side stream in pipelined mode).  An
+        // adaptive call's first upload follows a host wait on its own histogram pass, which sits behind that work on the
+        // call's stream; a call with optimised tables alone (methods 1, 2) uploads at once, and the side stream is behind
+        // nobody's wait: the upload stream is put behind both before anything goes to it (two asynchronous
+        // method-1 batches back to back: test_back_to_back_batches_without_a_host_wait).
+        if (int rco = order_on_stream(engine, st)) return rco;
+        HIP_TRY(hipEventRecord(sc.call_begin, st));
+        HIP_TRY(hipStreamWaitEvent(engine->batch_up, sc.call_begin, 0));
+        if (engine->side_pending) {
+          if (int rcs = side_mark(engine)) return rcs;
+          HIP_TRY(hipStreamWaitEvent(engine->batch_up, engine->side_done, 0));
+        }
+        engine->up_stream = engine->batch_up;
+      }
     }
     // device -> the pinned block, on the side stream: a kernel writes it over the bus (no runtime copy: stage_copy_kernel)
     auto read_back = [&](void* h_dst, const void* d_src, size_t bytes) -> int {

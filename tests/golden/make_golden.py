@@ -67,6 +67,12 @@ def main():
         put(f"noise4k|{mname}|q75|m0", r.encode(n4k, 75.0, 0, mode))
     for method in (1, 3, 4):
         put(f"struct4k|420|q75|m{method}", r.encode(s4k, 75.0, method, 1))
+    # G_noise 4K with default parameters (method 4); 4:4:4 and 4:0:0 beside it, and the
+    # structured picture in those two modes (wide levels, two bit windows per segment, 4:4:4 parts)
+    for mname, mode in MODES.items():
+        put(f"noise4k|{mname}|q75|m4", r.encode(n4k, 75.0, 4, mode))
+        if mname != "420":
+            put(f"struct4k|{mname}|q75|m4", r.encode(s4k, 75.0, 4, mode))
     # config #5: recompress recipe (examples/sjpeg.cc:262-286), method-0 variant
     src = r.encode_param(s4k, quality=92.0, yuv_mode=1, huffman=True, adaptive=True)
     nq, qm = r.find_quantizer(src)
@@ -93,6 +99,10 @@ def main():
     # config #3: 8K 4:4:4 q90
     s8k = synth.g_struct(7680, 4320)
     put("struct8k|444|q90|m0", r.encode(s8k, 90.0, 0, 3))
+    # SURVEY 8c / BASELINE "C3'": the same frame with default parameters (method 4)
+    put("struct8k|444|q90|m4", r.encode(s8k, 90.0, 4, 3))
+    put("struct8k|444|q90|m1", r.encode(s8k, 90.0, 1, 3))
+    put("struct8k|444|q90|m3", r.encode(s8k, 90.0, 3, 3))
     with open(os.path.join(HERE, "digests.json"), "w") as f:
         json.dump(dig, f, indent=1, sort_keys=True)
     print("wrote", len(small), "small vectors,", len(dig), "digests")

@@ -279,6 +279,83 @@ def test_methods_full_size_digests(engine, digests):
     assert hashlib.md5(host).hexdigest() == digests["struct4k|420|q75|m4"]["md5"]
 
 
+@pytest.mark.parametrize("key,gen,w,h,q,mode", [
+    ("struct8k|444|q90", "struct", 7680, 4320, 90.0, 3),      # SURVEY 8c / BASELINE C3': cd6a30d5..., 24 565 823 B
+    ("noise4k|420|q75", "noise", 3840, 2160, 75.0, 1),        # 1eb32ac3..., 4 445 849 B
+    ("noise4k|444|q75", "noise", 3840, 2160, 75.0, 3),
+    ("noise4k|400|q75", "noise", 3840, 2160, 75.0, 4),
+    ("struct4k|444|q75", "struct", 3840, 2160, 75.0, 3),
+    ("struct4k|400|q75", "struct", 3840, 2160, 75.0, 4),
+])
+def test_default_parameters_full_size_known_answers(engine, digests, key, gen, w, h, q, mode):
+    """Default parameters (method 4: adaptive quantization + optimised Huffman tables,
+    /root/reference/src/enc.cc:323-386, src/histogram.cc:126-339, src/entropy.cc:208-444) at full size in the
+    modes and on the pictures where the statistics / replay kinds see wide levels (> 127), two bit windows per
+    segment and 4:4:4 / 4:0:0 part lists: through the batch entry of the C-ABI (sjpeg_hip_encode_batch_src) and
+    through the host API (what sjpeg::Encode does with a default EncoderParam and this colour mode)."""
+    img = (synth.g_struct if gen == "struct" else synth.g_noise)(w, h)
+    d = digests[key + "|m4"]
+    got = sj.encode_device_method(dev(img), q, mode, 4, engine=engine)[0]
+    assert len(got) == d["size"] and hashlib.md5(got).hexdigest() == d["md5"], key
+    host = sj.SjpegEncode(img, q, 4, mode)
+    assert host is not None, sj.last_error()
+    assert len(host) == d["size"] and hashlib.md5(host).hexdigest() == d["md5"], key + " (host API)"
+    if key.startswith("struct8k"):
+        for m in (1, 3):                      # optimised tables alone, adaptive quantization alone
+            dm = digests[f"{key}|m{m}"]
+            got = sj.encode_device_method(dev(img), q, mode, m, engine=engine)[0]
+            assert len(got) == dm["size"] and hashlib.md5(got).hexdigest() == dm["md5"], (key, m)
+
+
+def test_default_parameters_batches_of_noise_and_444(engine, digests):
+    """The same known answers as members of BATCHES (two-part batches: >= 125 Mpixels): four 8K 4:4:4 q90 frames
+    (bench.py's "C3 default parameters x4"), and 4K noise next to the structured picture in one batch, so that a
+    part holds frames with narrow and with wide kept blocks."""
+    s8 = torch.from_numpy(synth.g_struct(7680, 4320)).cuda()
+    frames = s8.unsqueeze(0).expand(4, -1, -1, -1).contiguous()
+    got = sj.encode_device_method(frames, 90.0, 3, 4, engine=engine)
+    d = digests["struct8k|444|q90|m4"]
+    for k in range(4):
+        assert len(got[k]) == d["size"] and hashlib.md5(got[k]).hexdigest() == d["md5"], k
+    del frames, s8
+    pics = [synth.g_noise(3840, 2160), synth.g_struct(3840, 2160)]
+    frames = torch.from_numpy(np.stack([pics[k % 2] for k in range(18)])).cuda()
+    for mode, mname in ((1, "420"), (3, "444")):
+        got = sj.encode_device_method(frames, 75.0, mode, 4, engine=engine)
+        for k in range(18):
+            d = digests[("noise4k" if k % 2 == 0 else "struct4k") + f"|{mname}|q75|m4"]
+            assert len(got[k]) == d["size"] and hashlib.md5(got[k]).hexdigest() == d["md5"], (mname, k)
+
+
+def test_back_to_back_batches_without_a_host_wait(engine, oracle):
+    """Two asynchronous batch calls of a method with optimised tables but no adaptive quantization (methods 1, 2: the
+    call's first upload -- the statistics tables of its first part -- is not preceded by any host wait), two parts each
+    (>= 24 frames), queued back to back: the second call's early uploads must not reach the table and header buffers
+    before the first call's encode kernels have read them (scan_engine.hip: the upload stream waits for an
+    event on the call's stream).  Both calls' frames equal the oracle's."""
+    w, h = 1920, 1080
+    pics = [synth.g_struct(w, h, 900 + k) for k in range(3)] + [synth.g_noise(w, h, 77)]
+    want = {m: [oracle.encode_method(p, 75.0, 1, m) for p in pics] for m in (1, 2)}
+    frames = torch.from_numpy(np.stack([pics[k % 4] for k in range(26)])).cuda()
+    rows = frames.view(26, h, w * 3)
+    src, _ = sj.make_source(sj.SRC_RGB, [rows])
+    q = np.zeros((2, 64), np.uint8)
+    sj.lib().sjpeg_hip_quality_matrices(75.0, q.ctypes.data)
+    for piped in (False, True):
+        engine.set_pipelined(piped)
+        try:
+            for rep in range(3):
+                calls = [engine.encode_batch(src, 26, w, h, 1, q, method=m) for m in (1, 2, 1, 2)]
+                engine.wait()
+                torch.cuda.synchronize()
+                for (out, sizes), m in zip(calls, (1, 2, 1, 2)):
+                    got = sj._fetch_frames(out, sizes)
+                    for k in range(26):
+                        assert got[k] == want[m][k % 4], (piped, rep, m, k)
+        finally:
+            engine.set_pipelined(False)
+
+
 def test_methods_batched_per_frame_tables(engine, oracle):
     """One launch per pass over a batch whose frames each get their own adapted quantizer,
     optimised Huffman codes and header (sjpeg_hip_*_multi): every frame equals the reference's
