@@ -12,9 +12,11 @@
 // quantization, trellis quantization), and the multi-pass size / PSNR search (every pass is a GPU
 // pass over the resident picture), SJPEG_YUV_SHARP (the sharp
 // conversion runs on the device).  SJPEG_YUV_AUTO, SjpegCompress() and SjpegRiskiness() need the
-// reference's trained score table, which this library does not ship: install it with
-// sjpeg_hip_set_riskiness_table() or SJPEG_HIP_RISKINESS_TABLE (sjpeg_hip.h); without it those
-// requests FAIL (0 / false).  There is no CPU fallback for anything.
+// reference's trained score table: it SHIPS with the library as riskiness.bin (reference data,
+// unmodified, Apache-2.0: riskiness.NOTICE) and is found next to libsjpeg_amd.so; a table from
+// elsewhere goes in through SJPEG_HIP_RISKINESS_TABLE or sjpeg_hip_set_riskiness_table()
+// (sjpeg_hip.h).  A library installed WITHOUT the file fails those three requests (0 / false).
+// There is no CPU fallback for anything.
 // The reason of the last failure on the calling thread: SjpegHipLastError().
 #ifndef SJPEG_AMD_SJPEG_H_
 #define SJPEG_AMD_SJPEG_H_

@@ -273,6 +273,42 @@ def test_bench_launcher_starts_the_world_it_was_asked_for():
     assert r1.returncode == 0 and json.loads([ln for ln in r1.stdout.splitlines() if ln.startswith("{")][0])["n_gpus"] == 1
 
 
+def test_bench_two_ranks_end_to_end_with_a_stand_in_device():
+    """`bench.py --gpus 2` from `import torch` to the JSON line on gloo: the process group, the fences
+    and max-over-ranks timing, the packed-output exchange loop, the local sinks, config #4 sharded + gathered with
+    its real MD5 check, the model of the two ceilings -- everything but the device (tests/bench_stub.py: CPU tensors
+    for "cuda" ones, an engine that writes the oracle's streams).  The first run on an 8-GPU node must not be the
+    first run of this code."""
+    import json
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port),
+                        os.path.join(ROOT, "tests", "bench_stub.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--regions", "2", "--frames", "3", "--input", "noise", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                           # ONE line, from rank 0
+    d = json.loads(lines[0])
+    assert d["stub"] is True and d["value"] == 0.0                     # never mistaken for a measurement
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert d["bit_exact"] is True and "error" not in d
+    for key in ("metric", "unit", "ms_per_step", "higher_is_better", "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in d, key
+    assert d["with_gather"]["verified"] is True and d["with_gather"]["value"] > 0
+    assert d["with_local_sink"]["verified"] is True and d["with_local_sink"]["value"] > 0
+    c4 = d["c4_sharded_gathered"]
+    assert c4["bit_exact"] is True and c4["frames_per_rank"] == 32 and c4["gathered_bytes_per_step"] == 33508705
+    assert c4["encode_only"]["mpix_s"] > 0 and c4["with_gather"]["mpix_s"] > 0
+    m = d["multi_gpu_model"]
+    assert m["quote_beside_value"] == "with_local_sink" and m["rooted_gather_ceiling_per_peer_mpix_s"] > 0
+
+
 # ---- one frame over several ranks: exchange of band bit strings (SURVEY.md section 8e) -------------
 
 def _unstuffed_bits(oracle, img, quality, mode):
