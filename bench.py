@@ -872,6 +872,11 @@ def main():
                 g4k = [host[0]] if args.input == "struct" else [synth.g_struct(W, H, 7654321)]
                 oc["C2 4K G_struct q75 420 default parameters (method 4) x32"] = run_batch_config(
                     sj, torch, eng, g4k, 32, sj.YUV_420, 4, digests["struct4k|420|q75|m4"], latency_calls=500)
+                # SURVEY 8c's two other default-parameter known answers: C3 as a batch of four (cd6a30d5...), 4K noise (1eb32ac3...)
+                oc["C3 8K G_struct q90 444 default parameters (method 4) x4"] = run_batch_config(
+                    sj, torch, eng, c3, 4, sj.YUV_444, 4, digests["struct8k|444|q90|m4"], quality=90.0, reps=10)
+                oc["C2 4K G_noise q75 420 default parameters (method 4) x32"] = run_batch_config(
+                    sj, torch, eng, [synth.g_noise(W, H, 7654321)], 32, sj.YUV_420, 4, digests["noise4k|420|q75|m4"], reps=10)
                 c5q = np.array(digests["recompress|r90|m0"]["source_quant"], np.uint8).reshape(2, 64)
                 c5q = np.clip((c5q.astype(np.float64) * 100.0 / 90.0 + 0.5).astype(np.int64), 1, 255).astype(np.uint8)
                 oc["C5 4K recompress r=90 method 0 x32"] = run_batch_config(

@@ -146,16 +146,21 @@ constexpr int kSpec = 12;                                   // speculative batch
 constexpr int kPlaceLanes = 64;                             // one WAVE per segment, four segments per workgroup
 constexpr int kWideSpec = 3;                                // wide form: speculative batches of 256 words
 struct __attribute__((packed, aligned(4))) Words4 { uint32_t w[4]; };   // 16 bytes at any word address
-constexpr int kFusedSegs = 2048;                            // K2 inside K3: frames of up to 2048 segments
-template <bool FUSED>
+constexpr int kFusedSegs = 2048;                            // K2 inside K3: frames of up to 2048 segments (FUSED = 1)
+constexpr int kFusedSegsBig = 16384;                        // FUSED = 2, ONE large frame (8K 4:4:4 = 6172 segments): sums on demand
+template <int FUSED>
 __global__ __launch_bounds__(kThreads) void place_segments(const StitchArgs a) {
-  __shared__ unsigned long long off_lds[FUSED ? kFusedSegs + 1 : 1];
+  __shared__ uint32_t off_lds[FUSED == 1 ? kFusedSegs + 1 : 16];   // (32 bits: a fused frame has less than 2^32 bits of stream)
   __shared__ uint32_t scratch_k2[16];
   const int frame = blockIdx.y;
-  if (FUSED) {
+  const uint32_t* const nb_f = a.seg_nbits + static_cast<size_t>(frame) * a.nseg;
+  // FUSED = 2: the first segment this workgroup places; off_lds[0..7] = offsets of segments sc_first .. sc_first + 7,
+  // off_lds[8] = the frame's total
+  const int sc_first = static_cast<int>((blockIdx.x * (kThreads / 64)) / a.subs);
+  if (FUSED == 1) {
     // K2's scan, by every workgroup for itself (eight lengths per thread, one scan; the sums stay below 2^32: such a
     // frame has at most 8 MiB of stream); the loads go out with the speculative ones below
-    const uint32_t* const nb = a.seg_nbits + static_cast<size_t>(frame) * a.nseg;
+    const uint32_t* const nb = nb_f;
     constexpr int kRun = kFusedSegs / kThreads;
     const int i0 = static_cast<int>(threadIdx.x) * kRun;
     uint32_t v[kRun], mine = 0;
@@ -177,13 +182,53 @@ __global__ __launch_bounds__(kThreads) void place_segments(const StitchArgs a) {
     }
     __syncthreads();
   }
+  if (FUSED == 2) {
+    // One large frame: a workgroup needs the offsets of its own four segments, of the two behind them, and the total --
+    // not the frame's whole scan in LDS (6172 segments of an 8K 4:4:4 frame: K2 was a launch of ONE workgroup, 10 us
+    // between K1 and K3).  Every thread adds up a strided share of the lengths -- those in front of the workgroup's
+    // first segment, and all of them --, two workgroup sums, and eight threads finish the window.  Coalesced loads of
+    // an array that lies in the L2.
+    uint32_t front = 0, all = 0;
+    for (int i = threadIdx.x; i < a.nseg; i += kThreads) {
+      const uint32_t v = nb_f[i];
+      all += v;
+      front += i < sc_first ? v : 0u;
+    }
+    uint32_t front_total, all_total;
+    (void)wg_exclusive_scan<kThreads>(front, scratch_k2, &front_total);
+    (void)wg_exclusive_scan<kThreads>(all, scratch_k2, &all_total);
+    if (threadIdx.x < 8) {
+      uint32_t at = front_total;
+      for (int j = 0; j < static_cast<int>(threadIdx.x); ++j) at += sc_first + j < a.nseg ? nb_f[sc_first + j] : 0u;
+      off_lds[threadIdx.x] = at;
+    }
+    if (threadIdx.x == 8) {
+      off_lds[8] = all_total;
+      if (blockIdx.x == 0) {
+        a.seg_off[static_cast<size_t>(frame) * (a.nseg + 1) + a.nseg] = all_total;  // (K5 reads the total here)
+        if (a.frame_flags != nullptr && a.pool_ctr != nullptr) a.frame_flags[frame] = a.pool_ctr[2 * frame + 1];
+      }
+    }
+    __syncthreads();
+  }
   // a wave takes words [sub * kSpec * 64, ...) of one segment; normal segments have one wave
   // (subs == 1, the loop below takes the rare longer rest), whole bands are cut into many
   const uint32_t unit = blockIdx.x * (kThreads / kPlaceLanes) + (threadIdx.x >> 6);
   const int sc0 = static_cast<int>(unit / a.subs);
   const uint32_t ibase = (unit % a.subs) * (a.wide_subs ? kWideSpec * 256u : kSpec * kPlaceLanes);
   if (sc0 >= a.nseg) return;
-  const unsigned long long* off = FUSED ? off_lds : a.seg_off + static_cast<size_t>(frame) * (a.nseg + 1);
+  const unsigned long long* const off_g = a.seg_off + static_cast<size_t>(frame) * (a.nseg + 1);
+  auto off = [&](int i) -> unsigned long long {
+    if (FUSED == 1) return off_lds[i];
+    if (FUSED == 2) {
+      if (i >= a.nseg) return off_lds[8];
+      if (i - sc_first < 8) return off_lds[i - sc_first];
+      unsigned long long at = off_lds[7];          // (a word finished from segments further behind: short ones, rare)
+      for (int j = sc_first + 7; j < i; ++j) at += nb_f[j];
+      return at;
+    }
+    return off_g[i];
+  };
   const uint32_t* segw = a.seg_words + static_cast<size_t>(frame) * a.nseg * a.slot_words;
   const uint32_t* src = segw + static_cast<size_t>(sc0) * a.slot_words;
   // Two forms of the same loads.  WIDE (every ordinary call): a lane takes 4 consecutive words per batch
@@ -217,9 +262,9 @@ __global__ __launch_bounds__(kThreads) void place_segments(const StitchArgs a) {
   // behind it, and where that one ends (is it long enough to fill the word?)
   const bool has_next = sc0 + 1 < a.nseg;                   // uniform
   const uint32_t next_first = has_next ? src[a.slot_words] : 0u;
-  const unsigned long long b0 = off[sc0], b1 = off[sc0 + 1];
-  const unsigned long long b2 = off[has_next ? sc0 + 2 : sc0 + 1];
-  const unsigned long long T = off[a.nseg];                 // total bits
+  const unsigned long long b0 = off(sc0), b1 = off(sc0 + 1);
+  const unsigned long long b2 = off(has_next ? sc0 + 2 : sc0 + 1);
+  const unsigned long long T = off(a.nseg);                 // total bits
   const unsigned long long U = (T + 7) >> 3;                // bytes incl. 1-bit padding
   // a frame whose stream is longer than the scratch sized from out_stride cannot fit its output slot
   // either; one that overran its pool has words missing: K4 reports size 0 for both, nothing to place
@@ -260,7 +305,7 @@ __global__ __launch_bounds__(kThreads) void place_segments(const StitchArgs a) {
     int need = 32, sc = sc0;
     unsigned long long p = (wbeg + i) * 32, c_beg = b0, c_end = b1;
     while (need > 0 && p < T) {
-      while (p >= c_end) { ++sc; c_beg = c_end; c_end = off[sc + 1]; }
+      while (p >= c_end) { ++sc; c_beg = c_end; c_end = off(sc + 1); }
       const unsigned long long avail = c_end - p;
       const int take = avail < static_cast<unsigned long long>(need) ? static_cast<int>(avail) : need;
       const uint32_t rr = static_cast<uint32_t>(p - c_beg);
@@ -516,12 +561,15 @@ __global__ __launch_bounds__(kThreads) void pack_frame_edges(const StitchArgs a)
 // it has loaded itself (a fifth source word), so no two threads ever exchange anything.  94 % of the
 // threads hold no 0xFF byte (1 byte in 256 of an entropy-coded stream): four byte-aligns and two
 // ds_write2_b32 instead of the sixteen byte stores of the general path, which the others keep.
-constexpr uint32_t kFusedChunks = 2048;                     // K4 inside K5: frames of up to 8 MiB of un-stuffed stream
-template <bool FUSED>
+constexpr uint32_t kFusedChunks = 2048;                     // K4 inside K5: frames of up to 8 MiB of un-stuffed stream (FUSED = 1)
+constexpr uint32_t kFusedChunksBig = 1u << 17;              // FUSED = 2, ONE large frame of up to 512 MiB of stream: sums on demand
+template <int FUSED>
 __global__ __launch_bounds__(kThreads) void stuff_chunks(const StitchArgs a) {
+  constexpr uint32_t kCapChunks = FUSED == 2 ? kFusedChunksBig : kFusedChunks;
   __shared__ uint32_t scratch[16];
   __shared__ __attribute__((aligned(16))) uint8_t stage[2 * kChunkBytes + 64];
-  __shared__ uint32_t fused_off[FUSED ? kFusedChunks : 1];   // FUSED: 0xFF bytes in front of every chunk of the frame
+  __shared__ uint32_t fused_off[FUSED == 1 ? kFusedChunks : 1];   // FUSED = 1: 0xFF bytes in front of every chunk of the frame
+  uint32_t big_off = 0;                                      // FUSED = 2: 0xFF bytes in front of this workgroup's chunk at hand
   const int frame = blockIdx.y;
   const unsigned long long T = a.seg_off[static_cast<size_t>(frame) * (a.nseg + 1) + a.nseg];
   const unsigned long long U = (T + 7) >> 3;
@@ -530,26 +578,41 @@ __global__ __launch_bounds__(kThreads) void stuff_chunks(const StitchArgs a) {
   const unsigned long long* co = a.chunk_off + static_cast<size_t>(frame) * a.max_chunks;
   const uint32_t hoff = a.hdr_off ? a.hdr_off[frame] : 0u;
   const uint32_t hsize = a.hdr_off ? a.hdr_off[frame + 1] - hoff : a.header_size;
+  const uint32_t* const ff_f = a.chunk_ff + static_cast<size_t>(frame) * a.max_chunks;
   if (FUSED) {
     // K4's scan, by every workgroup for itself (the counts of at most 2048 chunks: eight per thread, one scan): no
     // launch between K3 and this kernel.  Workgroup 0 also reports the size and writes header and EOI.
-    const uint32_t* ff = a.chunk_ff + static_cast<size_t>(frame) * a.max_chunks;
+    const uint32_t* ff = ff_f;
     const uint32_t nch = nchunks < a.max_chunks ? nchunks : a.max_chunks;     // (more: the frame does not fit, below)
-    constexpr uint32_t kRun = kFusedChunks / kThreads;
-    const uint32_t i0 = threadIdx.x * kRun;
-    uint32_t v[kRun], mine = 0;
-#pragma unroll
-    for (uint32_t j = 0; j < kRun; ++j) {
-      v[j] = (i0 + j < nch) ? ff[i0 + j] : 0u;
-      mine += v[j];
-    }
     uint32_t total;
-    uint32_t at = wg_exclusive_scan<kThreads>(mine, scratch, &total);
+    if (FUSED == 1) {
+      constexpr uint32_t kRun = kFusedChunks / kThreads;
+      const uint32_t i0 = threadIdx.x * kRun;
+      uint32_t v[kRun], mine = 0;
 #pragma unroll
-    for (uint32_t j = 0; j < kRun; ++j) { fused_off[i0 + j] = at; at += v[j]; }
+      for (uint32_t j = 0; j < kRun; ++j) {
+        v[j] = (i0 + j < nch) ? ff[i0 + j] : 0u;
+        mine += v[j];
+      }
+      uint32_t at = wg_exclusive_scan<kThreads>(mine, scratch, &total);
+#pragma unroll
+      for (uint32_t j = 0; j < kRun; ++j) { fused_off[i0 + j] = at; at += v[j]; }
+    } else {
+      // one large frame (an 8K 4:4:4 q90 frame: 6204 chunks): the workgroup needs the count in front of ITS chunk and
+      // the total, not the whole scan in LDS -- strided loads of an array in the L2, two workgroup sums; the counts
+      // between this chunk and the workgroup's next one are added in the loop below
+      uint32_t front = 0, all = 0;
+      for (uint32_t i = threadIdx.x; i < nch; i += kThreads) {
+        const uint32_t v = ff[i];
+        all += v;
+        front += i < blockIdx.x ? v : 0u;
+      }
+      (void)wg_exclusive_scan<kThreads>(front, scratch, &big_off);
+      (void)wg_exclusive_scan<kThreads>(all, scratch, &total);
+    }
     const unsigned long long body = U + total;
     const unsigned long long size = hsize + body + (a.append_eoi ? 2 : 0);
-    const bool fits = nchunks <= kFusedChunks && size <= a.out_stride && ((U + 3) >> 2) + 1 <= a.ubuf_words && !frame_overran(a, frame);
+    const bool fits = nchunks <= kCapChunks && size <= a.out_stride && ((U + 3) >> 2) + 1 <= a.ubuf_words && !frame_overran(a, frame);
     if (blockIdx.x == 0) {
       if (threadIdx.x == 0) a.sizes[frame] = fits ? size : 0ull;
       if (a.fused_k2 && a.pool_ctr != nullptr && threadIdx.x == 0) {    // (K3, their last reader, is through)
@@ -578,7 +641,7 @@ __global__ __launch_bounds__(kThreads) void stuff_chunks(const StitchArgs a) {
     if (chunk >= nchunks) return;
     const unsigned long long w0 = static_cast<unsigned long long>(chunk) * kChunkWords + threadIdx.x * 4;
     const unsigned long long byte0 = w0 * 4;
-    *off = FUSED ? static_cast<unsigned long long>(fused_off[chunk]) : co[chunk];
+    *off = FUSED == 1 ? static_cast<unsigned long long>(fused_off[chunk]) : FUSED == 2 ? 0ull : co[chunk];
     if (byte0 < U) {
       *q = *reinterpret_cast<const uint4*>(ub + w0);
       *valid = (U - byte0 >= 16) ? 16 : static_cast<int>(U - byte0);
@@ -594,8 +657,14 @@ __global__ __launch_bounds__(kThreads) void stuff_chunks(const StitchArgs a) {
     const uint4 q = q_next;
     const uint32_t behind = behind_next;
     const int valid = valid_next;
-    const unsigned long long chunk_off = off_next;
+    const unsigned long long chunk_off = FUSED == 2 ? static_cast<unsigned long long>(big_off) : off_next;
     fetch(chunk + gridDim.x, &q_next, &behind_next, &valid_next, &off_next);
+    if (FUSED == 2 && chunk + gridDim.x < nchunks) {          // (uniform) the counts between this chunk and the next one
+      uint32_t mine = 0, step;
+      for (uint32_t i = chunk + threadIdx.x; i < chunk + gridDim.x; i += kThreads) mine += ff_f[i];
+      (void)wg_exclusive_scan<kThreads>(mine, scratch, &step);
+      big_off += step;
+    }
     const uint32_t w[4] = {q.x, q.y, q.z, q.w};
     uint32_t ffs = 0;
     if (valid == 16) {
