@@ -146,6 +146,7 @@ struct LocalRank {
 std::mutex g_local_mu;
 std::map<std::string, std::weak_ptr<LocalGroup>> g_local_groups;
 
+ncclResult_t local_destroy(ncclComm_t comm);
 LocalRank* local_join(const uint8_t* id, int rank, int world, std::string* why) {
   const std::string key(reinterpret_cast<const char*>(id), SJPEG_HIP_COMM_ID_BYTES);
   std::shared_ptr<LocalGroup> g;
@@ -169,7 +170,13 @@ LocalRank* local_join(const uint8_t* id, int rank, int world, std::string* why) 
     ++g->joined;
   }
   LocalRank* lr = new (std::nothrow) LocalRank;
-  if (lr == nullptr) { *why = "host allocation failed"; return nullptr; }
+  if (lr == nullptr) {                             // (the rank is free again: nothing of this call stays behind)
+    std::lock_guard<std::mutex> lk(g->mu);
+    g->taken[rank] = 0;
+    --g->joined;
+    *why = "host allocation failed";
+    return nullptr;
+  }
   lr->g = g; lr->key = key; lr->rank = rank;
   lr->ev_send.assign(world, nullptr); lr->ev_recv.assign(world, nullptr);
   bool ok = hipEventCreateWithFlags(&lr->ev_ready, hipEventDisableTiming) == hipSuccess &&
@@ -178,8 +185,15 @@ LocalRank* local_join(const uint8_t* id, int rank, int world, std::string* why) 
     ok = hipEventCreateWithFlags(&lr->ev_send[k], hipEventDisableTiming) == hipSuccess &&
          hipEventCreateWithFlags(&lr->ev_recv[k], hipEventDisableTiming) == hipSuccess;
   }
-  if (!ok) { *why = "hipEventCreate failed"; }
-  return lr;     // (a rank whose events could not be made still leaves through local_destroy)
+  if (!ok) {
+    // a communicator without its events must not be handed out (every gather would fail with an opaque HIP error
+    // while the peers wait out their 60 s -- ADVICE r05): the rank leaves the way it would through destroy
+    *why = "hipEventCreate failed";
+    (void)hipGetLastError();
+    (void)local_destroy(reinterpret_cast<ncclComm_t>(lr));
+    return nullptr;
+  }
+  return lr;
 }
 
 // every rank of the group has got here (false: timeout or a broken group)
@@ -316,12 +330,26 @@ ncclResult_t local_destroy(ncclComm_t comm) {
   if (me->ev_done) (void)hipEventDestroy(me->ev_done);
   for (hipEvent_t e : me->ev_send) if (e) (void)hipEventDestroy(e);
   for (hipEvent_t e : me->ev_recv) if (e) (void)hipEventDestroy(e);
+  bool last;
   {
     std::lock_guard<std::mutex> lk(me->g->mu);
     me->g->taken[me->rank] = 0;                  // (the rank may join again: a new communicator on the same id)
-    --me->g->joined;
+    last = --me->g->joined == 0;
+    // (a group everybody has left is whole again: ranks that re-join its id before the last shared_ptr is gone
+    // must not inherit the failure of the communicators that are destroyed)
+    if (last) {
+      me->g->broken = false; me->g->bar_n = 0;
+      for (auto& b : me->g->box) b.state = 0;
+    }
   }
+  const std::string key = me->key;
   delete me;                                     // the last rank's shared_ptr frees the group; the registry holds a weak one
+  {
+    // the registry forgets ids whose group is gone (128 bytes of key per id otherwise, for the life of the process)
+    std::lock_guard<std::mutex> lk(g_local_mu);
+    auto it = g_local_groups.find(key);
+    if (it != g_local_groups.end() && it->second.expired()) g_local_groups.erase(it);
+  }
   return ncclSuccess;
 }
 ncclResult_t local_count(const ncclComm_t comm, int* n) { *n = reinterpret_cast<const LocalRank*>(comm)->g->world; return ncclSuccess; }

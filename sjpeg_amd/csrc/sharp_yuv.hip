@@ -835,9 +835,17 @@ int sjpeg_hip_sharp_yuv(const sjpeg_hip_source* src, int width, int height, int 
   if (piped) {
     // A sweep spins on the counter of the sweep before it, another workgroup of the same launch: that only ends if
     // the producer is resident.  A launch therefore never has more workgroups than the device holds at once --
-    // chunks of 32 pictures = 128 workgroups of 1024 threads, one per CU on half the chip (the whole
+    // chunks of pictures, four workgroups of 1024 threads each, one per CU on at most half the chip (the whole
     // batch in one grid relied on dispatch order for batches beyond that) --; the chunks follow each other on the stream.
-    constexpr int kChunk = 32;
+    // (from the device's CU count, not a constant: a grid of (8, 4, pictures / 8) has four workgroups of 1024 threads
+    // per picture, one workgroup fills a CU's wave slots for this kernel -- a quarter of the CUs' worth of pictures per
+    // launch leaves every producer resident on any device, half the chip on MI355X as before: 256 / 8 = 32)
+    static const int kChunk = [] {
+      int dev = 0, cus = 0;
+      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) { (void)hipGetLastError(); cus = 0; }
+      const int c = (cus / 8) & ~7;               // whole groups of eight pictures (the grid's z dimension)
+      return c < 8 ? 8 : c > 32 ? 32 : c;
+    }();
     for (int f0 = 0; f0 < nframes; f0 += kChunk) {
       const int nf = nframes - f0 < kChunk ? nframes - f0 : kChunk;
       a.frame0 = f0;

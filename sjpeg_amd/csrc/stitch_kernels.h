@@ -46,8 +46,11 @@ struct StitchArgs {
   // K1 has cleared the frame's 0xFF counters): no K2 launch either -- K1, K3, K5
   int fused_k2;
 };
+// (frame_flags is written by K2 -- or by K3's first workgroup when K2 runs inside K3 -- from pool_ctr, and only when
+// BOTH are there: a call with flags but no pool has no overrun to report, and nothing wrote the flags -- ADVICE r05)
 __device__ __forceinline__ bool frame_overran(const StitchArgs& a, int frame) {
-  return a.frame_flags != nullptr ? a.frame_flags[frame] != 0u : (a.pool_ctr != nullptr && a.pool_ctr[2 * frame + 1] != 0u);
+  if (a.pool_ctr == nullptr) return false;
+  return a.frame_flags != nullptr ? a.frame_flags[frame] != 0u : a.pool_ctr[2 * frame + 1] != 0u;
 }
 
 __global__ __launch_bounds__(kThreads) void scan_seg_offsets(const StitchArgs a) {
