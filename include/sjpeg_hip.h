@@ -317,10 +317,12 @@ int sjpeg_hip_scan_symbol_stats_src(sjpeg_hip_engine* engine, const sjpeg_hip_so
  * `stream`).  quant = the two starting matrices (natural order, e.g. sjpeg_hip_quality_matrices),
  * min_quant NULL = ones, q_bias / qdelta_max_* as EncoderParam (0x78, 12, 1).  method 0..6 as
  * SjpegEncode (trellis methods: host API).  Output as sjpeg_hip_encode_scan_src (complete JPEGs,
- * EOI included).  A batch of 125 Mpixels or more (or 24 frames) is coded in two parts whose device passes
- * and host analysis overlap, on two more streams the ENGINE owns: make the engine early in the life of
- * the process -- a stream made late shares a hardware queue with an older one, the caller's as a rule,
- * and nothing overlaps (measured: 1.33 ms against 1.18 for 32 4K frames). */
+ * EOI included).  A batch of 90 Mpixels or more is coded as TWO JOBS -- halves of the batch, each a complete
+ * sequence of passes -- side by side: one on `stream`, one on a stream (and a child engine, with its own scratch)
+ * the ENGINE owns; the call's host thread drives both, and `stream` ends behind both (the usual asynchronous
+ * contract: outputs are complete when `stream` is).  The three passes have different bottlenecks, side by side they
+ * fill each other's gaps: 32 4K frames 1.12 -> 1.00 ms.  Make the engine early in the life of the
+ * process -- a stream made late shares a hardware queue with an older one, the caller's as a rule, and nothing overlaps. */
 int sjpeg_hip_encode_batch_src(sjpeg_hip_engine* engine, const sjpeg_hip_source* src,
                                int width, int height, int yuv_mode, int nframes,
                                const uint8_t quant[2][64], const uint8_t* min_quant /*[2][64]*/, int q_bias,

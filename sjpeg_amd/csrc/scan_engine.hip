@@ -173,6 +173,18 @@ struct sjpeg_hip_engine {
   // same --, not their priority -- the greatest made it 1.46).  Streams made when the engine is, early, keep queues of
   // their own (bisected in bench.py, round 5; profiles/HISTORY.md).
   hipStream_t batch_side = nullptr, batch_up = nullptr;
+  // LANES of the batch path (round 6): a large default-parameter batch is cut into jobs of about eight 4K frames, every
+  // job a complete histogram -> statistics -> encode sequence of its own, and the jobs run on up to four streams at once
+  // -- lane 0 is this engine on the caller's stream, lanes 1..3 are child engines (their own scratch) on streams the
+  // engine owns (batch_side, batch_up, batch_lane3: made WITH the engine, see above).  The three passes have different
+  // bottlenecks -- the histogram kind is latency-bound with the VALU 60 % busy, the statistics kind is the memory's, the
+  // replay kind the VALU's --: side by side they fill each other's gaps, one after the other (the two parts of round 5)
+  // they cannot.  Measured with independent calls from several host threads first (tools/two_stream_batch.py).
+  static constexpr int kLanes = 4;
+  sjpeg_hip_engine* lane[kLanes] = {nullptr, nullptr, nullptr, nullptr};   // [0] unused (this engine)
+  hipStream_t batch_lane3 = nullptr;
+  hipEvent_t lane_in = nullptr, lane_done[kLanes] = {nullptr, nullptr, nullptr, nullptr};
+  bool is_lane = false;                // a child engine: no streams or lanes of its own
   DevBuf<unsigned long long> seg_off, chunk_off, stamps;
   DevBuf<uint32_t> hdr_off;
   bool want_stamps = false;
@@ -607,8 +619,10 @@ int sjpeg_hip_engine_create(int device, sjpeg_hip_engine** engine) {
   e->device = device;
   if (prop.multiProcessorCount > 0) e->cu_count = prop.multiProcessorCount;
   if (hipStreamCreateWithFlags(&e->batch_side, hipStreamNonBlocking) != hipSuccess ||
-      hipStreamCreateWithFlags(&e->batch_up, hipStreamNonBlocking) != hipSuccess) {
+      hipStreamCreateWithFlags(&e->batch_up, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&e->batch_lane3, hipStreamNonBlocking) != hipSuccess) {
     if (e->batch_side) (void)hipStreamDestroy(e->batch_side);
+    if (e->batch_up) (void)hipStreamDestroy(e->batch_up);
     delete e;
     return fail(SJPEG_HIP_ERUNTIME, "hipStreamCreate failed");
   }
@@ -629,6 +643,12 @@ int sjpeg_hip_engine_create(int device, sjpeg_hip_engine** engine) {
 void sjpeg_hip_engine_destroy(sjpeg_hip_engine* e) {
   if (e == nullptr) return;
   (void)hipSetDevice(e->device);
+  if (!e->is_lane) {
+    for (hipStream_t bs : {e->batch_side, e->batch_up, e->batch_lane3}) if (bs) (void)hipStreamSynchronize(bs);   // (the lanes' work)
+    for (auto& l : e->lane) { if (l) sjpeg_hip_engine_destroy(l); l = nullptr; }
+    for (auto& ev : e->lane_done) if (ev) (void)hipEventDestroy(ev);
+    if (e->lane_in) (void)hipEventDestroy(e->lane_in);
+  }
   e->tables.release(); e->header.release(); e->seg_words.release(); e->seg_nbits.release(); e->pool.release(); e->pool_ctr.release(); e->seg_xbase.release(); e->replay.release();
   e->ubuf.release(); e->chunk_ff.release(); e->partial.release(); e->seg_off.release(); e->chunk_off.release(); e->hdr_off.release(); e->stamps.release();
   e->frame_flags.release();
@@ -640,7 +660,7 @@ void sjpeg_hip_engine_destroy(sjpeg_hip_engine* e) {
   }
   e->seg_words2.release(); e->seg_nbits2.release(); e->pool2.release(); e->pool_ctr2.release(); e->seg_xbase2.release();
   if (e->side) { (void)hipStreamSynchronize(e->side); (void)hipStreamDestroy(e->side); }
-  for (hipStream_t bs : {e->batch_side, e->batch_up}) if (bs) { (void)hipStreamSynchronize(bs); (void)hipStreamDestroy(bs); }
+  for (hipStream_t bs : {e->batch_side, e->batch_up, e->batch_lane3}) if (bs) { (void)hipStreamSynchronize(bs); (void)hipStreamDestroy(bs); }
   for (hipEvent_t ev : {e->k1_done, e->side_done, e->k3_done[0], e->k3_done[1], e->cross_ev}) if (ev) (void)hipEventDestroy(ev);
   delete e;
 }
@@ -650,6 +670,7 @@ int sjpeg_hip_engine_trim(sjpeg_hip_engine* e) {
   HIP_TRY(hipSetDevice(e->device));
   // the engine does not own the streams its calls ran on: wait for the whole device
   HIP_TRY(hipDeviceSynchronize());
+  for (auto& l : e->lane) { if (l != nullptr) { if (int rcl = sjpeg_hip_engine_trim(l)) return rcl; } }
   e->seg_words.release(); e->seg_nbits.release(); e->pool.release(); e->pool_ctr.release(); e->seg_xbase.release();
   e->seg_words2.release(); e->seg_nbits2.release(); e->pool2.release(); e->pool_ctr2.release(); e->seg_xbase2.release();
   e->ubuf.release(); e->chunk_ff.release(); e->partial.release(); e->replay.release();
@@ -754,7 +775,9 @@ float sjpeg_hip_engine_last_total_ms(sjpeg_hip_engine* e) { return elapsed(e, 0,
 size_t sjpeg_hip_engine_scratch_bytes(sjpeg_hip_engine* e) {
   if (e == nullptr) return 0;
   auto b = [](const auto& buf) { return buf.cap * sizeof(*buf.p); };
-  return b(e->tables) + b(e->header) + b(e->seg_words) + b(e->seg_nbits) + b(e->pool) + b(e->pool_ctr) + b(e->seg_xbase) +
+  size_t lanes = 0;
+  for (auto* l : e->lane) if (l != nullptr) lanes += sjpeg_hip_engine_scratch_bytes(l);
+  return lanes + b(e->tables) + b(e->header) + b(e->seg_words) + b(e->seg_nbits) + b(e->pool) + b(e->pool_ctr) + b(e->seg_xbase) +
          b(e->ubuf) + b(e->chunk_ff) + b(e->partial) + b(e->replay) + b(e->seg_off) + b(e->chunk_off) + b(e->stamps) +
          b(e->hdr_off) + b(e->seg_words2) + b(e->seg_nbits2) + b(e->pool2) + b(e->pool_ctr2) + b(e->seg_xbase2);
 }
@@ -1479,11 +1502,22 @@ struct BatchScratch {                 // per host thread: device scratch of sjpe
     if (pass_done) (void)hipEventDestroy(pass_done);
     if (call_begin) (void)hipEventDestroy(call_begin);
     pass_done = nullptr; call_begin = nullptr;
+    for (auto& e : job_ev) if (e) (void)hipEventDestroy(e);
+    job_ev.clear();
     d_hist = d_sums = d_freq = h_pinned = d_pinned = nullptr; hist_cap = sums_cap = freq_cap = pinned_cap = 0;
   }
   hipEvent_t ev[12] = {};                        // behind the read-backs of a part: sums [0..7] (two halves a part), counts [8..11]
   hipEvent_t pass_done = nullptr;
   hipEvent_t call_begin = nullptr;                 // on the call's stream before anything of the call: the early uploads wait for it
+  std::vector<hipEvent_t> job_ev;                  // one per job of a batch coded in lanes
+  bool EnsureJobEvents(size_t n) {
+    while (job_ev.size() < n) {
+      hipEvent_t e = nullptr;
+      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return false;
+      job_ev.push_back(e);
+    }
+    return true;
+  }
   bool EnsureEvents() {
     for (auto& e : ev) {
       if (e == nullptr && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { e = nullptr; return false; }
@@ -1587,6 +1621,169 @@ int sjpeg_hip_encode_batch_src(sjpeg_hip_engine* engine, const sjpeg_hip_source*
       }
       return s;
     };
+    // ---- LANES (round 6): jobs of about eight 4K frames, each a complete sequence of passes, on up to four streams at once
+    // (sjpeg_hip_engine::lane).  One host thread drives them: a job's next step is taken when the event behind its
+    // read-back has passed (polled -- the caller would block in hipEventSynchronize otherwise), whichever job that is.
+    static const int lanes_env = getenv("SJPEG_HIP_BATCH_LANES") ? atoi(getenv("SJPEG_HIP_BATCH_LANES")) : -1;   // (A/B: 0 = the two parts of round 5)
+    static const double job_px = getenv("SJPEG_HIP_BATCH_JOB_MPIX") ? atof(getenv("SJPEG_HIP_BATCH_JOB_MPIX")) * 1e6 : 66.4e6;
+    const double total_px = static_cast<double>(n) * width * height;
+    size_t njobs = static_cast<size_t>(total_px / job_px + 0.5);
+    if (getenv("SJPEG_HIP_BATCH_JOB_MPIX") == nullptr) njobs = total_px >= 90e6 ? 2 : 1;     // (the sweep: DESIGN.md section 4)
+    static const int njobs_env = getenv("SJPEG_HIP_BATCH_NJOBS") ? atoi(getenv("SJPEG_HIP_BATCH_NJOBS")) : 0;   // (experiments)
+    if (njobs_env > 0) njobs = static_cast<size_t>(njobs_env);
+    if (njobs > n) njobs = n;
+    if (njobs > 64) njobs = 64;
+    if (lanes_env != 0 && njobs >= 2 && (adaptive || optimize) && !engine->is_lane && parts_env == 0) {
+      const int nlanes = static_cast<int>(std::min<size_t>(njobs, lanes_env > 0 ? std::min(lanes_env, static_cast<int>(sjpeg_hip_engine::kLanes)) : sjpeg_hip_engine::kLanes));
+      hipStream_t lane_st[sjpeg_hip_engine::kLanes] = {st, engine->batch_side, engine->batch_up, engine->batch_lane3};
+      sjpeg_hip_engine* lane_e[sjpeg_hip_engine::kLanes] = {engine, nullptr, nullptr, nullptr};
+      for (int l = 1; l < nlanes; ++l) {
+        if (engine->lane[l] == nullptr) {
+          sjpeg_hip_engine* c = new (std::nothrow) sjpeg_hip_engine;
+          if (c == nullptr) return fail(SJPEG_HIP_ENOMEM, "host allocation failed");
+          c->device = engine->device; c->cu_count = engine->cu_count; c->histo_slots = engine->histo_slots;
+          c->scratch_limit = engine->scratch_limit; c->ablate = engine->ablate; c->is_lane = true;
+          engine->lane[l] = c;
+        }
+        if (engine->lane_done[l] == nullptr) HIP_TRY(hipEventCreateWithFlags(&engine->lane_done[l], hipEventDisableTiming));
+        lane_e[l] = engine->lane[l];
+      }
+      if (engine->lane_in == nullptr) HIP_TRY(hipEventCreateWithFlags(&engine->lane_in, hipEventDisableTiming));
+      if (!sc.EnsureJobEvents(njobs)) return fail(SJPEG_HIP_ENOMEM, "hipEventCreate(batch scratch) failed");
+      // the lanes' streams start behind everything the caller has put on its own (the pixels, the previous call)
+      if (int rco = order_on_stream(engine, st)) return rco;
+      HIP_TRY(hipEventRecord(engine->lane_in, st));
+      for (int l = 1; l < nlanes; ++l) HIP_TRY(hipStreamWaitEvent(lane_st[l], engine->lane_in, 0));
+      struct LanesGuard {                            // the child engines address whole calls again when this returns
+        sjpeg_hip_engine** e; int n;
+        ~LanesGuard() { for (int l = 1; l < n; ++l) if (e[l]) { e[l]->coefs_keep = e[l]->coefs_use = false; } }
+      } lanes_guard{lane_e, nlanes};
+      const bool keep_coefs = adaptive && optimize && getenv("SJPEG_HIP_NO_COEF_KEEP") == nullptr;
+      for (int l = 0; l < nlanes; ++l) lane_e[l]->coefs_keep = keep_coefs;
+      std::vector<sjpeg_hip_huffman_spec> jspecs(optimize ? n * 4 : 0);
+      struct Job { size_t f0, nf; int lane; int phase; };   // phase: 0 not started, 1 sums on their way, 2 counts on their way, 3 encode launched
+      std::vector<Job> jobs(njobs);
+      for (size_t j = 0; j < njobs; ++j) jobs[j] = Job{(n * j) / njobs, (n * (j + 1)) / njobs - (n * j) / njobs, static_cast<int>(j % static_cast<size_t>(nlanes)), 0};
+      const int ntab = yuv_mode == SJPEG_HIP_YUV400 ? 1 : 2;
+      // (the matrices every frame starts from: quant[] itself is adapted frame by frame while later jobs still start)
+      uint8_t q_start[2][64];
+      memcpy(q_start, &quant[0], sizeof(q_start));
+      auto read_back_on = [&](hipStream_t s2, void* h_dst, const void* d_src, size_t bytes) -> int {
+        void* const dv = sc.d_pinned == nullptr ? nullptr : static_cast<uint8_t*>(sc.d_pinned) + (static_cast<uint8_t*>(h_dst) - static_cast<uint8_t*>(sc.h_pinned));
+        return copy_by_kernel(dv, d_src, bytes, s2, hipMemcpyDeviceToHost, d_src, h_dst);
+      };
+      std::vector<uint8_t> jheaders;
+      std::vector<size_t> joffs;
+      // the three steps of a job; each ends with the launch of a pass (and of the read-back the next step waits for)
+      auto step_encode = [&](Job& jb) -> int {
+        sjpeg_hip_engine* const e = lane_e[jb.lane];
+        jheaders.clear();
+        joffs.assign(jb.nf + 1, 0);
+        uint8_t one[2048];
+        for (size_t f = jb.f0; f < jb.f0 + jb.nf; ++f) {
+          const size_t hs = sjpeg_hip_make_header_ex(width, height, yuv_mode, reinterpret_cast<const uint8_t(*)[64]>(&quant[f * 128]),
+                                                     optimize ? &jspecs[f * 4] : nullptr, one, sizeof(one));
+          if (hs == 0) return fail(SJPEG_HIP_EINVAL, "header generation failed");
+          jheaders.insert(jheaders.end(), one, one + hs);
+          joffs[f - jb.f0 + 1] = jheaders.size();
+        }
+        const sjpeg_hip_source ps = part_source(jb.f0);
+        const int rc = sjpeg_hip_encode_scan_multi(e, &ps, width, height, yuv_mode, static_cast<int>(jb.nf), &tables[jb.f0], jheaders.data(),
+                                                   joffs.data(), /*append_eoi=*/1, static_cast<uint8_t*>(d_out) + jb.f0 * out_stride,
+                                                   out_stride, d_sizes + jb.f0, lane_st[jb.lane]);
+        jb.phase = 3;
+        return rc;
+      };
+      auto step_stats = [&](Job& jb, size_t j) -> int {
+        if (!optimize) return step_encode(jb);
+        sjpeg_hip_engine* const e = lane_e[jb.lane];
+        for (size_t f = jb.f0; f < jb.f0 + jb.nf; ++f) tables[f].flags |= SJPEG_HIP_QUANT_KEEP;
+        e->coefs_use = e->coefs_keep;
+        const sjpeg_hip_source ps = part_source(jb.f0);
+        uint32_t* const d_freq = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(sc.d_freq) + jb.f0 * kFreq);
+        if (int rc = sjpeg_hip_scan_symbol_stats_multi(e, &ps, width, height, yuv_mode, static_cast<int>(jb.nf), &tables[jb.f0], d_freq, lane_st[jb.lane])) return rc;
+        if (int rc = read_back_on(lane_st[jb.lane], h_freq + jb.f0 * kFreq, d_freq, jb.nf * kFreq)) return rc;
+        HIP_TRY(hipEventRecord(sc.job_ev[j], lane_st[jb.lane]));
+        jb.phase = 2;
+        return 0;
+      };
+      auto step_start = [&](Job& jb, size_t j) -> int {
+        if (!adaptive) return step_stats(jb, j);
+        sjpeg_hip_engine* const e = lane_e[jb.lane];
+        hipStream_t const js = lane_st[jb.lane];
+        const sjpeg_hip_source ps = part_source(jb.f0);
+        uint32_t* const d_hist = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(sc.d_hist) + jb.f0 * kHist);
+        if (int rc = sjpeg_hip_scan_histogram_src(e, &ps, width, height, yuv_mode, static_cast<int>(jb.nf), d_hist, js)) return rc;
+        uint8_t* const d_grp = static_cast<uint8_t*>(sc.d_sums) + jb.f0 * (kSums + kTot);      // [nf][kSums] then [nf][kTot]
+        if (int rc = sjpeg_hip_adapt_sums(d_hist, static_cast<int>(jb.nf), q_start, min_quant,
+                                          reinterpret_cast<int64_t*>(d_grp), reinterpret_cast<int32_t*>(d_grp + jb.nf * kSums), js)) return rc;
+        uint8_t* const d_q = static_cast<uint8_t*>(sc.d_sums) + n * (kSums + kTot) + jb.f0 * 128;
+        if (int rc = adapt_decide(reinterpret_cast<const int64_t*>(d_grp), reinterpret_cast<const int32_t*>(d_grp + jb.nf * kSums), static_cast<int>(jb.nf),
+                                  q_start, ntab, qdelta_max_luma, qdelta_max_chroma, d_q, js)) return rc;
+        if (int rc = read_back_on(js, h_sums + jb.f0 * 128, d_q, jb.nf * 128)) return rc;
+        HIP_TRY(hipEventRecord(sc.job_ev[j], js));
+        jb.phase = 1;
+        return 0;
+      };
+      auto step_after = [&](Job& jb, size_t j) -> int {       // the event of phase 1 / 2 has passed
+        if (jb.phase == 1) {
+          for (size_t f = jb.f0; f < jb.f0 + jb.nf; ++f) {
+            memcpy(&quant[f * 128], h_sums + f * 128, static_cast<size_t>(ntab) * 64);
+            sjpeg_hip_finalize_quant(reinterpret_cast<uint8_t(*)[64]>(&quant[f * 128]), min_quant, q_bias, &tables[f]);
+          }
+          return step_stats(jb, j);
+        }
+        for (size_t f = jb.f0; f < jb.f0 + jb.nf; ++f) {
+          tables[f].flags = (tables[f].flags & ~SJPEG_HIP_QUANT_KEEP) | SJPEG_HIP_QUANT_REPLAY;
+          sjpeg_hip_optimize_huffman(reinterpret_cast<const uint32_t*>(h_freq + f * kFreq), yuv_mode, &jspecs[f * 4], &tables[f]);
+        }
+        return step_encode(jb);
+      };
+      size_t done = 0;
+      std::vector<size_t> lane_next(static_cast<size_t>(nlanes));      // the next job of a lane that has not started
+      for (int l = 0; l < nlanes; ++l) lane_next[static_cast<size_t>(l)] = static_cast<size_t>(l);
+      std::vector<long long> lane_busy(static_cast<size_t>(nlanes), -1);   // the job a lane is working on
+      int rc_lanes = 0;
+      while (done < njobs && rc_lanes == 0) {
+        bool moved = false;
+        for (int l = 0; l < nlanes && rc_lanes == 0; ++l) {
+          const size_t ls = static_cast<size_t>(l);
+          if (lane_busy[ls] < 0) {
+            // STAGGER: job j starts when job j - 1 has launched its statistics pass -- four histogram passes started
+            // together share the chip among themselves (each ran 320-400 us instead of 110) and the passes that
+            // complement them come later, all together again
+            static const int stagger = getenv("SJPEG_HIP_BATCH_STAGGER") ? atoi(getenv("SJPEG_HIP_BATCH_STAGGER")) : 0;
+            const bool held = stagger != 0 && lane_next[ls] < njobs && lane_next[ls] > 0 && jobs[lane_next[ls] - 1].phase < (stagger == 2 ? 3 : 2);
+            if (lane_next[ls] < njobs && !held) {      // (a lane's jobs follow each other: the engine's scratch is one job's)
+              lane_busy[ls] = static_cast<long long>(lane_next[ls]);
+              lane_next[ls] += static_cast<size_t>(nlanes);
+              rc_lanes = step_start(jobs[static_cast<size_t>(lane_busy[ls])], static_cast<size_t>(lane_busy[ls]));
+              moved = true;
+            }
+          } else {
+            const size_t j = static_cast<size_t>(lane_busy[ls]);
+            const hipError_t q = hipEventQuery(sc.job_ev[j]);
+            if (q == hipSuccess) {
+              rc_lanes = step_after(jobs[j], j);
+              moved = true;
+            } else if (q != hipErrorNotReady) {
+              (void)hipGetLastError();
+              rc_lanes = fail(SJPEG_HIP_ERUNTIME, std::string("hipEventQuery: ") + hipGetErrorString(q));
+            } else {
+              (void)hipGetLastError();
+            }
+          }
+          if (rc_lanes == 0 && lane_busy[ls] >= 0 && jobs[static_cast<size_t>(lane_busy[ls])].phase == 3) { lane_busy[ls] = -1; ++done; moved = true; }
+        }
+        if (!moved) __builtin_ia32_pause();
+      }
+      // the caller's stream ends behind every lane, failed call or not (what was launched reads the caller's buffers)
+      for (int l = 1; l < nlanes; ++l) {
+        if (hipEventRecord(engine->lane_done[l], lane_st[l]) == hipSuccess) (void)hipStreamWaitEvent(st, engine->lane_done[l], 0);
+        else (void)hipStreamSynchronize(lane_st[l]);
+      }
+      return rc_lanes;
+    }
     // (in parts: the sums of a part and their read-back go to the side stream, behind the pass that made
     // the partials, so that the next part's pass starts right behind this one's)
     hipStream_t rs = st;

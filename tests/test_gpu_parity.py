@@ -356,6 +356,22 @@ def test_back_to_back_batches_without_a_host_wait(engine, oracle):
             engine.set_pipelined(False)
 
 
+def test_batch_lanes_many_jobs():
+    """The lanes of the batch path (sjpeg_hip_encode_batch_src, round 6: jobs of a batch on up to four streams at once,
+    child engines, one polling host thread) with small pictures: a process of its own with the job size set to 0.02
+    Mpixels, so that a batch of 23 frames is many jobs, several per lane (tests/lanes_check.py); then once more with
+    the lanes off (the two parts of round 5), the same answers."""
+    import subprocess
+    import sys
+    for env_extra in ({"SJPEG_HIP_BATCH_JOB_MPIX": "0.02"}, {"SJPEG_HIP_BATCH_JOB_MPIX": "0.2", "SJPEG_HIP_BATCH_LANES": "3"},
+                      {"SJPEG_HIP_BATCH_LANES": "0"}):
+        env = dict(os.environ)
+        env.update(env_extra)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "lanes_check.py")], capture_output=True, text=True,
+                           timeout=600, env=env)
+        assert r.returncode == 0 and "lanes ok" in r.stdout, (env_extra, r.stdout[-500:], r.stderr[-2000:])
+
+
 def test_methods_batched_per_frame_tables(engine, oracle):
     """One launch per pass over a batch whose frames each get their own adapted quantizer,
     optimised Huffman codes and header (sjpeg_hip_*_multi): every frame equals the reference's

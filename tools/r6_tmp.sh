@@ -1,5 +1,3 @@
-python -m pytest tests -m gpu -x -q 2>&1 | grep -v "amdgpu.ids\|^RCCL\|^HIP ver\|^ROCm\|^Hostname\|^Librccl" | tail -4
-for rep in 1 2; do
-echo "fused big: $(python tools/profile_workload.py c3x1 30 2>&1 | grep c3x1:)"
-echo "no fused big: $(SJPEG_HIP_NO_FUSED_BIG=1 python tools/profile_workload.py c3x1 30 2>&1 | grep c3x1:)"
-done
+for sl in 384 512 640 768 1024; do for n in 16 32; do
+echo "slots $sl n $n  $(SJPEG_HIP_HISTO_SLOTS=$sl python tools/profile_workload.py m4n$n 30 2>&1 | grep "m4n$n:")"
+done; done
