@@ -176,7 +176,7 @@ struct sjpeg_hip_engine {
   // LANES of the batch path (round 6): a large default-parameter batch is cut into jobs of about eight 4K frames, every
   // job a complete histogram -> statistics -> encode sequence of its own, and the jobs run on up to four streams at once
   // -- lane 0 is this engine on the caller's stream, lanes 1..3 are child engines (their own scratch) on streams the
-  // engine owns (batch_side, batch_up, batch_lane3: made WITH the engine, see above).  The three passes have different
+  // engine owns (batch_side and batch_up, made WITH the engine, see above; the fourth on demand: two lanes are the default).  The three passes have different
   // bottlenecks -- the histogram kind is latency-bound with the VALU 60 % busy, the statistics kind is the memory's, the
   // replay kind the VALU's --: side by side they fill each other's gaps, one after the other (the two parts of round 5)
   // they cannot.  Measured with independent calls from several host threads first (tools/two_stream_batch.py).
@@ -618,11 +618,13 @@ int sjpeg_hip_engine_create(int device, sjpeg_hip_engine** engine) {
   if (e == nullptr) return fail(SJPEG_HIP_ENOMEM, "host allocation failed");
   e->device = device;
   if (prop.multiProcessorCount > 0) e->cu_count = prop.multiProcessorCount;
+  // (two streams, as in round 5, and not one more: the device has four hardware queues by default, and with a third
+  // engine-owned stream made here the stitch stream of the pipelined mode -- made later, by set_pipelined -- shared the
+  // caller's queue: the headline step went from 0.889 to 1.096 ms, K1 and the stitch one after the other.  The fourth
+  // lane of the batch path, an experiment knob, makes its stream when it is asked for.)
   if (hipStreamCreateWithFlags(&e->batch_side, hipStreamNonBlocking) != hipSuccess ||
-      hipStreamCreateWithFlags(&e->batch_up, hipStreamNonBlocking) != hipSuccess ||
-      hipStreamCreateWithFlags(&e->batch_lane3, hipStreamNonBlocking) != hipSuccess) {
+      hipStreamCreateWithFlags(&e->batch_up, hipStreamNonBlocking) != hipSuccess) {
     if (e->batch_side) (void)hipStreamDestroy(e->batch_side);
-    if (e->batch_up) (void)hipStreamDestroy(e->batch_up);
     delete e;
     return fail(SJPEG_HIP_ERUNTIME, "hipStreamCreate failed");
   }
@@ -1633,8 +1635,11 @@ int sjpeg_hip_encode_batch_src(sjpeg_hip_engine* engine, const sjpeg_hip_source*
     if (njobs_env > 0) njobs = static_cast<size_t>(njobs_env);
     if (njobs > n) njobs = n;
     if (njobs > 64) njobs = 64;
+    // (method 0 in lanes: 0.817 against 0.808 ms for 32 4K frames -- one K1 launch fills the chip by itself, and calls
+    // back to back overlap their stitch with the next K1 anyway)
     if (lanes_env != 0 && njobs >= 2 && (adaptive || optimize) && !engine->is_lane && parts_env == 0) {
       const int nlanes = static_cast<int>(std::min<size_t>(njobs, lanes_env > 0 ? std::min(lanes_env, static_cast<int>(sjpeg_hip_engine::kLanes)) : sjpeg_hip_engine::kLanes));
+      if (nlanes == 4 && engine->batch_lane3 == nullptr) HIP_TRY(hipStreamCreateWithFlags(&engine->batch_lane3, hipStreamNonBlocking));
       hipStream_t lane_st[sjpeg_hip_engine::kLanes] = {st, engine->batch_side, engine->batch_up, engine->batch_lane3};
       sjpeg_hip_engine* lane_e[sjpeg_hip_engine::kLanes] = {engine, nullptr, nullptr, nullptr};
       for (int l = 1; l < nlanes; ++l) {

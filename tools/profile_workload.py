@@ -78,6 +78,8 @@ elif cfg == "c5m0":
     step, px, sizes = plain([synth.g_struct(3840, 2160, 7654321)] * 16, 75.0, 1, quant=c5_quant())
 elif cfg == "c5m4":
     step, px, sizes = batch([synth.g_struct(3840, 2160, 7654321)] * 16, 1, 4, quant=c5_quant())
+elif cfg == "c5m0b32":                          # the batch entry with method 0 (what bench.py's C5 method-0 line calls)
+    step, px, sizes = batch([synth.g_struct(3840, 2160, 7654321)] * 32, 1, 0, quant=c5_quant())
 elif cfg == "c5m4x32":
     step, px, sizes = batch([synth.g_struct(3840, 2160, 7654321)] * 32, 1, 4, quant=c5_quant())
 else:

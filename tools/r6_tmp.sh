@@ -1,3 +1,4 @@
-for sl in 384 512 640 768 1024; do for n in 16 32; do
-echo "slots $sl n $n  $(SJPEG_HIP_HISTO_SLOTS=$sl python tools/profile_workload.py m4n$n 30 2>&1 | grep "m4n$n:")"
-done; done
+for rep in 1 2; do
+echo "m0 one launch  $(python tools/profile_workload.py c5m0b32 30 2>&1 | grep c5m0b32:)"
+echo "m0 two lanes   $(SJPEG_HIP_BATCH_LANES_M0=1 python tools/profile_workload.py c5m0b32 30 2>&1 | grep c5m0b32:)"
+done
