@@ -1744,6 +1744,11 @@ int sjpeg_hip_encode_batch_src(sjpeg_hip_engine* engine, const sjpeg_hip_source*
         }
         return step_encode(jb);
       };
+      static const bool lanes_debug = getenv("SJPEG_HIP_BATCH_DEBUG") != nullptr;    // (measurement aid: the host's timeline on stderr)
+      const auto t_lanes = std::chrono::steady_clock::now();
+      auto lmark = [&](const char* what, size_t j) {
+        if (lanes_debug) fprintf(stderr, "lanes %-22s job %zu  %8.1f us\n", what, j, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_lanes).count());
+      };
       size_t done = 0;
       std::vector<size_t> lane_next(static_cast<size_t>(nlanes));      // the next job of a lane that has not started
       for (int l = 0; l < nlanes; ++l) lane_next[static_cast<size_t>(l)] = static_cast<size_t>(l);
@@ -1763,13 +1768,16 @@ int sjpeg_hip_encode_batch_src(sjpeg_hip_engine* engine, const sjpeg_hip_source*
               lane_busy[ls] = static_cast<long long>(lane_next[ls]);
               lane_next[ls] += static_cast<size_t>(nlanes);
               rc_lanes = step_start(jobs[static_cast<size_t>(lane_busy[ls])], static_cast<size_t>(lane_busy[ls]));
+              lmark("started", static_cast<size_t>(lane_busy[ls]));
               moved = true;
             }
           } else {
             const size_t j = static_cast<size_t>(lane_busy[ls]);
             const hipError_t q = hipEventQuery(sc.job_ev[j]);
             if (q == hipSuccess) {
+              lmark(jobs[j].phase == 1 ? "sums here" : "counts here", j);
               rc_lanes = step_after(jobs[j], j);
+              lmark(jobs[j].phase == 2 ? "statistics launched" : "encode launched", j);
               moved = true;
             } else if (q != hipErrorNotReady) {
               (void)hipGetLastError();

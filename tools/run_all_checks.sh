@@ -9,6 +9,10 @@ N=1 run python tools/gpu_fuzz.py 1 240
 N=3 run python tools/low_entropy_fuzz.py 1 "${LOWENT:-120}"
 N=3 run python tools/extremes_fuzz.py 1 "${LOWENT:-120}"
 N=1 run python tools/batch_fuzz.py 1 "${LOWENT:-120}"
+# the same fuzz with the batch path's LANES forced onto these small pictures (round 6: jobs of 0.02 / 0.3 Mpixels on four / two lanes)
+N=1 run env SJPEG_HIP_BATCH_JOB_MPIX=0.02 python tools/batch_fuzz.py 2 "${LOWENT:-120}"
+N=1 run env SJPEG_HIP_BATCH_JOB_MPIX=0.3 SJPEG_HIP_BATCH_LANES=2 python tools/batch_fuzz.py 3 "${LOWENT:-120}"
+N=1 run python tests/lanes_check.py
 N=1 run python tools/gpu_soak.py 1 "${SOAK:-120}"
 N=1 run python tools/sharp_soak.py "${SOAK:-60}" 1
 N=1 run python tools/thread_soak.py 16 100
