@@ -28,9 +28,12 @@ these boxes the sysfs sclk lags and shows ~100 MHz, the measured figure is the o
 Rank 0 prints ONE JSON line.
 * `roofline` prices the dominant kernel (scan_segments) against the HBM read roofline with
   ALGORITHMIC bytes = 3 B/pixel; its duration is measured live with HIP
-  events on the launch stream (engine timing API) with strictly ordered kernels: `frac` is that
-  kernel ALONE; `frac_in_region` = the same bytes / `ms_per_step` / peak, i.e. the whole timed step
-  with the stitch kernels beside the dominant one -- the fraction `value` corresponds to.
+  events on the launch stream (engine timing API) IN THE MODE OF `value` -- pipelined, read once per
+  burst of eight back-to-back steps: `frac` / `kernel_ms` are that kernel with the previous step's
+  stitch kernels beside it, as in the timed regions (rocprofv3 of the timed regions agrees:
+  profiles/r06/timed_region_kernel_stats.csv); `frac_ordered` / `kernel_ms_ordered` are the kernel
+  ALONE on an otherwise idle chip (ordered calls, the host waits for every step); `frac_in_region` =
+  the same bytes / `ms_per_step` / peak, the whole timed step.
   `engine_scratch_bytes` is what the pipelined mode holds, `engine_scratch_bytes_ordered` what the
   ordered mode (`ms_per_step_ordered`) needs.  `roofline.valu` is the second roofline the
   kernel actually runs into: VALU instructions per wave (from the committed PMC pass named in
@@ -69,7 +72,7 @@ W, H, QUALITY = 3840, 2160, 75.0
 HBM_PEAK = 8.0e12          # B/s, MI355X HBM3E spec (MI355X_MICROARCH.md)
 N_SIMD, CLOCK_HZ = 256 * 4, 2.4e9
 # the PMC pass of this build the static figures (HBM traffic, VALU instructions per wave) come from
-PMC_SUMMARY = os.path.join("profiles", "r05", "final_pmc_summary.txt")
+PMC_SUMMARY = os.path.join("profiles", "r06", "final_pmc_summary.txt")
 
 
 def host_cpus():
