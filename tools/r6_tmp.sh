@@ -1,4 +1,2 @@
-for rep in 1 2; do
-echo "m0 one launch  $(python tools/profile_workload.py c5m0b32 30 2>&1 | grep c5m0b32:)"
-echo "m0 two lanes   $(SJPEG_HIP_BATCH_LANES_M0=1 python tools/profile_workload.py c5m0b32 30 2>&1 | grep c5m0b32:)"
-done
+python -m pytest tests -m gpu -x -q 2>&1 | grep -v "amdgpu.ids\|^RCCL\|^HIP ver\|^ROCm\|^Hostname\|^Librccl" | tail -3
+bash tools/lib_multi_ab.sh 3 tools/lib_k3old.bin -
