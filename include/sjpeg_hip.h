@@ -220,7 +220,8 @@ int sjpeg_hip_scan_quant_error_src(sjpeg_hip_engine* engine, const struct sjpeg_
 /* Number of entropy-coded bits (before byte stuffing and padding) of each frame of the most
  * recent sjpeg_hip_encode_scan*() call on this engine, copied to HOST memory `bits[nframes]`.
  * Synchronises the device.  With the coded size this gives what the reference's BitCounter
- * reports (src/bit_writer.h:292-365). */
+ * reports (src/bit_writer.h:292-365).  (Not defined behind sjpeg_hip_encode_batch_src, whose
+ * jobs may run on the engine's child engines.) */
 int sjpeg_hip_engine_entropy_bits(sjpeg_hip_engine* engine, uint64_t* bits, int nframes);
 
 /* ---- SJPEG_YUV_SHARP: the iterative sharp RGB -> YUV 4:2:0 conversion -----------------------------
@@ -240,10 +241,11 @@ int sjpeg_hip_sharp_yuv(const sjpeg_hip_source* src, int width, int height, int 
 /* ---- SJPEG_YUV_AUTO / SjpegRiskiness (src/jpeg_tools.cc:170-236) -------------------------------
  * The decision between 4:2:0 / sharp / 4:4:4 / 4:0:0 is made of three sums of a stencil over the
  * picture; the stencil looks pairs of 7x7x7 YUV cells up in a 343 x 343 byte table.  That table
- * is trained data of the reference (src/score_7.cc, `sjpeg::kSharpnessScore`) and is NOT part of
- * this library: install it once per process with sjpeg_hip_set_riskiness_table() (117649 bytes,
- * host memory; copied), or point the environment variable SJPEG_HIP_RISKINESS_TABLE at a file
- * holding those bytes.  Without it SJPEG_YUV_AUTO, SjpegCompress() and SjpegRiskiness() fail.
+ * is trained data of the reference (src/score_7.cc, `sjpeg::kSharpnessScore`): it ships beside the
+ * library as riskiness.bin (the reference's bytes, Apache-2.0: riskiness.NOTICE) and is found there;
+ * another copy goes in with sjpeg_hip_set_riskiness_table() (117649 bytes, host memory; copied) or
+ * through the environment variable SJPEG_HIP_RISKINESS_TABLE (a file holding those bytes).  A
+ * library installed without any: SJPEG_YUV_AUTO, SjpegCompress() and SjpegRiskiness() fail.
  * sjpeg_hip_riskiness_sums: device part; d_sums[nframes][3] = sum of the scores above the noise
  * level, their count, the count of neutral-chroma samples. */
 #define SJPEG_HIP_RISKINESS_TABLE_SIZE 117649

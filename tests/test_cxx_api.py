@@ -152,3 +152,23 @@ def test_cxx_out_of_the_box_auto_mode(tmp_path):
     run(exe2, str(tmp_path / "o3"), {"SJPEG_HIP_RISKINESS_TABLE": table})
     shutil.copy(table, libdir / "riskiness.bin")
     run(exe2, str(tmp_path / "o4"))
+
+
+@pytest.mark.gpu
+def test_cxx_batch_entry_against_the_host_api(tmp_path):
+    """sjpeg_hip_encode_batch_src from a plain C++ process (tests/cxx/batch_lanes_test.cc: hipMalloc'd frames, no torch):
+    every frame of every batch equals SjpegEncode's single-picture encode of it -- with the batch cut into one-frame jobs on
+    four lanes, into two lanes, into round 5's two parts, and by default.  (tools/san_engine.sh runs the same programme
+    against an engine compiled with AddressSanitizer: profiles/r06/san_engine.txt.)"""
+    exe = os.path.join(str(tmp_path), "batch_lanes_test")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"), "-I/opt/rocm/include",
+                           "-D__HIP_PLATFORM_AMD__", os.path.join(ROOT, "tests", "cxx", "batch_lanes_test.cc"), "-o", exe,
+                           "-L", sj.CSRC, "-lsjpeg_amd", "-L/opt/rocm/lib", "-lamdhip64",
+                           "-Wl,-rpath," + sj.CSRC, "-Wl,-rpath,/opt/rocm/lib"])
+    for extra in ({"SJPEG_HIP_BATCH_JOB_MPIX": "0.02"}, {"SJPEG_HIP_BATCH_JOB_MPIX": "0.3", "SJPEG_HIP_BATCH_LANES": "2"},
+                  {"SJPEG_HIP_BATCH_LANES": "0"}, {}):
+        env = dict(os.environ)
+        env["LD_LIBRARY_PATH"] = "/opt/rocm/lib:" + env.get("LD_LIBRARY_PATH", "")
+        env.update(extra)
+        r = subprocess.run([exe, "8"], capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0 and "mismatches: 0" in r.stdout, (extra, r.stdout[-500:], r.stderr[-1500:])
