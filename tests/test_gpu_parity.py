@@ -370,6 +370,16 @@ def test_batch_lanes_many_jobs():
         r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "lanes_check.py")], capture_output=True, text=True,
                            timeout=600, env=env)
         assert r.returncode == 0 and "lanes ok" in r.stdout, (env_extra, r.stdout[-500:], r.stderr[-2000:])
+    # ... and the batch tests of this file themselves, every one with jobs of 0.01 Mpixels on the lanes: the other source
+    # layouts (BGRA, RGBA, gray, planar, NV12 / NV21), per-frame tables, calls back to back, custom matrices with a floor
+    if os.environ.get("SJPEG_LANES_INNER") is None:
+        env = dict(os.environ)
+        env.update({"SJPEG_HIP_BATCH_JOB_MPIX": "0.01", "SJPEG_LANES_INNER": "1"})
+        r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-m", "gpu", "-x", "-q",
+                            "-k", "batch_entry_other_layouts or methods_batched_per_frame_tables or c5_recompress_default or "
+                                  "histogram_persistent or adaptive_decision"],
+                           capture_output=True, text=True, timeout=900, env=env)
+        assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
 
 
 def test_methods_batched_per_frame_tables(engine, oracle):
