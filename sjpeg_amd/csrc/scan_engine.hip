@@ -1759,9 +1759,10 @@ int sjpeg_hip_encode_batch_src(sjpeg_hip_engine* engine, const sjpeg_hip_source*
         for (int l = 0; l < nlanes && rc_lanes == 0; ++l) {
           const size_t ls = static_cast<size_t>(l);
           if (lane_busy[ls] < 0) {
-            // STAGGER: job j starts when job j - 1 has launched its statistics pass -- four histogram passes started
-            // together share the chip among themselves (each ran 320-400 us instead of 110) and the passes that
-            // complement them come later, all together again
+            // (SJPEG_HIP_BATCH_STAGGER=1, an experiment that lost: job j starts only when job j - 1 has launched its statistics
+            // pass, so that a histogram pass runs beside another KIND of pass instead of beside its twin -- 1.35 against 1.00 ms
+            // for 32 4K frames: the persistent histogram launch leaves the other kernel one workgroup per CU.  Default: all lanes
+            // start at once.)
             static const int stagger = getenv("SJPEG_HIP_BATCH_STAGGER") ? atoi(getenv("SJPEG_HIP_BATCH_STAGGER")) : 0;
             const bool held = stagger != 0 && lane_next[ls] < njobs && lane_next[ls] > 0 && jobs[lane_next[ls] - 1].phase < (stagger == 2 ? 3 : 2);
             if (lane_next[ls] < njobs && !held) {      // (a lane's jobs follow each other: the engine's scratch is one job's)
