@@ -873,6 +873,31 @@ def test_c3_8k_444_q90(engine, digests):
     assert len(got) == d["size"] and hashlib.md5(got).hexdigest() == d["md5"]
 
 
+@pytest.mark.parametrize("key,gen,w,h,q,mode,stride_mb", [
+    ("noise4k|444|q75|m0", "noise", 3840, 2160, 75.0, 3, 16),     # 10.3 MB of stream: 2 503 chunks, 791 x 3 / ... segments
+    ("noise4k|420|q75|m0", "noise", 3840, 2160, 75.0, 1, 12),     # 4.9 MB in a 12 MB slot: 3 072 chunks of room
+    ("struct8k|444|q90|m0", "struct", 7680, 4320, 90.0, 3, 64),   # 25.5 MB, 6 172 segments, 6 204 chunks
+    ("struct8k|444|q90|m0", "struct", 7680, 4320, 90.0, 3, 26),   # the same frame with 2 % of room behind it
+])
+def test_one_large_frame_sums_on_demand(engine, digests, key, gen, w, h, q, mode, stride_mb):
+    """ONE frame whose stream budget is beyond the scans-in-LDS of the small fused stitch (more than 2 048 chunks or
+    segments): K2 / K4 run inside K3 / K5 in their on-demand form (place_segments<2>, stuff_chunks<2>: every workgroup
+    adds up the lengths / 0xFF counts in front of its own, round 6) -- the reference's bytes for slots of several sizes
+    (/root/reference/src/bit_writer.h:172-209: flush granularity does not change the output)."""
+    img = (synth.g_struct if gen == "struct" else synth.g_noise)(w, h)
+    tables, quant = sj.make_tables(quality=q)
+    header = sj.make_header(w, h, mode, quant)
+    out, sizes = engine.encode_frames(dev(img), tables, header, mode, out_stride=stride_mb << 20)
+    torch.cuda.synchronize()
+    n = int(sizes[0].item())
+    d = digests[key]
+    assert n == d["size"] and hashlib.md5(bytes(out[0, :n].cpu().numpy())).hexdigest() == d["md5"], (key, stride_mb)
+    # a slot the stream does not fit: size 0 by contract, from the same kernels
+    out2, sizes2 = engine.encode_frames(dev(img), tables, header, mode, out_stride=((d["size"] * 3 // 4) + 4095) & ~4095)
+    torch.cuda.synchronize()
+    assert int(sizes2[0].item()) == 0
+
+
 def test_c4_batch_64x1080p(engine, digests):
     frames = torch.empty((64, 1080, 1920, 3), dtype=torch.uint8, device="cuda")
     for k in range(64):
