@@ -747,74 +747,101 @@ __global__ __launch_bounds__(kScanThreads, ((KINDX == kKindHisto && SRC == kSrcR
     }
     unsigned long long nzm = 0;
     if (emits) {
+      // One thread per block.  What the walk towards the sink reads of a node is ONE 16-byte record -- score, info
+      // (level | neg << 11 | pos << 12 | prev << 25), disto0 at its position -- asked for one candidate ahead: the three
+      // dependent private-memory reads per candidate of rounds 3-5 (info -> disto0[pos] -> score) were the kernel's time.
+      // The best entry point is kept as the nodes are made (the reference searches it backwards afterwards with a
+      // strict <: a later node wins a tie, and only a score below kMaxScore can win) -- for which disto0[63] is summed
+      // up front; the next position's coefficient and quantizer entry are asked for before this one's nodes are walked.
       constexpr int kNodes = 1 + 2 * 63;
-      uint32_t n_score[kNodes];
-      uint32_t n_info[kNodes];                     // level | neg << 11 | pos << 12 | rank << 18 | prev << 25
-      uint32_t disto0[64];
-      n_score[0] = 0; n_info[0] = 0;
-      disto0[0] = 0;
+      uint4 node[kNodes];
+      node[0] = make_uint4(0u, 0u, 0u, 0u);
+      uint4 newest = make_uint4(0u, 0u, 0u, 0u), second = newest;
+      uint32_t total = 0;                          // disto0[63] (32-bit arithmetic that may wrap, like the reference's)
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const uint4 w4 = *reinterpret_cast<const uint4*>(slot + 16 * r);
+        const uint32_t ws[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int lo = static_cast<int>(ws[u] << 16) >> 16, hi = static_cast<int>(ws[u]) >> 16;
+          if (r != 0 || u != 0) total += static_cast<uint32_t>(__mul24(lo, lo));
+          total += static_cast<uint32_t>(__mul24(hi, hi));
+        }
+      }
       int count = 1;                               // node 0 = the sink
+      int best = 0;
+      uint32_t best_sc = total;                    // (the sink's: nothing coded, everything distortion)
+      uint32_t dprev = 0;                          // disto0[i - 1]
       const uint32_t zrl_len = tl[0xf0];
+      int rv_n = raw[1];
+      int j_n = kZigTab[1];
+      uint4 t_n = qt[j_n >> 1];
       for (int i = 1; i < 64; ++i) {
-        const int j = kZigTab[i];
-        const uint4 t = qt[j >> 1];
+        const int rv = rv_n, j = j_n;
+        const uint4 t = t_n;
+        if (i < 63) { rv_n = raw[i + 1]; j_n = kZigTab[i + 1]; t_n = qt[j_n >> 1]; }
         const uint32_t iq = (j & 1) ? (t.x >> 16) : (t.x & 0xffffu);
         const uint32_t biq = (j & 1) ? t.z : t.y;
         const uint32_t qq = ((j & 1) ? (t.w >> 16) : (t.w & 0xffffu)) << 4;
         const uint32_t lambda = qq * qq / 32u;
-        const int rv = raw[i];
         const uint32_t neg = rv < 0 ? 1u : 0u;
         const int V = rv < 0 ? -rv : rv;
-        disto0[i] = static_cast<uint32_t>(V * V) + disto0[i - 1];
+        const uint32_t dhere = static_cast<uint32_t>(V * V) + dprev;
         int v = static_cast<int>((static_cast<uint32_t>(V) * iq + biq) >> 20);
-        if (v == 0) continue;
-        int nbits = 32 - __clz(v);
-        for (int kk = 0; kk < 2; ++kk) {
-          const int err = V - v * static_cast<int>(qq);
-          const int me = count;
-          uint32_t my_score = 0xffffffffu, my_prev = 0, my_rank = 0;
-          bool found = false;
-          const uint32_t base_disto = static_cast<uint32_t>(err * err) + disto0[i - 1];
-          for (int c = me - 1; c >= 0; --c) {
-            const uint32_t ci = n_info[c];
-            const int cpos = static_cast<int>((ci >> 12) & 63u);
-            const int run = i - 1 - cpos;
-            if (run < 0) continue;
-            uint32_t bits = static_cast<uint32_t>(nbits) + static_cast<uint32_t>(run >> 4) * zrl_len;
-            const uint32_t disto = base_disto - disto0[cpos];
-            if (disto + lambda * bits >= my_score) break;
-            bits += tl[((run & 15) << 4) | nbits];
-            const uint32_t score = disto + lambda * bits + n_score[c];
-            if (score < my_score) {
-              my_score = score; my_prev = static_cast<uint32_t>(c); my_rank = ((ci >> 18) & 127u) + 1u;
-              found = true;
+        if (v != 0) {
+          int nbits = 32 - __clz(v);
+          for (int kk = 0; kk < 2; ++kk) {
+            const int err = V - v * static_cast<int>(qq);
+            uint32_t my_score = 0xffffffffu, my_prev = 0;
+            bool found = false;
+            const uint32_t base_disto = static_cast<uint32_t>(err * err) + dprev;
+            // (the two newest nodes are in registers: the walk mostly ends there, and a node just stored would come
+            // back through the L2; the deeper ones are on their way while those two are priced)
+            uint4 ahead = node[count >= 3 ? count - 3 : 0];
+            auto price = [&](const uint4& cur, int c) -> bool {      // true: the walk stops at this node
+              const int run = i - 1 - static_cast<int>((cur.y >> 12) & 63u);
+              if (run < 0) return false;
+              uint32_t bits = static_cast<uint32_t>(nbits) + static_cast<uint32_t>(run >> 4) * zrl_len;
+              const uint32_t disto = base_disto - cur.z;
+              const uint32_t len = tl[((run & 15) << 4) | nbits];     // (asked for before the test it may not survive)
+              if (disto + lambda * bits >= my_score) return true;
+              bits += len;
+              const uint32_t score = disto + lambda * bits + cur.x;
+              if (score < my_score) { my_score = score; my_prev = static_cast<uint32_t>(c); found = true; }
+              return false;
+            };
+            bool stop = price(newest, count - 1);
+            if (!stop && count >= 2) stop = price(second, count - 2);
+            if (!stop) {
+              for (int c = count - 3; c >= 0; --c) {
+                const uint4 cur = ahead;
+                if (c > 0) ahead = node[c - 1];
+                if (price(cur, c)) break;
+              }
             }
+            if (found) {
+              second = newest;
+              newest = make_uint4(my_score, static_cast<uint32_t>(v) | (neg << 11) | (static_cast<uint32_t>(i) << 12) | (my_prev << 25), dhere, 0u);
+              node[count] = newest;
+              const uint32_t sc = my_score + (total - dhere);
+              if (sc <= best_sc && sc != 0xffffffffu) { best = count; best_sc = sc; }
+              ++count;
+            }
+            --nbits;
+            if (nbits <= 0) break;
+            v = (1 << nbits) - 1;
           }
-          if (found) {
-            n_score[me] = my_score;
-            n_info[me] = static_cast<uint32_t>(v) | (neg << 11) | (static_cast<uint32_t>(i) << 12) | (my_rank << 18) | (my_prev << 25);
-            ++count;
-          }
-          --nbits;
-          if (nbits <= 0) break;
-          v = (1 << nbits) - 1;
         }
-      }
-      // best entry point, searched backwards (the EOB cost is the same for all but position 63)
-      int best = 0;
-      if (count > 1) {
-        uint32_t best_score = 0xffffffffu;
-        for (int c = count - 1; c >= 0; --c) {
-          const uint32_t sc = n_score[c] + (disto0[63] - disto0[(n_info[c] >> 12) & 63u]);
-          if (sc < best_score) { best = c; best_score = sc; }
-        }
+        dprev = dhere;
       }
       // the slot becomes the usual sign-magnitude entries: zeros but for the chosen chain
 #pragma unroll
       for (int r = 0; r < 8; ++r) *reinterpret_cast<uint4*>(slot + 16 * r) = make_uint4(0, 0, 0, 0);
       u16_alias2* const zzw = reinterpret_cast<u16_alias2*>(slot);
-      for (int c = best; c > 0; c = static_cast<int>(n_info[c] >> 25)) {
-        const uint32_t ci = n_info[c];
+      for (int c = best; c > 0;) {
+        const uint32_t ci = node[c].y;
+        c = static_cast<int>(ci >> 25);
         const uint32_t pos = (ci >> 12) & 63u;
         zzw[pos] = static_cast<uint16_t>((ci & 0x7ffu) | (((ci >> 11) & 1u) << 15));
         nzm |= 1ull << pos;
