@@ -107,6 +107,7 @@ template <> struct Lds<false> {
   static constexpr int kOffQ = kOffWin;                          // uint4[64]
   static constexpr int kOffDc = kOffWin + 1024;                  // uint32[24] + safe masks [2] + EOB / ZRL words [4]
   static constexpr int kOffTlen = kOffWin + 1152;                // uint8[2][256], trellis kinds only
+  static constexpr int kOffTq = kOffWin + 1664;                  // uint2[2][64], trellis kinds only: the quantizer in ZIG-ZAG order
   // Entropy-phase bookkeeping inside the (still idle) bit window.  All of it lies behind the tables staged at
   // the front of the window (quantizer 0..1023, DC codes ..1151, trellis lengths ..1663 bytes): the DC codes are
   // still being read by slow waves when fast ones already write the part list -- no barrier between the two.
@@ -121,7 +122,7 @@ template <> struct Lds<false> {
   static constexpr int kLdsBytes = kOffMisc + 64;                // 48592: three workgroups per CU
   // kKindStats only: the symbol counters u32[2][256 AC + 16 DC], in TWO copies picked by lane parity, behind everything
   static constexpr int kOffStats = kLdsBytes, kStatsCopies = 2;
-  static_assert(kOffHist >= kOffTlen + 512 && kOffList >= kOffHist + 128 && kOffDcw >= kOffList + 2048 &&
+  static_assert(kOffTq >= kOffTlen + 512 && kOffHist >= kOffTq + 1024 && kOffList >= kOffHist + 128 && kOffDcw >= kOffList + 2048 &&
                 kOffDcw + 4 * kScanThreads <= kOffWin + kWinWords * 4, "bookkeeping behind the tables, inside the window");
 };
 template <> struct Lds<true> {
@@ -134,7 +135,7 @@ template <> struct Lds<true> {
   static constexpr int kListBytes = 1968;
   static constexpr int kOffHist = kOffWin + 1968;                // u32 [20]
   static constexpr int kOffDc = kOffWin + 2048;                  // uint32[24] + safe masks [2] + EOB / ZRL words [4]
-  static constexpr int kOffTlen = -1, kOffAc = -1;               // (no trellis kind, no raw AC table in this layout)
+  static constexpr int kOffTlen = -1, kOffAc = -1, kOffTq = -1;  // (no trellis kind, no raw AC table in this layout)
   static constexpr int kOffAcm = kOffWin + 2176;
   // kKindStats (which has no merged code words, DC code words, ZRL patterns or window): ONE copy of the counters
   static constexpr int kOffStats = kOffAcm, kStatsCopies = 1;

@@ -169,7 +169,15 @@ __global__ __launch_bounds__(kScanThreads, ((KINDX == kKindHisto && SRC == kSrcR
     } else {
       if (tid < kTablesB16) reinterpret_cast<uint4*>(smem + L::kOffAc)[tid] = t16[kTablesA16 + tid];
       if (tid < kTablesA16) reinterpret_cast<uint4*>(smem + L::kOffQ)[tid] = t16[tid];
-      if (TRELLIS && tid < 128) reinterpret_cast<uint32_t*>(smem + L::kOffTlen)[tid] = reinterpret_cast<const uint32_t*>(&t->tlen[0][0])[tid];
+      if (TRELLIS && tid < 128) {
+        reinterpret_cast<uint32_t*>(smem + L::kOffTlen)[tid] = reinterpret_cast<const uint32_t*>(&t->tlen[0][0])[tid];
+        // the trellis walks the positions of a block in a run-time loop: its quantizer entry -- reciprocal | step << 16,
+        // bias -- in zig-zag order (looked up through kZigTab per position, a global load sat in front of every one)
+        const int zj = kZigTab[tid & 63];
+        const uint4 q4 = t16[(tid >> 6) * 32 + (zj >> 1)];
+        reinterpret_cast<uint2*>(smem + L::kOffTq)[tid] = (zj & 1) ? make_uint2((q4.x >> 16) | (q4.w & 0xffff0000u), q4.z)
+                                                                  : make_uint2((q4.x & 0xffffu) | (q4.w << 16), q4.y);
+      }
     }
     // bookkeeping of the entropy phase that nothing touches until then: the sort's bins, the group queue
     if (KIND == kKindEncode || KIND == kKindStats) {
@@ -756,7 +764,13 @@ __global__ __launch_bounds__(kScanThreads, ((KINDX == kKindHisto && SRC == kSrcR
       constexpr int kNodes = 1 + 2 * 63;
       uint4 node[kNodes];
       node[0] = make_uint4(0u, 0u, 0u, 0u);
-      uint4 newest = make_uint4(0u, 0u, 0u, 0u), second = newest;
+#ifndef SJPEG_TRELLIS_RING
+#define SJPEG_TRELLIS_RING 8
+#endif
+      constexpr int kRing = SJPEG_TRELLIS_RING;
+      uint4 ring[kRing];                           // [0] = the newest node
+#pragma unroll
+      for (int r = 0; r < kRing; ++r) ring[r] = make_uint4(0u, 0u, 0u, 0u);
       uint32_t total = 0;                          // disto0[63] (32-bit arithmetic that may wrap, like the reference's)
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
@@ -774,56 +788,67 @@ __global__ __launch_bounds__(kScanThreads, ((KINDX == kKindHisto && SRC == kSrcR
       uint32_t best_sc = total;                    // (the sink's: nothing coded, everything distortion)
       uint32_t dprev = 0;                          // disto0[i - 1]
       const uint32_t zrl_len = tl[0xf0];
+      const uint2* const tq = reinterpret_cast<const uint2*>(smem + L::kOffTq) + tbl * 64;
       int rv_n = raw[1];
-      int j_n = kZigTab[1];
-      uint4 t_n = qt[j_n >> 1];
+      uint2 t_n = tq[1];
       for (int i = 1; i < 64; ++i) {
-        const int rv = rv_n, j = j_n;
-        const uint4 t = t_n;
-        if (i < 63) { rv_n = raw[i + 1]; j_n = kZigTab[i + 1]; t_n = qt[j_n >> 1]; }
-        const uint32_t iq = (j & 1) ? (t.x >> 16) : (t.x & 0xffffu);
-        const uint32_t biq = (j & 1) ? t.z : t.y;
-        const uint32_t qq = ((j & 1) ? (t.w >> 16) : (t.w & 0xffffu)) << 4;
-        const uint32_t lambda = qq * qq / 32u;
+        const int rv = rv_n;
+        const uint2 t = t_n;
+        if (i < 63) { rv_n = raw[i + 1]; t_n = tq[i + 1]; }
+        const uint32_t iq = t.x & 0xffffu, biq = t.y, qq = (t.x >> 16) << 4;
+        const uint32_t lambda = __umul24(qq, qq) / 32u;              // (every product here has factors below 2^24: full-rate multiplies)
         const uint32_t neg = rv < 0 ? 1u : 0u;
         const int V = rv < 0 ? -rv : rv;
-        const uint32_t dhere = static_cast<uint32_t>(V * V) + dprev;
-        int v = static_cast<int>((static_cast<uint32_t>(V) * iq + biq) >> 20);
+        const uint32_t dhere = static_cast<uint32_t>(__mul24(V, V)) + dprev;
+        int v = static_cast<int>((__umul24(static_cast<uint32_t>(V), iq) + biq) >> 20);
         if (v != 0) {
           int nbits = 32 - __clz(v);
           for (int kk = 0; kk < 2; ++kk) {
-            const int err = V - v * static_cast<int>(qq);
+            const int err = V - __mul24(v, static_cast<int>(qq));
             uint32_t my_score = 0xffffffffu, my_prev = 0;
             bool found = false;
-            const uint32_t base_disto = static_cast<uint32_t>(err * err) + dprev;
-            // (the two newest nodes are in registers: the walk mostly ends there, and a node just stored would come
-            // back through the L2; the deeper ones are on their way while those two are priced)
-            uint4 ahead = node[count >= 3 ? count - 3 : 0];
+            const uint32_t base_disto = static_cast<uint32_t>(__mul24(err, err)) + dprev;
+            // (the newest nodes are in registers: the walk mostly ends there, and every private-memory read is a trip
+            // to HBM -- three workgroups' node arrays are no L2's size -- that a wave waits ~1 000 cycles for)
             auto price = [&](const uint4& cur, int c) -> bool {      // true: the walk stops at this node
               const int run = i - 1 - static_cast<int>((cur.y >> 12) & 63u);
               if (run < 0) return false;
-              uint32_t bits = static_cast<uint32_t>(nbits) + static_cast<uint32_t>(run >> 4) * zrl_len;
+              uint32_t bits = static_cast<uint32_t>(nbits) + __umul24(static_cast<uint32_t>(run >> 4), zrl_len);
               const uint32_t disto = base_disto - cur.z;
               const uint32_t len = tl[((run & 15) << 4) | nbits];     // (asked for before the test it may not survive)
-              if (disto + lambda * bits >= my_score) return true;
+              if (disto + __umul24(lambda, bits) >= my_score) return true;
               bits += len;
-              const uint32_t score = disto + lambda * bits + cur.x;
+              const uint32_t score = disto + __umul24(lambda, bits) + cur.x;
               if (score < my_score) { my_score = score; my_prev = static_cast<uint32_t>(c); found = true; }
               return false;
             };
-            bool stop = price(newest, count - 1);
-            if (!stop && count >= 2) stop = price(second, count - 2);
-            if (!stop) {
-              for (int c = count - 3; c >= 0; --c) {
-                const uint4 cur = ahead;
-                if (c > 0) ahead = node[c - 1];
-                if (price(cur, c)) break;
+            bool stop = false;
+#pragma unroll
+            for (int r = 0; r < kRing; ++r) {
+              if (!stop && count - 1 - r >= 0) stop = price(ring[r], count - 1 - r);
+            }
+            if (!stop && count > kRing) {
+              // the older nodes: four records in flight (some lane of the wave walks deep at most nodes, and the trips
+              // to private memory are independent of each other -- a record asked for only one ahead left ~900 of its
+              // ~1 000 cycles in the open at every step)
+              int c = count - 1 - kRing;
+              uint4 f0 = node[c], f1 = node[max(c - 1, 0)], f2 = node[max(c - 2, 0)], f3 = node[max(c - 3, 0)];
+              for (;;) {
+                if (price(f0, c) || c == 0) break;
+                --c; f0 = node[max(c - 3, 0)];
+                if (price(f1, c) || c == 0) break;
+                --c; f1 = node[max(c - 3, 0)];
+                if (price(f2, c) || c == 0) break;
+                --c; f2 = node[max(c - 3, 0)];
+                if (price(f3, c) || c == 0) break;
+                --c; f3 = node[max(c - 3, 0)];
               }
             }
             if (found) {
-              second = newest;
-              newest = make_uint4(my_score, static_cast<uint32_t>(v) | (neg << 11) | (static_cast<uint32_t>(i) << 12) | (my_prev << 25), dhere, 0u);
-              node[count] = newest;
+#pragma unroll
+              for (int r = kRing - 1; r > 0; --r) ring[r] = ring[r - 1];
+              ring[0] = make_uint4(my_score, static_cast<uint32_t>(v) | (neg << 11) | (static_cast<uint32_t>(i) << 12) | (my_prev << 25), dhere, 0u);
+              node[count] = ring[0];
               const uint32_t sc = my_score + (total - dhere);
               if (sc <= best_sc && sc != 0xffffffffu) { best = count; best_sc = sc; }
               ++count;

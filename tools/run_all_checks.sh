@@ -8,6 +8,7 @@ N=2 run python -m pytest tests -m gpu -x -q
 N=1 run python tools/gpu_fuzz.py 1 240
 N=3 run python tools/low_entropy_fuzz.py 1 "${LOWENT:-120}"
 N=3 run python tools/extremes_fuzz.py 1 "${LOWENT:-120}"
+N=1 run python tools/trellis_fuzz.py "${TRELLIS:-300}"
 N=1 run python tools/batch_fuzz.py 1 "${LOWENT:-120}"
 # the same fuzz with the batch path's LANES forced onto these small pictures (round 6: jobs of 0.02 / 0.3 Mpixels on four / two lanes)
 N=1 run env SJPEG_HIP_BATCH_JOB_MPIX=0.02 python tools/batch_fuzz.py 2 "${LOWENT:-120}"
