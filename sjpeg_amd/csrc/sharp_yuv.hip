@@ -53,6 +53,7 @@ struct SharpArgs {
   // t % 3 and writes plane (t + 1) % 3; ctrl[f][32]: progress[4] (row pairs done), done[4], sum[4] (two words
   // each), cancel, final sweep.  nplanes == 1: the in-place kernels, everything in plane 0.
   uint32_t* ctrl;
+  int ctrl_words;                                 // per picture: 32, or 32 + 4 * strips (sharp_sweeps_strips: progress[4][strips] behind the 32)
   int nframes, nplanes;
   int frame0;                                     // sharp_sweeps_piped: first frame of this launch (batches go in chunks)
   uint8_t* y; uint8_t* u; uint8_t* v;
@@ -458,7 +459,7 @@ __global__ __launch_bounds__(kSweepThreads) void sharp_sweeps_piped(const SharpA
   int16_t* const out_uv = a.best_uv + (static_cast<size_t>(pout) * a.nframes + frame) * usz;
   const uint16_t* const target_y = a.target_y + static_cast<size_t>(frame) * ysz;
   const int16_t* const target_uv = a.target_uv + static_cast<size_t>(frame) * usz;
-  uint32_t* const ctrl = a.ctrl + static_cast<size_t>(frame) * 32;
+  uint32_t* const ctrl = a.ctrl + static_cast<size_t>(frame) * a.ctrl_words;
   const unsigned long long threshold = static_cast<unsigned long long>(3.0 * w * h);
 
   struct RowData {                                  // what one row pair needs from global memory, per column
@@ -668,13 +669,260 @@ __global__ __launch_bounds__(kSweepThreads) void sharp_sweeps_piped(const SharpA
   }
 }
 
+// ---- the pipelined sweeps ACROSS THE WIDTH as well (round 6).  A row pair of a sweep was one workgroup's: sixteen waves
+// on ONE CU, ~300 instructions and 26 gamma-table lookups a column -- a step's time was that CU's issue rate and grew
+// with the width (1080p 2.9 us, 4K 6.1 us a row pair, x 540 / x 1080 row pairs).  The columns of a row pair do not
+// depend on each other; what a column needs that is NEW in this sweep is the row above at columns c - 1 .. c + 1.  So a
+// sweep is cut into STRIPS of kStripOwn chroma columns, a workgroup of kStripThreads each, which carries kStripHalo more
+// columns on either side: it computes them as well (they are the neighbour strip's, computed there too -- the same
+// integers from the same inputs), and each row pair one more column from either edge has no valid row above any
+// more.  After kStripHalo row pairs what is left valid is exactly the strip's own columns: there, and only there, the strips
+// of a sweep meet -- every strip has published its rows (the counter of the hand-over to the next sweep), waits for its two
+// neighbours' counters and takes the halo's row above from their output.  Everything else a column reads is the sweep
+// before's plane, whose strips s - 1 .. s + 1 are waited for as the one workgroup was.  The exit test (:660-666) is the
+// last strip's of a sweep to arrive: the strips add their sums of |dW| up in the control block.
+// ctrl[f][32 + 4 * strips]: arrivals[4], done[4], sum[4] (two words each), cancel, final sweep, stamps[8]; progress[4][strips] at 32.
+// Grid (strips, 4, pictures of the chunk): a workgroup only ever waits for workgroups of a smaller linear index or
+// for its neighbour strips, which are dispatched next to it; a launch holds no more workgroups than are resident at once.
+constexpr int kStripThreads = 256, kStripHalo = 32, kStripOwn = kStripThreads - 2 * kStripHalo;
+__global__ __launch_bounds__(kStripThreads) void sharp_sweeps_strips(const SharpArgs a) {
+  __shared__ uint32_t g2l[kMaxY + 1];
+  __shared__ uint32_t l2g[kGammaTab + 2];
+  __shared__ unsigned long long red[kStripThreads / 64];
+  __shared__ int go;
+  __shared__ int16_t above[2][3][kStripThreads];    // the updated row above, ping-pong
+  const int strip = blockIdx.x, nstrips = gridDim.x, t = blockIdx.y, tid = threadIdx.x;
+  const int frame = a.frame0 + blockIdx.z;
+  for (int i = tid; i <= kMaxY; i += kStripThreads) g2l[i] = a.tab->g2l[i];
+  if (tid < kGammaTab + 2) l2g[tid] = a.tab->l2g[tid];
+  const int w = a.w, h = a.h, uv_w = a.uv_w, uv_h = a.uv_h;
+  const size_t ysz = static_cast<size_t>(w) * h, usz = static_cast<size_t>(uv_h) * 3 * uv_w;
+  const int pin = t % 3, pout = (t + 1) % 3;
+  const uint16_t* const in_y = a.best_y + (static_cast<size_t>(pin) * a.nframes + frame) * ysz;
+  uint16_t* const out_y = a.best_y + (static_cast<size_t>(pout) * a.nframes + frame) * ysz;
+  const int16_t* const in_uv = a.best_uv + (static_cast<size_t>(pin) * a.nframes + frame) * usz;
+  int16_t* const out_uv = a.best_uv + (static_cast<size_t>(pout) * a.nframes + frame) * usz;
+  const uint16_t* const target_y = a.target_y + static_cast<size_t>(frame) * ysz;
+  const int16_t* const target_uv = a.target_uv + static_cast<size_t>(frame) * usz;
+  uint32_t* const ctrl = a.ctrl + static_cast<size_t>(frame) * a.ctrl_words;
+  uint32_t* const progress = ctrl + 32;             // [4][nstrips]
+  const unsigned long long threshold = static_cast<unsigned long long>(3.0 * w * h);
+  const int own0 = strip * kStripOwn, own1 = own0 + kStripOwn < uv_w ? own0 + kStripOwn : uv_w;
+  const int c = own0 - kStripHalo + tid;            // this thread's chroma column
+  const bool live = c >= 0 && c < uv_w;
+  const bool owned = c >= own0 && c < own1;
+  // the neighbours' places in the LDS row (a column at the picture's edge is its own neighbour, as in the reference;
+  // one at the workgroup's edge has none -- it is the first to go invalid, whatever it reads)
+  const int tl = (c > 0 && tid > 0) ? tid - 1 : tid, tr = (c < uv_w - 1 && tid < kStripThreads - 1) ? tid + 1 : tid;
+  const int s_lo = strip > 0 ? strip - 1 : 0, s_hi = strip < nstrips - 1 ? strip + 1 : strip;
+
+  struct RowData { int uv[3][3]; uint32_t wy[2], ty[2]; int tuv[3]; };
+  auto load_uv = [&](int row, int (&dst)[3][3]) {
+    const int cl = c > 0 ? c - 1 : 0, cr = c < uv_w - 1 ? c + 1 : uv_w - 1;
+    const int16_t* r = in_uv + static_cast<size_t>(row) * 3 * uv_w;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { dst[k][0] = r[k * uv_w + cl]; dst[k][1] = r[k * uv_w + c]; dst[k][2] = r[k * uv_w + cr]; }
+  };
+  auto load_rest = [&](int ry, RowData& d) {
+    d.wy[0] = reinterpret_cast<const uint32_t*>(in_y + static_cast<size_t>(2 * ry) * w)[c];
+    d.wy[1] = reinterpret_cast<const uint32_t*>(in_y + static_cast<size_t>(2 * ry + 1) * w)[c];
+    d.ty[0] = reinterpret_cast<const uint32_t*>(target_y + static_cast<size_t>(2 * ry) * w)[c];
+    d.ty[1] = reinterpret_cast<const uint32_t*>(target_y + static_cast<size_t>(2 * ry + 1) * w)[c];
+    const int16_t* tu = target_uv + static_cast<size_t>(ry) * 3 * uv_w;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) d.tuv[k] = tu[k * uv_w + c];
+  };
+  // Waits until strips s_lo .. s_hi of sweep `tt` have all finished `want` row pairs (visible here), or a sweep has been
+  // named the final one (returns -1).  Returns the least of the three counters.
+  auto wait_strips = [&](int tt, int want, bool self_too) -> int {
+    if (tid == 0) {
+      int seen = 0x7fffffff;
+      for (int s = s_lo; s <= s_hi && seen >= 0; ++s) {
+        if (!self_too && s == strip) continue;
+        for (;;) {
+          if (__hip_atomic_load(&ctrl[16], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 0u) { seen = -1; break; }
+          const int p = static_cast<int>(__hip_atomic_load(&progress[tt * nstrips + s], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT));
+          if (p >= want) { seen = p < seen ? p : seen; break; }
+          __builtin_amdgcn_s_sleep(8);
+        }
+      }
+      go = seen;
+    }
+    __syncthreads();
+    const int g = go;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");     // every wave's loads behind this see the producers' rows
+    __syncthreads();                                // (`go` is rewritten by the next call)
+    return g;
+  };
+  constexpr int kAhead = 16;
+  int known = t == 0 ? uv_h : 0;                    // row pairs of the sweep before known to be done in all three strips
+  auto wait_for = [&](int need) -> bool {
+    if (need > uv_h) need = uv_h;
+    if (known >= need) return true;
+    const int g = wait_strips(t - 1, need + kAhead < uv_h ? need + kAhead : uv_h, true);
+    if (g < 0) return false;
+    known = g;
+    return true;
+  };
+  SHARP_RACE_POINT(40);
+  __syncthreads();
+  if (tid == 0 && strip == 0) ctrl[18 + 2 * t] = static_cast<uint32_t>(__builtin_amdgcn_s_memrealtime());
+  unsigned long long diff = 0;
+  bool wanted = wait_for(3);
+  if (wanted) {
+    // (a step is shorter than a trip to memory now: what a row pair needs is asked for TWO steps ahead)
+    RowData now, ahead, ahead2;
+    int nxt[3][3];
+    if (live) {
+      load_uv(0, now.uv);
+      load_rest(0, now);
+      load_uv(uv_h > 1 ? 1 : 0, nxt);
+      if (uv_h > 1) { load_rest(1, ahead); load_uv(uv_h > 2 ? 2 : 1, ahead.uv); }
+#pragma unroll
+      for (int k = 0; k < 3; ++k) above[0][k][tid] = static_cast<int16_t>(now.uv[k][1]);   // row pair 0: "above" is the row itself
+    }
+    SHARP_RACE_POINT(42);
+    __syncthreads();
+    for (int ry = 0; ry < uv_h; ++ry) {
+      const int pp = ry & 1;
+      SHARP_RACE_POINT(43);
+      if (ry > 0 && (ry % kStripHalo) == 0 && nstrips > 1) {
+        // the strips of this sweep meet: the halo's row above comes from the neighbours' output (row ry - 1)
+        SHARP_RACE_POINT(47);
+        if (wait_strips(t, ry, false) < 0) { wanted = false; break; }
+        if (live && !owned) {
+          const int16_t* const r = out_uv + static_cast<size_t>(ry - 1) * 3 * uv_w;
+#pragma unroll
+          for (int k = 0; k < 3; ++k) above[pp][k][tid] = r[k * uv_w + c];       // (behind wait_strips' acquire)
+        }
+        __syncthreads();
+      }
+      if (ry + 2 < uv_h) {
+        wanted = wait_for(ry + 4);
+        if (!wanted) break;
+        if (live) {
+          load_rest(ry + 2, ahead2);
+          load_uv(ry + 3 < uv_h ? ry + 3 : ry + 2, ahead2.uv);     // becomes `nxt` two steps on
+        }
+      }
+      if (live) {
+        const int wy[2][2] = {{static_cast<int>(now.wy[0] & 0xffffu), static_cast<int>(now.wy[0] >> 16)},
+                              {static_cast<int>(now.wy[1] & 0xffffu), static_cast<int>(now.wy[1] >> 16)}};
+        const int ty[2][2] = {{static_cast<int>(now.ty[0] & 0xffffu), static_cast<int>(now.ty[0] >> 16)},
+                              {static_cast<int>(now.ty[1] & 0xffffu), static_cast<int>(now.ty[1] >> 16)}};
+        int px[2][2][3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const int A = now.uv[k][1], Al = now.uv[k][0], Ar = now.uv[k][2];
+          const int P = above[pp][k][tid], Pl = above[pp][k][tl], Pr = above[pp][k][tr];
+          const bool has_next = ry + 1 < uv_h;
+          const int N = has_next ? nxt[k][1] : A, Nl = has_next ? nxt[k][0] : Al, Nr = has_next ? nxt[k][2] : Ar;
+          int up0, up1, dn0, dn1;
+          if (c == 0) { up0 = (A * 3 + P + 2) >> 2; dn0 = (A * 3 + N + 2) >> 2; }
+          else { up0 = (A * 9 + Al * 3 + P * 3 + Pl + 8) >> 4; dn0 = (A * 9 + Al * 3 + N * 3 + Nl + 8) >> 4; }
+          if (c == uv_w - 1) { up1 = (A * 3 + P + 2) >> 2; dn1 = (A * 3 + N + 2) >> 2; }
+          else { up1 = (A * 9 + Ar * 3 + P * 3 + Pr + 8) >> 4; dn1 = (A * 9 + Ar * 3 + N * 3 + Nr + 8) >> 4; }
+          px[0][0][k] = clip_y(wy[0][0] + up0); px[0][1][k] = clip_y(wy[0][1] + up1);
+          px[1][0][k] = clip_y(wy[1][0] + dn0); px[1][1][k] = clip_y(wy[1][1] + dn1);
+        }
+        int wt[2][2], uv[3];
+        eval_group(g2l, l2g, px, wt, uv);
+        uint32_t newy[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          int ny[2];
+#pragma unroll
+          for (int cc = 0; cc < 2; ++cc) {
+            const int d = ty[r][cc] - wt[r][cc];
+            ny[cc] = clip_y(wy[r][cc] + d);
+            if (owned) diff += static_cast<unsigned long long>(d < 0 ? -d : d);
+          }
+          newy[r] = static_cast<uint32_t>(ny[0]) | (static_cast<uint32_t>(ny[1]) << 16);
+        }
+        // (the rows go out as agent-scope stores -- write-through, `sc1` -- so that publishing them needs no release
+        // fence: that is an L2 write-back of whatever is dirty, per workgroup and hand-over, and with twenty times the
+        // workgroups of the one-per-sweep kernel it halved the throughput of a batch)
+        if (owned) {
+          __hip_atomic_store(&reinterpret_cast<uint32_t*>(out_y + static_cast<size_t>(2 * ry) * w)[c], newy[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(&reinterpret_cast<uint32_t*>(out_y + static_cast<size_t>(2 * ry + 1) * w)[c], newy[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const int16_t nv = static_cast<int16_t>(now.uv[k][1] + (now.tuv[k] - uv[k]));
+          if (owned) __hip_atomic_store(&out_uv[static_cast<size_t>(ry) * 3 * uv_w + k * uv_w + c], nv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          above[pp ^ 1][k][tid] = nv;
+        }
+      }
+      SHARP_RACE_POINT(44);
+      // hand-over (to the next sweep, and to the neighbour strips of this one): every wave's stores are acknowledged in
+      // front of the barrier (written through, see above), the counter behind it is a store of the same kind
+      const bool hand_over = (ry & 7) == 7 || ry + 1 == uv_h;
+      if (hand_over) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+      } else {
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      }
+      SHARP_RACE_POINT(45);
+      if (hand_over && tid == 0) {
+        __hip_atomic_store(&progress[t * nstrips + strip], static_cast<uint32_t>(ry + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { now.uv[k][q] = nxt[k][q]; nxt[k][q] = ahead.uv[k][q]; ahead.uv[k][q] = ahead2.uv[k][q]; }
+        now.tuv[k] = ahead.tuv[k]; ahead.tuv[k] = ahead2.tuv[k];
+      }
+      now.wy[0] = ahead.wy[0]; now.wy[1] = ahead.wy[1];
+      now.ty[0] = ahead.ty[0]; now.ty[1] = ahead.ty[1];
+      ahead.wy[0] = ahead2.wy[0]; ahead.wy[1] = ahead2.wy[1];
+      ahead.ty[0] = ahead2.ty[0]; ahead.ty[1] = ahead2.ty[1];
+    }
+  }
+  if (tid == 0 && strip == 0) ctrl[19 + 2 * t] = static_cast<uint32_t>(__builtin_amdgcn_s_memrealtime());
+  if (!wanted) return;                              // (uniform: an earlier sweep is the final one)
+  // exit test (:660-666): the sweep's sum of |dW| over the picture = the strips' sums; the last strip to arrive takes it
+  for (int d = 32; d > 0; d >>= 1) diff += __shfl_down(diff, d, 64);
+  if ((tid & 63) == 0) red[tid >> 6] = diff;
+  SHARP_RACE_POINT(46);
+  __syncthreads();
+  if (tid == 0) {
+    unsigned long long mine = 0;
+    for (int i = 0; i < kStripThreads / 64; ++i) mine += red[i];
+    unsigned long long* const sum_t = reinterpret_cast<unsigned long long*>(ctrl + 8 + 2 * t);
+    __hip_atomic_fetch_add(sum_t, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t arrived = __hip_atomic_fetch_add(&ctrl[t], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (arrived + 1u == static_cast<uint32_t>(nstrips)) {
+      const unsigned long long sum = __hip_atomic_load(sum_t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      bool cancelled = false;
+      unsigned long long prev = ~0ull;
+      if (t > 0) {
+        while (__hip_atomic_load(&ctrl[4 + t - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+          if (__hip_atomic_load(&ctrl[16], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+          __builtin_amdgcn_s_sleep(4);
+        }
+        cancelled = __hip_atomic_load(&ctrl[16], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+        prev = __hip_atomic_load(reinterpret_cast<unsigned long long*>(ctrl + 8 + 2 * (t - 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if (!cancelled) {
+        const bool stop = t > 0 && (sum < threshold || sum > prev);
+        if (stop || t == 3) {
+          ctrl[17] = static_cast<uint32_t>(t);
+          __hip_atomic_store(&ctrl[16], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __hip_atomic_store(&ctrl[4 + t], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
+}
+
 // ---- back to 8-bit planes (:543-575; this file's own -11058 / -5328 constants)
 __global__ __launch_bounds__(256) void sharp_export(const SharpArgs a) {
   const int frame = blockIdx.z;
   const int c = blockIdx.x * 256 + threadIdx.x, ry = blockIdx.y;
   if (c >= a.uv_w) return;
   // (pipelined sweeps: the plane the last sweep that counts wrote)
-  const int plane = a.nplanes == 3 ? static_cast<int>((a.ctrl[frame * 32 + 17] + 1u) % 3u) : 0;
+  const int plane = a.nplanes == 3 ? static_cast<int>((a.ctrl[static_cast<size_t>(frame) * a.ctrl_words + 17] + 1u) % 3u) : 0;
   const size_t pf = static_cast<size_t>(plane) * a.nframes + frame;
   const size_t uo = (pf * a.uv_h + ry) * 3 * a.uv_w;
   const int r = a.best_uv[uo + c], g = a.best_uv[uo + a.uv_w + c], b = a.best_uv[uo + 2 * a.uv_w + c];
@@ -773,7 +1021,8 @@ size_t sjpeg_hip_sharp_workspace(int width, int height, int nframes) {
   const size_t w = (static_cast<size_t>(width) + 1) & ~size_t(1), h = (static_cast<size_t>(height) + 1) & ~size_t(1);
   // (three planes of W and chroma for the pipelined sweeps + the two target arrays, the side row of the in-place
   // kernel, the sweeps' control words)
-  const size_t per = 4 * align256(w * h * 2) + 4 * align256(3 * (w / 2) * (h / 2) * 2) + align256(3 * (w / 2) * 2) + 256;
+  const size_t strips = (w / 2 + kStripOwn - 1) / kStripOwn;
+  const size_t per = 4 * align256(w * h * 2) + 4 * align256(3 * (w / 2) * (h / 2) * 2) + align256(3 * (w / 2) * 2) + align256((32 + 4 * strips) * 4);
   return align256(sizeof(GammaTables)) + per * static_cast<size_t>(nframes);
 }
 
@@ -827,12 +1076,37 @@ int sjpeg_hip_sharp_yuv(const sjpeg_hip_source* src, int width, int height, int 
   const dim3 grid((a.uv_w + 255) / 256, a.uv_h, nframes);
   // SJPEG_HIP_SHARP_INPLACE=1: round 3's one-workgroup-per-picture sweeps (A/B, and the fallback for very wide pictures)
   static const bool inplace = getenv("SJPEG_HIP_SHARP_INPLACE") != nullptr && atoi(getenv("SJPEG_HIP_SHARP_INPLACE")) != 0;
-  const bool piped = !inplace && a.uv_w <= kFastCols * kSweepThreads;
+  // SJPEG_HIP_SHARP_STRIPS=0: round 4's one workgroup per picture and sweep (A/B)
+  static const bool no_strips = getenv("SJPEG_HIP_SHARP_STRIPS") != nullptr && atoi(getenv("SJPEG_HIP_SHARP_STRIPS")) == 0;
+  const int nstrips = (a.uv_w + kStripOwn - 1) / kStripOwn;
+  const bool strips = !inplace && !no_strips;
+  const bool piped = !inplace && (strips || a.uv_w <= kFastCols * kSweepThreads);
   a.nplanes = piped ? 3 : 1;
-  if (piped && hipMemsetAsync(a.ctrl, 0, static_cast<size_t>(nframes) * 32 * sizeof(uint32_t), st) != hipSuccess) return SJPEG_HIP_ERUNTIME;
+  a.ctrl_words = strips ? 32 + 4 * nstrips : 32;
+  if (piped && hipMemsetAsync(a.ctrl, 0, static_cast<size_t>(nframes) * a.ctrl_words * sizeof(uint32_t), st) != hipSuccess) return SJPEG_HIP_ERUNTIME;
   hipLaunchKernelGGL(sharp_import, grid, dim3(256), 0, st, a);
   a.frame0 = 0;
-  if (piped) {
+  if (strips) {
+    // (as below: a launch never has more workgroups than are resident at once -- 4 * strips small workgroups a picture,
+    // as many a CU as the occupancy query says)
+    static const int kSlots = [] {
+      if (const char* e = getenv("SJPEG_HIP_SHARP_SLOTS")) { const int v = atoi(e); if (v > 0) return v; }   // (A/B)
+      int dev = 0, cus = 0, per_cu = 0;
+      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+          hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sharp_sweeps_strips, kStripThreads, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        return 16;
+      }
+      const int all = cus * per_cu;               // what the device holds of this kernel at once; three quarters of it a launch
+      return all < 32 ? 16 : all / 4 * 3;
+    }();
+    const int chunk = kSlots / (4 * nstrips) < 1 ? 1 : kSlots / (4 * nstrips);
+    for (int f0 = 0; f0 < nframes; f0 += chunk) {
+      a.frame0 = f0;
+      hipLaunchKernelGGL(sharp_sweeps_strips, dim3(nstrips, 4, nframes - f0 < chunk ? nframes - f0 : chunk), dim3(kStripThreads), 0, st, a);
+    }
+    a.frame0 = 0;
+  } else if (piped) {
     // A sweep spins on the counter of the sweep before it, another workgroup of the same launch: that only ends if
     // the producer is resident.  A launch therefore never has more workgroups than the device holds at once --
     // chunks of pictures, four workgroups of 1024 threads each, one per CU on at most half the chip (the whole
@@ -858,9 +1132,10 @@ int sjpeg_hip_sharp_yuv(const sjpeg_hip_source* src, int width, int height, int 
   else hipLaunchKernelGGL(sharp_sweeps, dim3(nframes), dim3(kSweepThreads), 0, st, a);
   hipLaunchKernelGGL(sharp_export, grid, dim3(256), 0, st, a);
   if (piped && getenv("SJPEG_HIP_SHARP_DEBUG") != nullptr) {        // when the four sweeps of frame 0 ran (10 ns ticks), who was final
-    uint32_t c[32];
+    uint32_t c[36];
     if (hipMemcpyAsync(c, a.ctrl, sizeof(c), hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess) {
-      fprintf(stderr, "sharp sweeps: final %u, rows done %u %u %u %u of %d;", c[17], c[0], c[1], c[2], c[3], a.uv_h);
+      if (strips) fprintf(stderr, "sharp sweeps, %d strips: final %u, strips arrived %u %u %u %u;", nstrips, c[17], c[0], c[1], c[2], c[3]);
+      else fprintf(stderr, "sharp sweeps: final %u, rows done %u %u %u %u of %d;", c[17], c[0], c[1], c[2], c[3], a.uv_h);
       for (int t = 0; t < 4; ++t) fprintf(stderr, " [%d] %.1f..%.1f us", t, (c[18 + 2 * t] - c[18]) / 100.0, (c[19 + 2 * t] - c[18]) / 100.0);
       fprintf(stderr, "\n");
     }

@@ -1154,6 +1154,45 @@ def test_sharp_sweeps_as_a_pipeline_of_workgroups(oracle):
                     np.array_equal(v[k].cpu().numpy(), want[k][2]), (w, h, k, rep)
 
 
+def test_sharp_sweeps_in_strips_across_the_width(oracle):
+    """Round 6: a sweep is cut into strips of 192 chroma columns (a workgroup each, 32 columns of halo computed on either
+    side) which meet every 32 row pairs (sharp_sweeps_strips): widths at and around the strips' edges, one to five
+    strips, fewer row pairs than one block and several blocks, pictures that stop after the second sweep and ones that
+    never do, batches, 4-byte pixels."""
+    rng = np.random.RandomState(45)
+    def sat(h, w):
+        return (rng.randint(0, 2, (h, w, 3)) * 255).astype(np.uint8)
+    for (w, h, n) in ((383, 66, 2), (384, 70, 3), (385, 131, 2), (386, 64, 1), (448, 258, 2), (770, 67, 3), (1153, 140, 2), (1537, 99, 1)):
+        imgs = []
+        for k in range(n):
+            kind = (k + w) % 3
+            imgs.append(synth.g_struct(w, h, 160 + k) if kind == 0 else rng.randint(0, 256, (h, w, 3)).astype(np.uint8) if kind == 1 else sat(h, w))
+        want = [oracle.sharp_yuv(im) for im in imgs]
+        batch = torch.from_numpy(np.stack(imgs).reshape(n, h, 3 * w)).cuda()
+        rgba = np.stack([np.concatenate([im, np.full((h, w, 1), 9, np.uint8)], 2) for im in imgs])
+        for fmt, b in ((sj.SRC_RGB, batch), (sj.SRC_RGBA, torch.from_numpy(rgba.reshape(n, h, 4 * w)).cuda())):
+            for rep in range(2):
+                y, u, v = sj.sharp_yuv(fmt, b)
+                for k in range(n):
+                    assert np.array_equal(y[k].cpu().numpy(), want[k][0]) and np.array_equal(u[k].cpu().numpy(), want[k][1]) and \
+                        np.array_equal(v[k].cpu().numpy(), want[k][2]), (w, h, k, fmt, rep)
+
+
+def test_sharp_kernels_before_the_strips():
+    """The one-workgroup-per-sweep pipeline (SJPEG_HIP_SHARP_STRIPS=0) and the in-place sweeps (SJPEG_HIP_SHARP_INPLACE=1)
+    stay in the library for A/B runs: the file's sharp tests once more in processes that take them."""
+    import subprocess
+    import sys
+    if os.environ.get("SJPEG_SHARP_INNER"):
+        pytest.skip("inner run")
+    for knob in ("SJPEG_HIP_SHARP_STRIPS=0", "SJPEG_HIP_SHARP_INPLACE=1"):
+        k, v = knob.split("=")
+        env = dict(os.environ, SJPEG_SHARP_INNER="1", **{k: v})
+        r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-x", "-q", "-k",
+                            "sharp_yuv or sharp_sweeps or sharp_and_auto"], env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, (knob, r.stdout[-2000:], r.stderr[-1000:])
+
+
 def test_adaptive_analysis_on_device_equals_host(engine):
     """AnalyseHisto's bin loops on the GPU (sjpeg_hip_adapt_sums) + the float half on the host ==
     the all-host analysis (which the CPU tests pin against the oracle), incl. min-quant limits."""

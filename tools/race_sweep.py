@@ -49,7 +49,7 @@ print(f"race sweep K1: {runs} encodes over 26 points x 4 waves, lagging and lead
 import hashlib  # noqa: E402
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 img128 = np.fromfile(os.path.join(ROOT, "tests", "golden", "test128.rgb"), np.uint8).reshape(128, 128, 3)
-small = synth.g_struct(301, 203, 9)
+small = synth.g_struct(801, 203, 9)               # three strips of chroma columns that meet three times (sharp_sweeps_strips)
 wide = synth.g_struct(4242, 10, 11)               # chroma rows of 2121 > 2048 columns: sharp_sweeps
 want_small = o.encode_method(small, 80.0, 2, 4)
 want_wide = o.encode_method(wide, 75.0, 2, 0)
