@@ -230,8 +230,10 @@ int sjpeg_hip_engine_entropy_bits(sjpeg_hip_engine* engine, uint64_t* bits, int 
  * the result is three tightly packed 8-bit planes per frame: Y width x height, U and V
  * ((width+1)/2) x ((height+1)/2), frames y_frame_stride / uv_frame_stride bytes apart -- exactly
  * what a SJPEG_HIP_SRC_YUV420 source of sjpeg_hip_encode_scan_src() then takes.  The row pairs of
- * a picture are sequential by construction (in-place sweeps), pictures of a batch run in
- * parallel.  d_workspace: sjpeg_hip_sharp_workspace() bytes of device memory. */
+ * a sweep are sequential by construction (a row pair reads the row above as this sweep left it); the
+ * columns of a row pair, the up to four sweeps of a picture (a pipeline a few row pairs apart) and
+ * the pictures of a batch run in parallel.  Any width.  d_workspace: sjpeg_hip_sharp_workspace()
+ * bytes of device memory. */
 size_t sjpeg_hip_sharp_workspace(int width, int height, int nframes);
 int sjpeg_hip_sharp_yuv(const sjpeg_hip_source* src, int width, int height, int nframes,
                         uint8_t* d_y, uint8_t* d_u, uint8_t* d_v, int64_t y_frame_stride,

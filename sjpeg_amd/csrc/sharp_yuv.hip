@@ -6,9 +6,10 @@
 // gamma-correct targets and feed the differences back.  A sweep walks the row pairs top to bottom
 // and updates the chroma rows IN PLACE -- the row above a pair already belongs to this sweep, the
 // row below still to the previous one -- so the row pairs of one sweep are inherently
-// sequential; the parallelism is across the width of a row pair (one workgroup per picture and sweep,
-// barriers between row pairs), across the SWEEPS of a picture (sharp_sweeps_piped: sweep t + 1 runs a few
-// row pairs behind sweep t in a workgroup of its own, on versioned planes instead of in place) and across
+// sequential; the parallelism is across the width of a row pair (sharp_sweeps_strips, round 6: strips of
+// columns, a workgroup each on a CU of its own, which meet every 32 row pairs; before that one workgroup per
+// picture and sweep with barriers between row pairs), across the SWEEPS of a picture (sweep t + 1 runs a few
+// row pairs behind sweep t in workgroups of its own, on versioned planes instead of in place) and across
 // the pictures of a batch.  The import and the final conversion have no such dependency and run one
 // thread per chroma sample.
 //
