@@ -741,8 +741,10 @@ __global__ __launch_bounds__(kStripThreads) void sharp_sweeps_strips(const Sharp
       for (int s = s_lo; s <= s_hi && seen >= 0; ++s) {
         if (!self_too && s == strip) continue;
         for (;;) {
-          if (__hip_atomic_load(&ctrl[16], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 0u) { seen = -1; break; }
-          const int p = static_cast<int>(__hip_atomic_load(&progress[tt * nstrips + s], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT));
+          // (relaxed looks: an acquire load is a load AND a cache invalidate, per look and waiting workgroup; the one
+          // acquire that matters is the fence behind the barrier below)
+          if (__hip_atomic_load(&ctrl[16], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { seen = -1; break; }
+          const int p = static_cast<int>(__hip_atomic_load(&progress[tt * nstrips + s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
           if (p >= want) { seen = p < seen ? p : seen; break; }
           __builtin_amdgcn_s_sleep(8);
         }
