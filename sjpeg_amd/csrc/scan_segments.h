@@ -64,13 +64,14 @@ __device__ __forceinline__ void race_point(int code, int n) {
 #define RACE_POINT(n)
 #endif
 
-// (the histogram kind needs the block slots and nothing else in LDS: four workgroups per CU instead of
-// three, with its registers held to the 128 that leaves room for -- 131 without the bound.  Packed RGB
-// only: ROCm 7.2's clang crashes in its register allocator on the 4-byte-pixel instantiation with the
-// smaller LDS block)
+// (the histogram kind is compiled for the THREE persistent workgroups per CU it runs as: 168 registers.  Held to the 128
+// of four per CU -- what rounds 4 and 5 shipped, from when it ran four -- it spilt ten registers' worth of loop-invariant
+// values that every segment reloaded from private memory: pass 0.217 -> 0.204 ms per 16 4K frames, the default-parameter
+// calls 2-2.5 % (round 6).  Packed RGB only: ROCm 7.2's clang crashes in its register allocator on the 4-byte-pixel
+// instantiation with the smaller LDS block)
 // the compact LDS layout (scan_device.h): four workgroups per CU
 #ifndef SJPEG_HISTO_WGS
-#define SJPEG_HISTO_WGS 4          // workgroups per CU the histogram kind is compiled for (experiments: 3)
+#define SJPEG_HISTO_WGS 3          // workgroups per CU the histogram kind is compiled for (A/B: 4)
 #endif
 template <int MODE, int KINDX, int SRC>
 constexpr bool kCompactLds = (KINDX == kKindEncode || KINDX == kKindEncodeReplay || KINDX == kKindStats || KINDX == kKindStatsCoef);
