@@ -15,6 +15,11 @@ for c in c2noise c3x4 c3x1 c4 one4k m4 c5m0 c5m4; do
   [ -f $P/$c.log ] && grep "ms/step" $P/$c.log > $D/${c}_line.txt
   [ -f $P/${c}_pmc_summary.txt ] && cp $P/${c}_pmc_summary.txt $D/
 done
+for c in trellis1080 trellis4k sharp1080 sharp4k; do
+  [ -f $P/${c}_kernel_stats.csv ] && cut -c1-200 $P/${c}_kernel_stats.csv | head -12 > $D/${c}_kernel_stats.csv
+  [ -f $P/${c}_line.txt ] && cp $P/${c}_line.txt $D/
+done
+[ -f $P/sharp_batches.txt ] && cp $P/sharp_batches.txt $D/
 cp gpurun_out/$TAG/final_bench.json $D/final_bench.json
 cp gpurun_out/$TAG/exchange_n1.json $D/exchange_n1.json
 ls $D
