@@ -17,6 +17,7 @@ N=1 run python tests/lanes_check.py
 N=1 run python tools/gpu_soak.py 1 "${SOAK:-120}"
 N=1 run python tools/sharp_soak.py "${SOAK:-60}" 1
 N=1 run python tools/thread_soak.py 16 100
+N=1 run python tools/sharp_threads.py 8 60
 N=2 run python tools/engine_churn.py 100
 N=5 run python tools/many_frames_check.py
 if command -v hipcc >/dev/null 2>&1 || [ -x /opt/rocm/bin/hipcc ]; then
