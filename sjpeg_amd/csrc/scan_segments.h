@@ -741,7 +741,6 @@ __global__ __launch_bounds__(kScanThreads, ((KINDX == kKindHisto && SRC == kSrcR
     // src/quantize.cc:325-457): the slot holds the RAW coefficients in zig-zag order.  For every
     // coefficient that does not quantize to zero, two candidate levels become nodes of a graph;
     // an edge costs distortion + lambda * bits (bits priced with the AC code lengths in `tl`).
-    // One thread per block, nodes in private memory: a correct, not a fast, path.
     typedef int16_t __attribute__((may_alias)) i16_alias;
     typedef uint16_t __attribute__((may_alias)) u16_alias2;
     const i16_alias* const raw = reinterpret_cast<const i16_alias*>(slot);
