@@ -233,7 +233,9 @@ int sjpeg_hip_engine_entropy_bits(sjpeg_hip_engine* engine, uint64_t* bits, int 
  * a sweep are sequential by construction (a row pair reads the row above as this sweep left it); the
  * columns of a row pair, the up to four sweeps of a picture (a pipeline a few row pairs apart) and
  * the pictures of a batch run in parallel.  Any width.  d_workspace: sjpeg_hip_sharp_workspace()
- * bytes of device memory. */
+ * bytes of device memory.  (Environment, read once, for A/B runs only: SJPEG_HIP_SHARP_STRIPS=0 takes
+ * the kernel with one workgroup per picture and sweep, SJPEG_HIP_SHARP_INPLACE=1 the in-place sweeps;
+ * same planes.) */
 size_t sjpeg_hip_sharp_workspace(int width, int height, int nframes);
 int sjpeg_hip_sharp_yuv(const sjpeg_hip_source* src, int width, int height, int nframes,
                         uint8_t* d_y, uint8_t* d_u, uint8_t* d_v, int64_t y_frame_stride,
