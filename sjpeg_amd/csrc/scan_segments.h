@@ -810,38 +810,45 @@ __global__ __launch_bounds__(kScanThreads, ((KINDX == kKindHisto && SRC == kSrcR
             const uint32_t base_disto = static_cast<uint32_t>(__mul24(err, err)) + dprev;
             // (the newest nodes are in registers: the walk mostly ends there, and every private-memory read is a trip
             // to HBM -- three workgroups' node arrays are no L2's size -- that a wave waits ~1 000 cycles for)
-            auto price = [&](const uint4& cur, int c) -> bool {      // true: the walk stops at this node
+            // Pricing one node is PREDICATED, not branched: a lane whose walk has stopped (or has no such node) goes
+            // through the same instructions and keeps its values -- the nested ifs of the first form cost as many scalar
+            // instructions (exec masks saved, combined, restored) as vector ones; one uniform test per node ends the
+            // walk when no lane is at it any more.
+            bool walking = true;
+            auto price = [&](const uint4& cur, int c) {
               const int run = i - 1 - static_cast<int>((cur.y >> 12) & 63u);
-              if (run < 0) return false;
-              uint32_t bits = static_cast<uint32_t>(nbits) + __umul24(static_cast<uint32_t>(run >> 4), zrl_len);
-              const uint32_t disto = base_disto - cur.z;
-              const uint32_t len = tl[((run & 15) << 4) | nbits];     // (asked for before the test it may not survive)
-              if (disto + __umul24(lambda, bits) >= my_score) return true;
-              bits += len;
-              const uint32_t score = disto + __umul24(lambda, bits) + cur.x;
-              if (score < my_score) { my_score = score; my_prev = static_cast<uint32_t>(c); found = true; }
-              return false;
+              const bool here = walking && c >= 0 && run >= 0;           // (run < 0: the other node of this position -- skipped, the walk goes on)
+              const uint32_t bits0 = static_cast<uint32_t>(nbits) + __umul24(static_cast<uint32_t>(run >> 4) & 3u, zrl_len);
+              const uint32_t bound = base_disto - cur.z + __umul24(lambda, bits0);
+              const uint32_t len = tl[((run & 15) << 4) | nbits];
+              const bool stop = here && bound >= my_score;
+              const uint32_t score = bound + __umul24(lambda, len) + cur.x;
+              const bool better = here && !stop && score < my_score;
+              my_score = better ? score : my_score;
+              my_prev = better ? static_cast<uint32_t>(c) : my_prev;
+              found = found || better;
+              walking = walking && !stop && c > 0;
             };
-            bool stop = false;
 #pragma unroll
             for (int r = 0; r < kRing; ++r) {
-              if (!stop && count - 1 - r >= 0) stop = price(ring[r], count - 1 - r);
+              if (__builtin_amdgcn_ballot_w64(walking && count - 1 - r >= 0) == 0ull) break;
+              price(ring[r], count - 1 - r);
             }
-            if (!stop && count > kRing) {
-              // the older nodes: four records in flight (some lane of the wave walks deep at most nodes, and the trips
-              // to private memory are independent of each other -- a record asked for only one ahead left ~900 of its
-              // ~1 000 cycles in the open at every step)
-              int c = count - 1 - kRing;
-              uint4 f0 = node[c], f1 = node[max(c - 1, 0)], f2 = node[max(c - 2, 0)], f3 = node[max(c - 3, 0)];
+            walking = walking && count > kRing;
+            if (__builtin_amdgcn_ballot_w64(walking) != 0ull) {
+              // the older nodes: four records in flight (the trips to private memory are independent of each other)
+              int c = count - 1 - kRing;                                // (per lane; a lane that is not walking reads node 0)
+              auto at = [&](int k) { const int x = walking ? c - k : 0; return node[x > 0 ? x : 0]; };
+              uint4 f0 = at(0), f1 = at(1), f2 = at(2), f3 = at(3);
               for (;;) {
-                if (price(f0, c) || c == 0) break;
-                --c; f0 = node[max(c - 3, 0)];
-                if (price(f1, c) || c == 0) break;
-                --c; f1 = node[max(c - 3, 0)];
-                if (price(f2, c) || c == 0) break;
-                --c; f2 = node[max(c - 3, 0)];
-                if (price(f3, c) || c == 0) break;
-                --c; f3 = node[max(c - 3, 0)];
+                price(f0, c); if (__builtin_amdgcn_ballot_w64(walking) == 0ull) break;
+                --c; f0 = at(3);
+                price(f1, c); if (__builtin_amdgcn_ballot_w64(walking) == 0ull) break;
+                --c; f1 = at(3);
+                price(f2, c); if (__builtin_amdgcn_ballot_w64(walking) == 0ull) break;
+                --c; f2 = at(3);
+                price(f3, c); if (__builtin_amdgcn_ballot_w64(walking) == 0ull) break;
+                --c; f3 = at(3);
               }
             }
             if (found) {
